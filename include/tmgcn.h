@@ -1,0 +1,121 @@
+/*
+ * tmgcn.h — C-ABI of the MI355X (gfx950) TM-GCN propagation layer.
+ *
+ * This is the drop-in boundary for the ONE hot path of IBM/TM-GCN: the tensor
+ * M-product graph-convolution layer  Y = (Â ⋆_M X) W  forward and backward.
+ * The reference has no FFI of its own (it is flat PyTorch-CPU Python); every
+ * entry point below names the reference statement(s) it replaces, relative to
+ * TensorGCN-master/embedding_help_functions.py ("ehf").  INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (hipMalloc / torch ROCm storage) unless
+ *     the parameter name ends in _host.  No torch types cross this boundary.
+ *   - All tensors are dense row-major with the innermost dimension contiguous.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every
+ *     launcher is asynchronous on that stream, allocates nothing and never
+ *     synchronises, so a caller may capture it into a hipGraph.
+ *   - Return value: 0 on success, a negative tmgcn_status otherwise;
+ *     tmgcn_last_error() returns a thread-local message for the last failure.
+ *
+ * Data layout in HBM
+ *   feature tensor  X[T][N][F]  fp32, tube fibre stride N*F, viewed as [T][C=N*F] by P1
+ *                               and as [R=T*N][F] by P2/P3.
+ *   batched CSR     rowptr[T*N+1] int64 (global offsets into col/val; row r = k*N+i),
+ *                   col[nnz] int32 (column inside the slice, 0..N-1), val[nnz] fp32.
+ *                   Slice k is rows [k*N,(k+1)*N).  Total nnz may exceed 2^31.
+ */
+#ifndef TMGCN_H
+#define TMGCN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  TMGCN_OK = 0,
+  TMGCN_ERR_INVALID = -1,  /* bad argument (shape, null pointer, unsupported size) */
+  TMGCN_ERR_LAUNCH = -2,   /* HIP reported an error at launch                       */
+  TMGCN_ERR_WORKSPACE = -3 /* caller-provided workspace too small                   */
+} tmgcn_status;
+
+/* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
+enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
+
+int tmgcn_abi_version(void);
+const char* tmgcn_last_error(void);
+
+/* ---- P1: tube-fibre M-transform ------------------------------------------------
+ * Replaces  t.matmul(self.M, X.reshape(self.T,-1)).reshape(X.size())
+ *   ehf:204, ehf:308, ehf:404 (forward), ehf:346 (third application),
+ *   ehf:224/332/341 (Minv), and autograd's Mᵀ product in backward.
+ *
+ *   Y[k][c] = sum_{j=0..T_in-1} Mop[row_off + k][col_off + j] * X[j][c]
+ *        k = 0..T_out-1, c = 0..C-1,   Mop = M (transpose=0) or Mᵀ (transpose=1)
+ *
+ * M is a dense [Tm][Tm] fp32 matrix with leading dimension ldm.  The caller
+ * promises Mop[a][b] == 0 unless  a - band_lo <= b <= a + band_hi  (a, b are
+ * indices into Mop, offsets included); pass band_lo = band_hi = Tm for a dense M.
+ * Entries outside the promised band are never read.  X and Y must not overlap.
+ */
+int tmgcn_mtransform_f32(const float* M, int32_t Tm, int32_t ldm, int32_t transpose,
+                         int32_t row_off, int32_t col_off, int32_t T_out, int32_t T_in,
+                         int32_t band_lo, int32_t band_hi,
+                         const float* X, float* Y, int64_t C, void* stream);
+
+/* ---- P2: batched CSR SpMM (per-frontal-slice Â_k · X_k) -------------------------
+ * Replaces the loops  for k in range(T): AtXt[k] = t.sparse.mm(At[k], Xt[k])
+ *   ehf:206-207, 303-304, 310-311, 406-407, 471-472; with the transposed CSR it is
+ *   autograd's sparse.mm backward  dXt[k] = Â_kᵀ · dAtXt[k].
+ *
+ *   Y[r][f] = sum_{p=rowptr[r]}^{rowptr[r+1]-1} val[p] * X[(r / N) * N + col[p]][f]
+ *        r = 0..n_rows-1 (n_rows = T*N), f = 0..F-1
+ *
+ * Row sums are formed in a fixed order (no atomics): bitwise reproducible.
+ */
+int tmgcn_spmm_csr_batched_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                               const float* X, float* Y, int64_t n_rows, int32_t N, int32_t F,
+                               void* stream);
+/* Same, with the caller's average stored non-zeros per row (< 0: unknown); it only steers
+ * how many lanes share a row in the small-F kernel, never the result. */
+int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int32_t* col, const float* val,
+                                    const float* X, float* Y, int64_t n_rows, int32_t N,
+                                    int32_t F, float avg_nnz_per_row, void* stream);
+
+/* ---- P3: feature·weight contraction ----------------------------------------------
+ * Replaces  t.matmul(AtXt, Wt)  ehf:222, 330, 340, 344, 349, 415, 486-489.
+ *
+ *   Y[r][n] = act( sum_k A[r][k] * Wop_b[k][n] ),   b = rows_per_batch ? r / rows_per_batch : 0
+ *   Wop_b = W_b (trans_w=0, W_b is [K][Nf]) or W_bᵀ (trans_w=1, W_b is [Nf][K]);
+ *   W_b = W + b * w_batch_stride.  rows_per_batch = 0 is the reference's condensed_W
+ *   (one shared weight, ehf:189); rows_per_batch = N gives one weight per slice (ehf:191).
+ *   trans_w=1 is the backward  dA = dY · Wᵀ.
+ *   pre_act (optional, may be NULL): when act != NONE also store the pre-activation sum.
+ */
+int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* pre_act,
+                   int64_t R, int32_t K, int32_t Nf, int32_t trans_w,
+                   int64_t rows_per_batch, int64_t w_batch_stride, int32_t act, void* stream);
+
+/* Backward of P3 with respect to the weight (autograd of ehf:222 etc.):
+ *   dW_b[k][n] = sum_{r in batch b} A[r][k] * dY[r][n]
+ * workspace: tmgcn_gemm_dw_workspace_bytes() bytes of scratch on the device
+ * (partial slabs, reduced in a fixed order: bitwise reproducible).
+ */
+int64_t tmgcn_gemm_dw_workspace_bytes(int64_t R, int32_t K, int32_t Nf, int64_t rows_per_batch);
+int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW,
+                      int64_t R, int32_t K, int32_t Nf, int64_t rows_per_batch,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- P5: pointwise non-linearity between layers (ehf:284-289, 332-334, 486) -------
+ *   fwd: y = act(x);   bwd: dx = dy * act'(x)   (x = the pre-activation input)
+ */
+int tmgcn_act_fwd_f32(const float* x, float* y, int64_t n, int32_t act, void* stream);
+int tmgcn_act_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, int32_t act,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMGCN_H */

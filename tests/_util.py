@@ -1,0 +1,66 @@
+"""Helpers shared by the tests: fixture loading and tolerances."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(HERE, "golden")
+
+# Stated tolerance (SURVEY §8c / DESIGN.md §5): fp32 build vs the reference's fp64->fp32 path.
+REL_TOL = 1e-5
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def golden_names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+def coo_list(d, name, T, N, dtype=torch.float64, prefix=""):
+    """Fixture COO arrays -> the reference's list of per-slice sparse tensors."""
+    k, i, j, v = (d[f"{prefix}{name}_{s}"] for s in "kijv")
+    out = []
+    for t in range(T):
+        m = k == t
+        idx = torch.from_numpy(np.stack([i[m], j[m]]).astype(np.int64))
+        out.append(torch.sparse_coo_tensor(idx, torch.from_numpy(v[m]).to(dtype), (N, N)))
+    return out
+
+
+def max_rel_err(got, ref):
+    got = torch.as_tensor(got).double().cpu()
+    ref = torch.as_tensor(ref).double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    scale = max(float(ref.abs().max()), 1e-30)
+    return float((got - ref).abs().max()) / scale
+
+
+def assert_close(got, ref, tol=REL_TOL, what=""):
+    err = max_rel_err(got, ref)
+    assert err <= tol, f"{what}: max|Δ|/max|ref| = {err:.3e} > {tol:.1e}"
+
+
+def load_c_oracle():
+    path = os.path.join(ROOT, "oracle", "libtmgcn_ref.so")
+    if not os.path.exists(path):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = C.CDLL(path)
+    p, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.ref_mtransform.argtypes = [p, C.c_int, C.c_int, p, p, i64]
+    lib.ref_spmm.argtypes = [p, p, p, p, p, i64, i32, i32]
+    lib.ref_gemm.argtypes = [p, p, p, i64, i32, i32, i32, i64, i64]
+    lib.ref_gemm_dw.argtypes = [p, p, p, i64, i32, i32, i64]
+    for f in (lib.ref_mtransform, lib.ref_spmm, lib.ref_gemm, lib.ref_gemm_dw):
+        f.restype = None
+    return lib
+
+
+def cptr(t):
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,245 @@
+"""Generate the golden fixtures tests/golden/*.npz by running the REAL reference.
+
+Run in the build container only (needs /root/reference; the GPU box has neither the reference
+nor this need — the committed .npz files travel instead):
+
+    python tests/golden/make_golden.py
+
+What it does: imports /root/reference/TensorGCN-master/embedding_help_functions.py ("ehf",
+with an empty torchvision stub — ehf imports it but never uses it), builds small seeded inputs
+with tmgcn_amd.synth, runs the reference classes, and stores inputs + outputs + gradients.
+For G5 it also ast-extracts the preprocessing *functions* of read_data.py (a script with
+hard-coded paths that cannot be imported) and runs them on a node-subsampled slice of the one
+dataset the reference ships (data/chess), which pins tmgcn_amd.synth's restated pipeline.
+
+Fixtures are data only (arrays): no reference source text is stored.
+"""
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/TensorGCN-master"
+sys.path.insert(0, ROOT)
+
+for m in ("torchvision", "torchvision.datasets"):
+    sys.modules.setdefault(m, types.ModuleType(m))
+sys.modules["torchvision"].datasets = sys.modules["torchvision.datasets"]
+sys.path.insert(0, REF)
+import embedding_help_functions as ehf  # noqa: E402  (the real reference)
+
+import tmgcn_amd.synth as synth  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def coo_arrays(mats):
+    ks, rs, cs, vs = [], [], [], []
+    for k, m in enumerate(mats):
+        m = m.tocoo()
+        ks.append(np.full(m.nnz, k, np.int32))
+        rs.append(m.row.astype(np.int32))
+        cs.append(m.col.astype(np.int32))
+        vs.append(m.data.astype(np.float64))
+    return np.concatenate(ks), np.concatenate(rs), np.concatenate(cs), np.concatenate(vs)
+
+
+def ref_list(mats):
+    """The reference's list-of-COO form: built WITHOUT explicit size, as ehf:564 does."""
+    out = []
+    for m in mats:
+        m = m.tocoo()
+        idx = torch.tensor(np.stack([m.row, m.col]), dtype=torch.long)
+        out.append(torch.sparse.DoubleTensor(idx, torch.tensor(m.data, dtype=torch.float64)))
+    return out
+
+
+def graph_inputs(g, prefix=""):
+    d = {}
+    for name, mats in (("At", g.Ct), ("A", g.C)):
+        k, r, c, v = coo_arrays(mats)
+        d.update({f"{prefix}{name}_k": k, f"{prefix}{name}_i": r, f"{prefix}{name}_j": c, f"{prefix}{name}_v": v})
+    d[prefix + "X"] = g.X
+    d[prefix + "M"] = g.M
+    d[prefix + "edges"] = g.edges
+    d[prefix + "labels"] = g.labels
+    return d
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def loss_and_grads(model, target, alpha=0.9):
+    crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([alpha, 1.0 - alpha]))
+    out = model()
+    loss = crit(out, target)
+    model.zero_grad()
+    loss.backward()
+    return out.detach().numpy(), float(loss), {n: p.grad.detach().numpy().copy() for n, p in model.named_parameters()}
+
+
+# ------------------------------------------------------------------------------ G1
+def g1():
+    for T, N, F in ((5, 7, 2), (34, 200, 16), (5, 200, 2), (34, 7, 16)):
+        g = synth.dynamic_graph(T, N, edges_per_slice=max(4, N // 2), seed=T * 1000 + N, no_diag=min(20, T), F0=F)
+        torch.manual_seed(0)
+        m = ehf.EmbeddingGCN(ref_list(g.Ct), torch.tensor(g.X), torch.tensor(g.edges), torch.tensor(g.M),
+                             hidden_feat=[3, 2], condensed_W=True, use_Minv=False)
+        save(f"g1_AtXt_T{T}_N{N}_F{F}", AtXt=m.AtXt.numpy(), **graph_inputs(g))
+
+
+# ------------------------------------------------------------------------------ G2
+def g2():
+    g = synth.dynamic_graph(12, 60, 90, seed=2, no_diag=5)
+    base = graph_inputs(g)
+    tgt = torch.tensor(g.labels)
+    for condensed in (True, False):
+        torch.manual_seed(11)
+        m = ehf.EmbeddingGCN(ref_list(g.Ct), torch.tensor(g.X), torch.tensor(g.edges), torch.tensor(g.M),
+                             hidden_feat=[6, 2], condensed_W=condensed, use_Minv=False)
+        W0, U0 = m.W.detach().numpy().copy(), m.U.detach().numpy().copy()
+        out, loss, grads = loss_and_grads(m, tgt)
+        save(f"g2_gcn_condensed{int(condensed)}", seed=11, W0=W0, U0=U0, logits=out, loss=loss,
+             dW=grads["W"], dU=grads["U"], **base)
+    # use_Minv=True runs in the reference only with all-fp32 inputs
+    torch.manual_seed(12)
+    At32 = [a.float() for a in ref_list(g.Ct)]
+    m = ehf.EmbeddingGCN(At32, torch.tensor(g.X).float(), torch.tensor(g.edges), torch.tensor(g.M).float(),
+                         hidden_feat=[6, 2], condensed_W=True, use_Minv=True)
+    W0, U0 = m.W.detach().numpy().copy(), m.U.detach().numpy().copy()
+    out, loss, grads = loss_and_grads(m, tgt)
+    save("g2_gcn_minv_fp32", seed=12, W0=W0, U0=U0, logits=out, loss=loss, dW=grads["W"], dU=grads["U"], **base)
+
+
+# ------------------------------------------------------------------------------ G3
+def g3():
+    g = synth.dynamic_graph(10, 50, 80, seed=3, no_diag=4)
+    gv = synth.dynamic_graph(10, 50, 70, seed=33, no_diag=4)  # a "validation" window
+    base = graph_inputs(g)
+    base.update(graph_inputs(gv, prefix="val_"))
+    tgt = torch.tensor(g.labels)
+    branches = {"default": dict(), "twice": dict(apply_M_twice=True),
+                "three": dict(apply_M_twice=True, apply_M_three_times=True)}
+    for bname, kw in branches.items():
+        for nl in ("relu", "leaky", "selu"):
+            for condensed in ((True, False) if (bname == "twice" and nl == "selu") else (True,)):
+                torch.manual_seed(21)
+                m = ehf.EmbeddingGCN2(ref_list(g.Ct), torch.tensor(g.X), torch.tensor(g.edges), torch.tensor(g.M),
+                                      hidden_feat=[6, 6, 2], condensed_W=condensed, use_Minv=False, nonlin2=nl, **kw)
+                p0 = {n + "0": p.detach().numpy().copy() for n, p in m.named_parameters()}
+                out, loss, grads = loss_and_grads(m, tgt)
+                with torch.no_grad():  # validation-style call: layer 2 still uses the training At (ehf:343/348)
+                    out_val = m(ref_list(gv.Ct), torch.tensor(gv.X), torch.tensor(gv.edges)).numpy()
+                save(f"g3_gcn2_{bname}_{nl}_condensed{int(condensed)}", seed=21, logits=out, loss=loss,
+                     logits_val=out_val, dW1=grads["W1"], dW2=grads["W2"], dU=grads["U"], **p0, **base)
+
+
+# ------------------------------------------------------------------------------ G4
+def g4():
+    g = synth.dynamic_graph(9, 40, 60, seed=4, no_diag=3)
+    base = graph_inputs(g)
+    tgt = torch.tensor(g.labels)
+    for hf, nl in (([6, 2], "relu"), ([6, 5, 2], "selu"), ([6, 5, 2], "leaky")):
+        torch.manual_seed(31)
+        m = ehf.EmbeddingKWGCN(ref_list(g.C), torch.tensor(g.X), torch.tensor(g.edges), hidden_feat=hf, nonlin2=nl)
+        p0 = {n + "0": p.detach().numpy().copy() for n, p in m.named_parameters()}
+        out, loss, grads = loss_and_grads(m, tgt)
+        save(f"g4_kwgcn_{len(hf) - 1}layer_{nl}", seed=31, logits=out, loss=loss,
+             **{"d" + n: v for n, v in grads.items()}, **p0, **base)
+
+
+# ------------------------------------------------------------------------------ G5
+def extract_functions(path, names, env):
+    """Compile selected top-level function definitions of a reference script into `env`."""
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), env)
+    return env
+
+
+def g5():
+    raw = np.loadtxt(os.path.join(REF, "data/chess/out.chess.csv"), comments="%")
+    keep_nodes, TT = 300, 16
+    dates = np.unique(raw[:, 3])[:TT]
+    sel = (raw[:, 0] <= keep_nodes) & (raw[:, 1] <= keep_nodes) & np.isin(raw[:, 3], dates)
+    data = raw[sel]
+    N = keep_nodes
+    t_idx = np.searchsorted(dates, data[:, 3])
+    idx = torch.tensor(np.stack([t_idx, data[:, 0] - 1, data[:, 1] - 1]), dtype=torch.long)
+    A = torch.sparse.DoubleTensor(idx, torch.ones(idx.shape[1], dtype=torch.double), torch.Size([TT, N, N])).coalesce()
+    env = {"torch": torch, "np": np, "edge_life_window": 10, "no_diag": 20}
+    extract_functions(os.path.join(REF, "read_data.py"),
+                      {"func_make_symmetric", "func_edge_life", "func_laplacian_transformation", "func_MProduct"}, env)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        B = env["func_edge_life"](env["func_make_symmetric"](A, N, TT), N, TT)
+        Cn = env["func_laplacian_transformation"](B, N, TT)
+        # read_data.py:55-62 M: ones on 20 diagonals, row-normalised
+        M = np.zeros((TT, TT))
+        for i in range(20):
+            np.fill_diagonal(M[i:, :TT - i], 1)
+        M = M / M.sum(axis=1)[:, None]
+        Ct = env["func_MProduct"](Cn, torch.tensor(M))
+    Ai = A._indices().numpy()
+    Ci, Cv = Cn._indices().numpy(), Cn._values().numpy()
+    Ti, Tv = Ct._indices().numpy(), Ct._values().numpy()
+    # then the model on top of it (chess has 3 label classes -1/0/1; use sign>=0 as the 2-class target)
+    edges = Ai
+    labels = (np.asarray(A._values().numpy()) > 0).astype(np.int64)
+    lab_src = {(int(a), int(b), int(c)): int(w >= 0) for a, b, c, w in zip(t_idx, data[:, 0] - 1, data[:, 1] - 1, data[:, 2])}
+    labels = np.array([lab_src[(int(a), int(b), int(c))] for a, b, c in edges.T], dtype=np.int64)
+    At_list = [torch.sparse.DoubleTensor(torch.tensor(Ti[1:3, Ti[0] == k]), torch.tensor(Tv[Ti[0] == k])) for k in range(TT)]
+    Xf = torch.zeros(TT, N, 2)
+    Xf[:, :, 0] = torch.sparse.sum(A, 1).to_dense()
+    Xf[:, :, 1] = torch.sparse.sum(A, 2).to_dense()
+    torch.manual_seed(41)
+    m = ehf.EmbeddingGCN2(At_list, Xf.double(), torch.tensor(edges), torch.tensor(M), hidden_feat=[6, 6, 2],
+                          condensed_W=True, use_Minv=False, nonlin2="selu")
+    p0 = {n + "0": p.detach().numpy().copy() for n, p in m.named_parameters()}
+    out, loss, grads = loss_and_grads(m, torch.tensor(labels))
+    save("g5_chess_gcn2", seed=41, T=TT, N=N, raw_k=Ai[0].astype(np.int32), raw_i=Ai[1].astype(np.int32),
+         raw_j=Ai[2].astype(np.int32), C_k=Ci[0].astype(np.int32), C_i=Ci[1].astype(np.int32), C_j=Ci[2].astype(np.int32),
+         C_v=Cv, At_k=Ti[0].astype(np.int32), At_i=Ti[1].astype(np.int32), At_j=Ti[2].astype(np.int32), At_v=Tv,
+         M=M, X=Xf.double().numpy(), edges=edges, labels=labels, logits=out, loss=loss,
+         dW1=grads["W1"], dW2=grads["W2"], dU=grads["U"], **p0)
+
+
+# ------------------------------------------------------------------------------ G6
+def g6():
+    g = synth.dynamic_graph(10, 50, 80, seed=6, no_diag=4)
+    base = graph_inputs(g)
+    tgt = torch.tensor(g.labels)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1]))
+    for name, ctor in (
+        ("gcn", lambda: ehf.EmbeddingGCN(ref_list(g.Ct), torch.tensor(g.X), torch.tensor(g.edges), torch.tensor(g.M),
+                                          hidden_feat=[6, 2], condensed_W=True, use_Minv=False)),
+        ("gcn2", lambda: ehf.EmbeddingGCN2(ref_list(g.Ct), torch.tensor(g.X), torch.tensor(g.edges), torch.tensor(g.M),
+                                            hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False, nonlin2="selu")),
+    ):
+        torch.manual_seed(51)
+        m = ctor()
+        # scale the N(0,1) init down so that 10 SGD steps stay in a numerically tame regime
+        opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+        losses = []
+        for _ in range(10):
+            opt.zero_grad()
+            loss = crit(m(), tgt)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        final = {n + "_final": p.detach().numpy().copy() for n, p in m.named_parameters()}
+        save(f"g6_sgd_{name}", seed=51, losses=np.array(losses), **final, **base)
+
+
+if __name__ == "__main__":
+    g1(); g2(); g3(); g4(); g5(); g6()

@@ -1,0 +1,183 @@
+"""CPU: the oracle (oracle/tmgcn_oracle.py, oracle/tmgcn_ref.c) against the golden fixtures
+captured from the real reference (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from _util import REL_TOL, assert_close, coo_list, cptr, golden, golden_names, load_c_oracle
+from oracle import tmgcn_oracle as orc
+import tmgcn_amd
+from tmgcn_amd import synth
+from tmgcn_amd.csr import BatchedCSR
+
+TIGHT = 2e-7  # same ATen ops in the same order: only thread-count reduction-order noise
+
+
+def _inputs(d, T=None, N=None, prefix=""):
+    X = torch.from_numpy(d[prefix + "X"])
+    T, N = X.shape[0], X.shape[1]
+    return dict(T=T, N=N, X=X, M=torch.from_numpy(d[prefix + "M"]), edges=torch.from_numpy(d[prefix + "edges"]),
+                labels=torch.from_numpy(d[prefix + "labels"]),
+                At=coo_list(d, "At", T, N, prefix=prefix), A=coo_list(d, "A", T, N, prefix=prefix) if prefix + "A_k" in d else None)
+
+
+def _loss_grads(out_fn, params, target, alpha=0.9):
+    ps = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out = out_fn(ps)
+    loss = torch.nn.CrossEntropyLoss(weight=torch.tensor([alpha, 1 - alpha]))(out, target)
+    loss.backward()
+    return out.detach(), float(loss), {k: v.grad for k, v in ps.items()}
+
+
+@pytest.mark.parametrize("name", golden_names("g1_"))
+def test_g1_compute_AtXt(name):
+    d = golden(name)
+    i = _inputs(d)
+    assert_close(orc.compute_AtXt(i["M"], i["At"], i["X"]), d["AtXt"], TIGHT, name)
+
+
+@pytest.mark.parametrize("name", golden_names("g1_"))
+def test_g1_c_oracle_and_dense_identity(name):
+    """The plain-C restatement and the einsum identity agree with the reference's AtXt."""
+    d = golden(name)
+    i = _inputs(d)
+    lib = load_c_oracle()
+    T, N, F = i["X"].shape
+    csr = BatchedCSR.from_coo_list(i["At"], N=N)
+    X32 = i["X"].float().contiguous()
+    Xt = torch.empty_like(X32)
+    M64 = i["M"].contiguous()
+    lib.ref_mtransform(cptr(M64), T, 0, cptr(X32), cptr(Xt), N * F)
+    Y = torch.empty_like(X32)
+    lib.ref_spmm(cptr(csr.rowptr), cptr(csr.col), cptr(csr.val), cptr(Xt), cptr(Y), T * N, N, F)
+    assert_close(Y, d["AtXt"], REL_TOL, name + " C oracle")
+    dense = torch.einsum("knm,kmf->knf", csr.to_dense().double(), torch.einsum("kj,jnf->knf", i["M"], i["X"]))
+    assert_close(dense, d["AtXt"], REL_TOL, name + " einsum")
+
+
+@pytest.mark.parametrize("name", golden_names("g2_"))
+def test_g2_gcn(name):
+    d = golden(name)
+    i = _inputs(d)
+    fp32 = name.endswith("minv_fp32")
+    if fp32:
+        M, At, X = i["M"].float(), [a.float() for a in i["At"]], i["X"].float()
+        Minv = torch.tensor(np.linalg.inv(M))
+    else:
+        M, At, X, Minv = i["M"], i["At"], i["X"], None
+    # parameter draw order and values
+    torch.manual_seed(int(d["seed"]))
+    p = orc.draw_params("gcn", i["T"], [X.shape[-1], 6, 2], condensed_W=d["W0"].ndim == 2)
+    assert np.array_equal(p["W"].numpy(), d["W0"]) and np.array_equal(p["U"].numpy(), d["U0"])
+    AtXt = orc.compute_AtXt(M, At, X)
+    src, dst = orc.flat_edge_index(i["edges"], i["N"])
+    out, loss, g = _loss_grads(lambda q: orc.gcn_forward(AtXt, q["W"], q["U"], src, dst, Minv), p, i["labels"])
+    assert_close(out, d["logits"], 1e-6, name + " logits")
+    assert abs(loss - float(d["loss"])) <= 1e-6 * max(1.0, abs(float(d["loss"])))
+    assert_close(g["W"], d["dW"], 1e-6, name + " dW")
+    assert_close(g["U"], d["dU"], 1e-6, name + " dU")
+
+
+@pytest.mark.parametrize("name", golden_names("g3_"))
+def test_g3_gcn2(name):
+    d = golden(name)
+    i = _inputs(d)
+    v = _inputs(d, prefix="val_")
+    _, _, branch, nl, cond = name.split("_")
+    kw = dict(apply_M_twice=branch in ("twice", "three"), apply_M_three_times=branch == "three", nonlin=nl)
+    torch.manual_seed(int(d["seed"]))
+    p = orc.draw_params("gcn2", i["T"], [2, 6, 6, 2], condensed_W=cond.endswith("1"))
+    for k in ("W1", "W2", "U"):
+        assert np.array_equal(p[k].numpy(), d[k + "0"]), k
+    AtXt = orc.compute_AtXt(i["M"], i["At"], i["X"])
+    src, dst = orc.flat_edge_index(i["edges"], i["N"])
+    fwd = lambda q, a=AtXt, s=src, t=dst: orc.gcn2_forward(a, i["At"], i["M"], q["W1"], q["W2"], q["U"], s, t, **kw)
+    out, loss, g = _loss_grads(fwd, p, i["labels"])
+    assert_close(out, d["logits"], 1e-6, name + " logits")
+    for k in ("W1", "W2", "U"):
+        assert_close(g[k], d["d" + k], 2e-6, name + " d" + k)
+    # validation-style call: layer 1 uses the passed At/X, layer 2 the TRAINING At (ehf:339-348)
+    vs, vd = orc.flat_edge_index(v["edges"], v["N"])
+    with torch.no_grad():
+        out_val = fwd(p, orc.compute_AtXt(i["M"], v["At"], v["X"]), vs, vd)
+    assert_close(out_val, d["logits_val"], 1e-6, name + " val logits")
+
+
+@pytest.mark.parametrize("name", golden_names("g4_"))
+def test_g4_kwgcn(name):
+    d = golden(name)
+    i = _inputs(d)
+    two = "2layer" in name
+    nl = name.split("_")[-1]
+    torch.manual_seed(int(d["seed"]))
+    p = orc.draw_params("kw", i["T"], [2, 6, 5, 2] if two else [2, 6, 2])
+    for k in p:
+        assert np.array_equal(p[k].numpy(), d[k + "0"]), k
+    AX = orc.slice_spmm(i["A"], i["X"])
+    src, dst = orc.flat_edge_index(i["edges"], i["N"])
+    out, loss, g = _loss_grads(lambda q: orc.kwgcn_forward(AX, i["A"], q["W1"], q["U"], src, dst, q.get("W2"), nl), p, i["labels"])
+    assert_close(out, d["logits"], 1e-6, name)
+    for k in p:
+        assert_close(g[k], d["d" + k], 2e-6, name + " d" + k)
+
+
+def test_g5_chess_pipeline_and_model():
+    """The reference's own preprocessing functions (read_data.py, run on the chess data it ships)
+    pin synth's restated pipeline; the 2-layer model on top pins the oracle on a real graph."""
+    import scipy.sparse as sp
+    d = golden("g5_chess_gcn2")
+    T, N = int(d["T"]), int(d["N"])
+    raw = [sp.coo_matrix((np.ones((d["raw_k"] == t).sum()), (d["raw_i"][d["raw_k"] == t], d["raw_j"][d["raw_k"] == t])),
+                         shape=(N, N)).tocsr() for t in range(T)]
+    C = synth.normalise(synth.edge_life(synth.symmetrise(raw), 10))
+    M = synth.band_M(T, 20, "python")
+    assert_close(M, d["M"], 1e-15, "band M (read_data.py:55-62)")
+    Ct = synth.m_product(C, M)
+
+    def dense(k, i, j, v):
+        out = np.zeros((T, N, N))
+        np.add.at(out, (k, i, j), v)
+        return out
+
+    assert_close(np.stack([c.toarray() for c in C]), dense(d["C_k"], d["C_i"], d["C_j"], d["C_v"]), 1e-12, "normalised adjacency")
+    assert_close(np.stack([c.toarray() for c in Ct]), dense(d["At_k"], d["At_i"], d["At_j"], d["At_v"]), 1e-12, "M-product of A")
+    assert_close(synth.node_features(raw), d["X"], 0.0, "node features")
+
+    At = coo_list(d, "At", T, N)
+    X, Mt = torch.from_numpy(d["X"]), torch.from_numpy(d["M"])
+    torch.manual_seed(int(d["seed"]))
+    p = orc.draw_params("gcn2", T, [2, 6, 6, 2])
+    AtXt = orc.compute_AtXt(Mt, At, X)
+    src, dst = orc.flat_edge_index(torch.from_numpy(d["edges"]), N)
+    out, loss, g = _loss_grads(lambda q: orc.gcn2_forward(AtXt, At, Mt, q["W1"], q["W2"], q["U"], src, dst, nonlin="selu"),
+                               p, torch.from_numpy(d["labels"]))
+    assert_close(out, d["logits"], 1e-6, "chess logits")
+    for k in ("W1", "W2", "U"):
+        assert_close(g[k], d["d" + k], 2e-6, "chess d" + k)
+
+
+@pytest.mark.parametrize("kind", ["gcn", "gcn2"])
+def test_g6_sgd_trajectory(kind):
+    d = golden("g6_sgd_" + kind)
+    i = _inputs(d)
+    torch.manual_seed(int(d["seed"]))
+    p = orc.draw_params(kind, i["T"], [2, 6, 2] if kind == "gcn" else [2, 6, 6, 2])
+    ps = {k: torch.nn.Parameter(v) for k, v in p.items()}
+    AtXt = orc.compute_AtXt(i["M"], i["At"], i["X"])
+    src, dst = orc.flat_edge_index(i["edges"], i["N"])
+    opt = torch.optim.SGD(list(ps.values()), lr=0.01, momentum=0.9)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1]))
+    losses = []
+    for _ in range(10):
+        opt.zero_grad()
+        if kind == "gcn":
+            out = orc.gcn_forward(AtXt, ps["W"], ps["U"], src, dst)
+        else:
+            out = orc.gcn2_forward(AtXt, i["At"], i["M"], ps["W1"], ps["W2"], ps["U"], src, dst, nonlin="selu")
+        loss = crit(out, i["labels"])
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert_close(np.array(losses), d["losses"], 1e-5, kind + " losses")
+    for k, v in ps.items():
+        assert_close(v.detach(), d[k + "_final"], 1e-5, kind + " final " + k)

@@ -1,0 +1,15 @@
+"""tmgcn_amd — MI355X-native TM-GCN propagation layer (tensor M-product GCN, fwd + bwd).
+
+The hot path of IBM/TM-GCN (embedding_help_functions.EmbeddingGCN / EmbeddingGCN2 /
+EmbeddingKWGCN) as hand-written gfx950 HIP kernels behind a C-ABI (include/tmgcn.h), with a
+Python host side that keeps the reference's class contract:
+
+    import tmgcn_amd.layers as ehf
+    gcn = ehf.EmbeddingGCN2(Ct_train_2, X_train, edges_train, M, hidden_feat=[6,6,2],
+                            condensed_W=True, use_Minv=False, nonlin2="selu")
+"""
+from .csr import BatchedCSR  # noqa: F401
+from . import _lib, ops, layers  # noqa: F401
+from .layers import EmbeddingGCN, EmbeddingGCN2, EmbeddingKWGCN  # noqa: F401
+
+__all__ = ["BatchedCSR", "EmbeddingGCN", "EmbeddingGCN2", "EmbeddingKWGCN", "ops", "layers"]

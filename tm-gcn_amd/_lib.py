@@ -1,0 +1,71 @@
+"""ctypes binding of the C-ABI declared in include/tmgcn.h.
+
+The HIP library is the product path: there is no CPU fallback.  Loading fails loudly
+(``TmgcnLibraryError``) if ``libtmgcn_hip.so`` has not been built
+(``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C tm-gcn_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtmgcn_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tmgcn.h")
+
+ACT_IDS = {None: 0, "none": 0, "relu": 1, "leaky": 2, "selu": 3}
+
+
+class TmgcnLibraryError(RuntimeError):
+    pass
+
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); mirrors include/tmgcn.h one to one
+SIGNATURES = {
+    "tmgcn_abi_version": (C.c_int, []),
+    "tmgcn_last_error": (C.c_char_p, []),
+    "tmgcn_mtransform_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i64, _p]),
+    "tmgcn_spmm_csr_batched_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "tmgcn_spmm_csr_batched_f32_hint": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, C.c_float, _p]),
+    "tmgcn_gemm_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _p]),
+    "tmgcn_gemm_dw_workspace_bytes": (_i64, [_i64, _i32, _i32, _i64]),
+    "tmgcn_gemm_dw_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p]),
+    "tmgcn_act_fwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p]),
+    "tmgcn_act_bwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libtmgcn_hip.so (once) and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TmgcnLibraryError(
+            f"{LIB_PATH} not found: build the HIP library first "
+            "(make -C tm-gcn_amd/csrc, or __graft_entry__.build()). "
+            "There is no CPU fallback for the TM-GCN layer."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise TmgcnLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise TmgcnLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().tmgcn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (status {rc}): {msg}")

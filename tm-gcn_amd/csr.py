@@ -1,0 +1,174 @@
+"""Batched CSR: the HBM format of the adjacency tensor Â (T frontal slices, N×N each).
+
+The reference keeps Â as a Python list of T 2-D COO tensors with int64 indices and fp64
+values (embedding_help_functions.py:560-574, experiment_bitcoin_our.py:52-64) and
+multiplies them one ``t.sparse.mm`` at a time.  Here all T slices live in ONE block-diagonal
+CSR so that a single kernel launch covers the whole tensor:
+
+    rowptr  int64 [T*N + 1]   global offsets into col/val; row r = k*N + i  (slice k, node i)
+    col     int32 [nnz]       column inside the slice, 0..N-1
+    val     fp32  [nnz]
+
+Duplicates in the COO input are kept as separate entries (their products are summed by the
+SpMM exactly as ``sparse.mm`` sums uncoalesced entries).  Within a row, entries are ordered
+by column, ties in input order, so every row sum has a fixed order.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+
+class BatchedCSR:
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, T: int, N: int):
+        assert rowptr.dtype == torch.int64 and col.dtype == torch.int32 and val.dtype == torch.float32
+        assert rowptr.numel() == T * N + 1, (rowptr.numel(), T, N)
+        assert col.numel() == val.numel()
+        self.rowptr = rowptr.contiguous()
+        self.col = col.contiguous()
+        self.val = val.contiguous()
+        self.T = int(T)
+        self.N = int(N)
+        self.nnz = int(col.numel())
+        self._t: Optional["BatchedCSR"] = None
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def device(self):
+        return self.val.device
+
+    @property
+    def n_rows(self) -> int:
+        return self.T * self.N
+
+    @property
+    def avg_nnz_per_row(self) -> float:
+        return self.nnz / max(1, self.n_rows)
+
+    def __repr__(self):
+        return f"BatchedCSR(T={self.T}, N={self.N}, nnz={self.nnz}, device={self.device})"
+
+    # ------------------------------------------------------------------ constructors
+    @staticmethod
+    def from_coo(slice_idx, row, col, val, T: int, N: int, device=None) -> "BatchedCSR":
+        """Build from one batched COO (any order).  Index tensors are integer, val any float."""
+        device = torch.device(device) if device is not None else val.device
+        slice_idx = torch.as_tensor(slice_idx).to(device=device, dtype=torch.int64)
+        row = torch.as_tensor(row).to(device=device, dtype=torch.int64)
+        col = torch.as_tensor(col).to(device=device, dtype=torch.int64)
+        val = torch.as_tensor(val).to(device=device)
+        if slice_idx.numel():
+            if int(slice_idx.min()) < 0 or int(slice_idx.max()) >= T:
+                raise RuntimeError(f"slice index out of range [0,{T})")
+            if int(min(row.min(), col.min())) < 0 or int(max(row.max(), col.max())) >= N:
+                raise RuntimeError(f"node index out of range [0,{N}) — the adjacency does not match X.shape[1]")
+        key = (slice_idx * N + row) * N + col  # T*N*N < 2^63 for every config in scope
+        order = torch.sort(key, stable=True).indices
+        rkey = (slice_idx * N + row)[order]
+        counts = torch.bincount(rkey, minlength=T * N)
+        rowptr = torch.zeros(T * N + 1, dtype=torch.int64, device=device)
+        torch.cumsum(counts, 0, out=rowptr[1:])
+        return BatchedCSR(rowptr, col[order].to(torch.int32), val[order].to(torch.float32), T, N)
+
+    @staticmethod
+    def from_coo_list(slices: Sequence[torch.Tensor], N: Optional[int] = None, device=None) -> "BatchedCSR":
+        """Build from the reference's list of T sparse COO matrices (ehf:560-574).
+
+        The reference builds each slice without an explicit size (ehf:564); N therefore has
+        to come from the feature tensor (``X.shape[1]``) and is validated against the indices.
+        """
+        T = len(slices)
+        if T == 0:
+            raise RuntimeError("empty adjacency list")
+        ks, rs, cs, vs = [], [], [], []
+        n_seen = 0
+        for k, a in enumerate(slices):
+            if not a.is_sparse:
+                raise RuntimeError(f"slice {k} is not a sparse COO tensor")
+            idx = a._indices()
+            v = a._values()
+            if idx.shape[0] != 2:
+                raise RuntimeError(f"slice {k} is not 2-D")
+            ks.append(torch.full((idx.shape[1],), k, dtype=torch.int64, device=idx.device))
+            rs.append(idx[0])
+            cs.append(idx[1])
+            vs.append(v)
+            n_seen = max(n_seen, int(a.shape[0]), int(a.shape[1]))
+        if N is None:
+            N = n_seen
+        return BatchedCSR.from_coo(torch.cat(ks), torch.cat(rs), torch.cat(cs), torch.cat(vs), T, int(N),
+                                   device=device if device is not None else vs[0].device)
+
+    @staticmethod
+    def from_scipy_list(mats, device=None) -> "BatchedCSR":
+        """Build from a list of scipy.sparse matrices (harness convenience)."""
+        import numpy as np
+
+        T = len(mats)
+        N = mats[0].shape[0]
+        ks, rs, cs, vs = [], [], [], []
+        for k, m in enumerate(mats):
+            m = m.tocoo()
+            ks.append(np.full(m.nnz, k, dtype=np.int64))
+            rs.append(m.row.astype(np.int64))
+            cs.append(m.col.astype(np.int64))
+            vs.append(m.data)
+        return BatchedCSR.from_coo(torch.from_numpy(np.concatenate(ks)), torch.from_numpy(np.concatenate(rs)),
+                                   torch.from_numpy(np.concatenate(cs)), torch.from_numpy(np.concatenate(vs)),
+                                   T, N, device=device)
+
+    # ------------------------------------------------------------------ views / conversions
+    def to(self, device) -> "BatchedCSR":
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        out = BatchedCSR(self.rowptr.to(device), self.col.to(device), self.val.to(device), self.T, self.N)
+        return out
+
+    def row_ids(self) -> torch.Tensor:
+        """Global row index (k*N + i) of every stored entry."""
+        counts = self.rowptr[1:] - self.rowptr[:-1]
+        return torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), counts)
+
+    def transpose(self) -> "BatchedCSR":
+        """Per-slice transpose (Â_kᵀ for every k), cached.  Used by the backward SpMM."""
+        if self._t is None:
+            rid = self.row_ids()
+            k = rid // self.N
+            i = rid - k * self.N
+            t = BatchedCSR.from_coo(k, self.col.to(torch.int64), i, self.val, self.T, self.N, device=self.device)
+            t._t = self
+            self._t = t
+        return self._t
+
+    def slices(self, k0: int, k1: int) -> "BatchedCSR":
+        """Slices [k0, k1) as their own batched CSR (the shard one rank owns)."""
+        assert 0 <= k0 <= k1 <= self.T
+        lo, hi = k0 * self.N, k1 * self.N
+        base = int(self.rowptr[lo])
+        end = int(self.rowptr[hi])
+        return BatchedCSR((self.rowptr[lo:hi + 1] - base).clone(), self.col[base:end].clone(),
+                          self.val[base:end].clone(), k1 - k0, self.N)
+
+    def to_coo_list(self, dtype=torch.float64) -> List[torch.Tensor]:
+        """Back to the reference's list-of-COO form (CPU), for the oracle / CPU baseline."""
+        rid = self.row_ids().cpu()
+        col = self.col.cpu().to(torch.int64)
+        val = self.val.cpu().to(dtype)
+        rp = self.rowptr.cpu()
+        out = []
+        for k in range(self.T):
+            a, b = int(rp[k * self.N]), int(rp[(k + 1) * self.N])
+            idx = torch.stack([rid[a:b] - k * self.N, col[a:b]])
+            out.append(torch.sparse_coo_tensor(idx, val[a:b], (self.N, self.N)))
+        return out
+
+    def to_dense(self) -> torch.Tensor:
+        """[T, N, N] dense tensor (tests only; small sizes)."""
+        rid = self.row_ids()
+        k = rid // self.N
+        i = rid - k * self.N
+        d = torch.zeros(self.T, self.N, self.N, dtype=self.val.dtype, device=self.device)
+        d.index_put_((k, i, self.col.to(torch.int64)), self.val, accumulate=True)
+        return d

@@ -1,0 +1,422 @@
+// P3 — feature·weight contraction and its two backward products   (gfx950 / CDNA4)
+//
+// Replaces  t.matmul(AtXt, Wt)  (embedding_help_functions.py:222, 330, 340, 344, 349, 415,
+// 486-489) and autograd's  dA = dY·Wᵀ,  dW = Σ_r A[r]ᵀ dY[r].
+//
+//   gemm_mfma      Y[R][Nf] = act(A[R][K] · Wop): exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//                  A 64-row tile is staged through LDS with full-line loads; each wave
+//                  keeps its 32-column strip of W in registers (B fragments) for the whole
+//                  persistent loop, so W is read once per block.  The k index inside a
+//                  step is permuted (lane half h takes k = 8j+4h+s) so that one
+//                  ds_read_b128 feeds four MFMAs.
+//   gemm_small     thread-per-row FMA kernel for the reference's real sizes (2x6, 6x6, 12x2):
+//                  MFMA tiles would be >90 % padding there; the op is a pure HBM stream.
+//   gemm_dw_mfma   dW = AᵀdY.  The reduction index is the row r, so the MFMA A/B operands
+//                  are read straight from global memory with the feature index on the lane
+//                  (128-B coalesced segments, no LDS); row-chunk partial slabs are reduced
+//                  in a fixed order by a second kernel (no float atomics: reproducible).
+#include "common.h"
+
+namespace tmgcn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64;        // rows per tile
+constexpr int KC = 128;       // k-chunk held in registers
+constexpr int LDA = KC + 4;   // LDS row stride (floats): conflict-free ds_read_b128
+
+struct GemmArgs {
+  const float* A;
+  const float* W;
+  float* Y;
+  float* pre;
+  int64_t R;
+  int32_t K, Nf;
+  int32_t trans_w;
+  int64_t rows_per_batch;  // 0 = shared W
+  int64_t w_batch_stride;
+  int32_t act;
+  int64_t tiles_per_batch;
+  int64_t n_tiles;
+};
+
+__device__ __forceinline__ float wop(const GemmArgs& a, const float* Wb, int k, int n) {
+  if (k >= a.K || n >= a.Nf) return 0.f;
+  return a.trans_w ? Wb[(int64_t)n * a.K + k] : Wb[(int64_t)k * a.Nf + n];
+}
+
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
+  __shared__ float As[BM * LDA];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int n0 = blockIdx.y * 128 + wave * 32;  // this wave's column strip
+  const int64_t batch_rows = a.rows_per_batch ? a.rows_per_batch : a.R;
+
+  float wreg[KC / 8][4];
+  int64_t cur_batch = -1;
+  const int n_kchunks = (a.K + KC - 1) / KC;
+
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t batch = tile / a.tiles_per_batch;
+    const int64_t row0 = batch * batch_rows + (tile % a.tiles_per_batch) * BM;
+    int64_t row_end = (batch + 1) * batch_rows;
+    if (row_end > a.R) row_end = a.R;
+    const float* Wb = a.W + (a.rows_per_batch ? batch * a.w_batch_stride : 0);
+
+    f32x16 acc[BM / 32];
+#pragma unroll
+    for (int mb = 0; mb < BM / 32; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
+
+    for (int kc = 0; kc < n_kchunks; ++kc) {
+      const int k0 = kc * KC;
+      int kw = a.K - k0;
+      if (kw > KC) kw = KC;
+      const int nj = (kw + 7) / 8;
+      // B fragments: reload when the weight (batch) or the k-chunk changes
+      if (batch != cur_batch || n_kchunks > 1) {
+#pragma unroll
+        for (int j = 0; j < KC / 8; ++j)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            wreg[j][s] = (j < nj) ? wop(a, Wb, k0 + 8 * j + 4 * lh + s, n0 + li) : 0.f;
+      }
+      __syncthreads();  // previous tile's fragment reads are done
+      // stage A[row0 .. row0+BM) x [k0, k0+8*nj) into LDS, zero padded
+      const int kw8 = nj * 8;
+      if ((a.K % 4 == 0) && (reinterpret_cast<uintptr_t>(a.A) % 16 == 0)) {
+        const int f4_per_row = kw8 / 4;
+        for (int t = threadIdx.x; t < BM * f4_per_row; t += 256) {
+          const int rr = t / f4_per_row, q = t % f4_per_row;
+          const int64_t r = row0 + rr;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (r < row_end && k0 + 4 * q < a.K)
+            v = *reinterpret_cast<const float4*>(a.A + r * a.K + k0 + 4 * q);
+          *reinterpret_cast<float4*>(&As[rr * LDA + 4 * q]) = v;
+        }
+      } else {
+        for (int t = threadIdx.x; t < BM * kw8; t += 256) {
+          const int rr = t / kw8, q = t % kw8;
+          const int64_t r = row0 + rr;
+          As[rr * LDA + q] = (r < row_end && k0 + q < a.K) ? a.A[r * a.K + k0 + q] : 0.f;
+        }
+      }
+      __syncthreads();
+      if (n0 < a.Nf) {
+#pragma unroll
+        for (int mb = 0; mb < BM / 32; ++mb) {
+#pragma unroll
+          for (int j = 0; j < KC / 8; ++j) {
+            if (j < nj) {
+              const float4 av =
+                  *reinterpret_cast<const float4*>(&As[(mb * 32 + li) * LDA + 8 * j + 4 * lh]);
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wreg[j][0], acc[mb], 0, 0, 0);
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wreg[j][1], acc[mb], 0, 0, 0);
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wreg[j][2], acc[mb], 0, 0, 0);
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wreg[j][3], acc[mb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    cur_batch = batch;
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+    const int n = n0 + li;
+    if (n < a.Nf) {
+#pragma unroll
+      for (int mb = 0; mb < BM / 32; ++mb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t r = row0 + mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+          if (r < row_end) {
+            const float s = acc[mb][i];
+            if (a.pre) a.pre[r * a.Nf + n] = s;
+            a.Y[r * a.Nf + n] = act_apply(s, a.act);
+          }
+        }
+      }
+    }
+  }
+}
+
+// thread-per-row kernel for small K / Nf; W (zero padded to a multiple of 8 columns) in LDS.
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
+  extern __shared__ float Ws[];  // [n_w][K][Nfp]
+  const int Nfp = (a.Nf + 7) & ~7;
+  const int64_t batch_rows = a.rows_per_batch ? a.rows_per_batch : a.R;
+  const int64_t r_first = (int64_t)blockIdx.x * blockDim.x;
+  int64_t r_last = r_first + blockDim.x - 1;
+  if (r_last >= a.R) r_last = a.R - 1;
+  const int64_t b_first = r_first / batch_rows;
+  const int n_w = (int)(r_last / batch_rows - b_first) + 1;  // weights this block touches
+  for (int t = threadIdx.x; t < n_w * a.K * Nfp; t += blockDim.x) {
+    const int wb = t / (a.K * Nfp), rem = t % (a.K * Nfp);
+    const int k = rem / Nfp, n = rem % Nfp;
+    const float* Wb = a.W + (a.rows_per_batch ? (b_first + wb) * a.w_batch_stride : 0);
+    Ws[t] = wop(a, Wb, k, n);
+  }
+  __syncthreads();
+  const int64_t r = r_first + threadIdx.x;
+  if (r >= a.R) return;
+  const float* Wl = Ws + (int64_t)(r / batch_rows - b_first) * a.K * Nfp;
+  const float* Ar = a.A + r * a.K;
+  for (int nb = 0; nb < Nfp; nb += 8) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int k = 0; k < a.K; ++k) {
+      const float x = Ar[k];
+      const float* w = Wl + k * Nfp + nb;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(x, w[i], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (nb + i < a.Nf) {
+        if (a.pre) a.pre[r * a.Nf + nb + i] = acc[i];
+        a.Y[r * a.Nf + nb + i] = act_apply(acc[i], a.act);
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// dW
+// --------------------------------------------------------------------------------------
+struct DwArgs {
+  const float* A;
+  const float* dY;
+  float* part;  // [n_batch][chunks][K][Nf]
+  int64_t R;
+  int32_t K, Nf;
+  int64_t batch_rows;
+  int32_t chunks;  // row chunks per batch
+  int64_t rows_per_chunk;
+};
+
+// grid: x = batch*chunks + chunk, y = 128x128 output tile (ky * n_tiles_n + ny)
+__global__ __launch_bounds__(256) void gemm_dw_mfma_kernel(DwArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int tiles_n = (a.Nf + 127) / 128;
+  const int kt = blockIdx.y / tiles_n, nt = blockIdx.y % tiles_n;
+  const int64_t batch = blockIdx.x / a.chunks;
+  const int chunk = blockIdx.x % a.chunks;
+  const int64_t b0 = batch * a.batch_rows;
+  int64_t b1 = b0 + a.batch_rows;
+  if (b1 > a.R) b1 = a.R;
+  const int64_t r0 = b0 + (int64_t)chunk * a.rows_per_chunk;
+  int64_t r1 = r0 + a.rows_per_chunk;
+  if (r1 > b1) r1 = b1;
+
+  const int k = kt * 128 + wave * 32 + li;  // A-operand feature on the lane
+  const bool k_ok = k < a.K;
+  int ncol[4];
+  bool n_ok[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    ncol[nb] = nt * 128 + nb * 32 + li;
+    n_ok[nb] = ncol[nb] < a.Nf;
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+  constexpr int UR = 4;  // MFMA k-steps (row pairs) in flight
+  for (int64_t r = r0; r < r1; r += 2 * UR) {
+    float av[UR], bv[UR][4];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int64_t rr = r + 2 * u + lh;
+      const bool ok = rr < r1;
+      av[u] = (ok && k_ok) ? a.A[rr * a.K + k] : 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) bv[u][nb] = (ok && n_ok[nb]) ? a.dY[rr * a.Nf + ncol[nb]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][nb], acc[nb], 0, 0, 0);
+  }
+  float* P = a.part + ((int64_t)blockIdx.x) * a.K * a.Nf;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    if (n_ok[nb]) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = kt * 128 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        if (kk < a.K) P[(int64_t)kk * a.Nf + ncol[nb]] = acc[nb][i];
+      }
+    }
+  }
+}
+
+// small dW: one output element per thread-slot, rows staged through LDS.
+constexpr int DW_ROWS = 64;
+__global__ __launch_bounds__(256) void gemm_dw_small_kernel(DwArgs a) {
+  extern __shared__ float sm[];  // [DW_ROWS][K] then [DW_ROWS][Nf]
+  float* sa = sm;
+  float* sd = sm + DW_ROWS * a.K;
+  const int64_t batch = blockIdx.x / a.chunks;
+  const int chunk = blockIdx.x % a.chunks;
+  const int64_t b0 = batch * a.batch_rows;
+  int64_t b1 = b0 + a.batch_rows;
+  if (b1 > a.R) b1 = a.R;
+  const int64_t r0 = b0 + (int64_t)chunk * a.rows_per_chunk;
+  int64_t r1 = r0 + a.rows_per_chunk;
+  if (r1 > b1) r1 = b1;
+  const int n_out = a.K * a.Nf;
+  constexpr int OMAX = 4;  // n_out <= 1024
+  float acc[OMAX];
+  int ok_[OMAX], on_[OMAX];
+#pragma unroll
+  for (int o = 0; o < OMAX; ++o) {
+    acc[o] = 0.f;
+    const int idx = threadIdx.x + o * 256;
+    ok_[o] = idx < n_out ? idx / a.Nf : -1;
+    on_[o] = idx < n_out ? idx % a.Nf : 0;
+  }
+  for (int64_t r = r0; r < r1; r += DW_ROWS) {
+    const int nr = (int)((r1 - r) < DW_ROWS ? (r1 - r) : DW_ROWS);
+    __syncthreads();
+    for (int t = threadIdx.x; t < nr * a.K; t += 256) sa[t] = a.A[r * a.K + t];
+    for (int t = threadIdx.x; t < nr * a.Nf; t += 256) sd[t] = a.dY[r * a.Nf + t];
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o) {
+      if (ok_[o] >= 0) {
+        float s = acc[o];
+        for (int i = 0; i < nr; ++i) s = fmaf(sa[i * a.K + ok_[o]], sd[i * a.Nf + on_[o]], s);
+        acc[o] = s;
+      }
+    }
+  }
+  float* P = a.part + ((int64_t)blockIdx.x) * n_out;
+#pragma unroll
+  for (int o = 0; o < OMAX; ++o)
+    if (ok_[o] >= 0) P[threadIdx.x + o * 256] = acc[o];
+}
+
+// dW[b][o] = sum over chunks (ascending) of part[b][chunk][o]
+__global__ void gemm_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
+                                      int64_t n_out, int32_t chunks, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t b = idx / n_out, o = idx % n_out;
+  const float* p = part + b * chunks * n_out + o;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += p[(int64_t)c * n_out];
+  dW[idx] = s;
+}
+
+static bool use_small(int K, int Nf) { return (K < 16 || Nf < 16) && K <= 64 && Nf <= 64; }
+
+static void dw_plan(int64_t R, int64_t rows_per_batch, int64_t* n_batch, int* chunks,
+                    int64_t* rows_per_chunk) {
+  const int64_t br = rows_per_batch ? rows_per_batch : R;
+  const int64_t nb = br ? (R + br - 1) / br : 1;
+  int64_t c = (br + 2047) / 2048;  // >= 2048 rows per chunk
+  int64_t cmax = 2048 / (nb > 0 ? nb : 1);
+  if (cmax < 1) cmax = 1;
+  if (c > cmax) c = cmax;
+  if (c < 1) c = 1;
+  int64_t rpc = (br + c - 1) / c;
+  rpc = (rpc + 7) & ~(int64_t)7;  // whole unrolled steps
+  c = (br + rpc - 1) / (rpc ? rpc : 1);
+  if (c < 1) c = 1;
+  *n_batch = nb;
+  *chunks = (int)c;
+  *rows_per_chunk = rpc;
+}
+
+}  // namespace tmgcn
+
+using namespace tmgcn;
+
+extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* pre_act, int64_t R,
+                               int32_t K, int32_t Nf, int32_t trans_w, int64_t rows_per_batch,
+                               int64_t w_batch_stride, int32_t act, void* stream) {
+  TMGCN_REQUIRE(R >= 0 && K > 0 && Nf > 0, "gemm: bad shape R=%lld K=%d Nf=%d", (long long)R, K, Nf);
+  TMGCN_REQUIRE(rows_per_batch >= 0, "gemm: negative rows_per_batch");
+  TMGCN_REQUIRE(act >= TMGCN_ACT_NONE && act <= TMGCN_ACT_SELU, "gemm: unknown activation %d", act);
+  if (R == 0) return TMGCN_OK;
+  TMGCN_REQUIRE(A && W && Y, "gemm: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a{A, W, Y, pre_act, R, K, Nf, trans_w, rows_per_batch, w_batch_stride, act, 0, 0};
+  if (use_small(K, Nf)) {
+    const int Nfp = (Nf + 7) & ~7;
+    const int64_t br = rows_per_batch ? rows_per_batch : R;
+    const int64_t max_w = br >= 256 ? 2 : (256 / br + 2);
+    const size_t smem = (size_t)max_w * K * Nfp * sizeof(float);
+    TMGCN_REQUIRE(smem <= 64 * 1024, "gemm: per-slice weights too small a batch (%lld rows)",
+                  (long long)br);
+    const unsigned grid = (unsigned)((R + 255) / 256);
+    hipLaunchKernelGGL(gemm_small_kernel, dim3(grid), dim3(256), smem, st, a);
+    return check_launch("gemm_small");
+  }
+  const int64_t br = rows_per_batch ? rows_per_batch : R;
+  const int64_t nb = (R + br - 1) / br;
+  a.tiles_per_batch = (br + BM - 1) / BM;
+  a.n_tiles = nb * a.tiles_per_batch;
+  const unsigned gy = (unsigned)((Nf + 127) / 128);
+  int64_t gx = a.n_tiles < 1024 ? a.n_tiles : 1024;
+  hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
+  return check_launch("gemm_mfma");
+}
+
+extern "C" int64_t tmgcn_gemm_dw_workspace_bytes(int64_t R, int32_t K, int32_t Nf,
+                                                  int64_t rows_per_batch) {
+  if (R <= 0 || K <= 0 || Nf <= 0) return 0;
+  int64_t nb, rpc;
+  int chunks;
+  dw_plan(R, rows_per_batch, &nb, &chunks, &rpc);
+  return nb * chunks * (int64_t)K * Nf * (int64_t)sizeof(float);
+}
+
+extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int64_t R, int32_t K,
+                                  int32_t Nf, int64_t rows_per_batch, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+  TMGCN_REQUIRE(R >= 0 && K > 0 && Nf > 0, "gemm_dw: bad shape");
+  TMGCN_REQUIRE(rows_per_batch >= 0, "gemm_dw: negative rows_per_batch");
+  TMGCN_REQUIRE(dW, "gemm_dw: null dW");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t nb, rpc;
+  int chunks;
+  dw_plan(R, rows_per_batch, &nb, &chunks, &rpc);
+  if (R == 0) {
+    hipMemsetAsync(dW, 0, (size_t)K * Nf * sizeof(float), st);
+    return check_launch("gemm_dw memset");
+  }
+  TMGCN_REQUIRE(A && dY, "gemm_dw: null pointer");
+  const int64_t need = nb * chunks * (int64_t)K * Nf * (int64_t)sizeof(float);
+  if (!workspace || workspace_bytes < need) {
+    set_error("gemm_dw: workspace %lld B < required %lld B", (long long)workspace_bytes,
+              (long long)need);
+    return TMGCN_ERR_WORKSPACE;
+  }
+  DwArgs a{A, dY, (float*)workspace, R, K, Nf, rows_per_batch ? rows_per_batch : R, chunks, rpc};
+  const unsigned gx = (unsigned)(nb * chunks);
+  if (use_small(K, Nf)) {
+    const size_t smem = (size_t)DW_ROWS * (K + Nf) * sizeof(float);
+    hipLaunchKernelGGL(gemm_dw_small_kernel, dim3(gx), dim3(256), smem, st, a);
+  } else {
+    const unsigned gy = (unsigned)(((K + 127) / 128) * ((Nf + 127) / 128));
+    hipLaunchKernelGGL(gemm_dw_mfma_kernel, dim3(gx, gy), dim3(256), 0, st, a);
+  }
+  int rc = check_launch("gemm_dw");
+  if (rc) return rc;
+  const int64_t n_out = (int64_t)K * Nf;
+  const int64_t total = nb * n_out;
+  hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     (const float*)workspace, dW, n_out, chunks, total);
+  return check_launch("gemm_dw_reduce");
+}

@@ -1,0 +1,258 @@
+"""Autograd operators of the TM-GCN layer over the C-ABI kernels (include/tmgcn.h).
+
+    m_transform   P1  Xt = M ×₁ X                 (ehf:204, 308, 346, 404; Minv ehf:224)
+    spmm          P2  AtXt[k] = Â_k · Xt[k]        (ehf:206-207, 303-304, 310-311, 471-472)
+    feature_gemm  P3  Y = act(AtXt · W)            (ehf:222, 330, 344, 349, 486-489)
+    activation    P5                               (ehf:284-289)
+
+Every operator runs the hand-written HIP kernels on the current torch stream; there is no
+CPU path — tensors that are not fp32 ROCm tensors raise.  ``kernels`` is the one object
+through which the operators reach the device code (tests of the sharding logic substitute
+it; the product never does).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .csr import BatchedCSR
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _want(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a ROCm (cuda) tensor, got device {t.device}; "
+                           "the TM-GCN layer has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+class MOperator:
+    """The T×T mixing matrix M of the M-product, resident on the device in fp32, with the
+    band structure the kernels exploit (read_data.m:116-124 builds a lower band of 20)."""
+
+    def __init__(self, M, device):
+        M64 = torch.as_tensor(M).detach().to("cpu", torch.float64).contiguous()
+        if M64.dim() != 2 or M64.shape[0] != M64.shape[1]:
+            raise RuntimeError(f"M must be square, got {tuple(M64.shape)}")
+        self.T = int(M64.shape[0])
+        nz = torch.nonzero(M64)
+        if nz.numel():
+            d = nz[:, 1] - nz[:, 0]  # column - row
+            self.band_lo = int(max(0, -int(d.min())))
+            self.band_hi = int(max(0, int(d.max())))
+        else:
+            self.band_lo = self.band_hi = 0
+        self.M64 = M64
+        self.M = M64.to(torch.float32).to(device).contiguous()
+        self._inv: Optional["MOperator"] = None
+
+    def inverse(self) -> "MOperator":
+        """M⁻¹ computed on the host in fp64 as the reference does (ehf:184, 273)."""
+        if self._inv is None:
+            self._inv = MOperator(torch.from_numpy(np.linalg.inv(self.M64.numpy())), self.M.device)
+        return self._inv
+
+    def window(self, k0: int, k1: int) -> "MOperator":
+        """The [k0,k1) x [k0,k1) principal block (the reference's ``M[:-1,:-1]`` idiom)."""
+        return MOperator(self.M64[k0:k1, k0:k1], self.M.device)
+
+
+class HipKernels:
+    """Thin launchers: validate, allocate the output, call the C-ABI on the current stream."""
+
+    name = "hip"
+
+    def __init__(self):
+        self._dw_ws = {}
+
+    # P1 ---------------------------------------------------------------------------------
+    def mtransform(self, op: MOperator, X: torch.Tensor, transpose=False, row_off=0, col_off=0,
+                   T_out: Optional[int] = None) -> torch.Tensor:
+        lib = _lib.load()
+        _want(X, "mtransform X")
+        T_in = X.shape[0]
+        if T_out is None:
+            T_out = T_in
+        C_ = X.numel() // max(1, T_in)
+        Y = torch.empty((T_out,) + tuple(X.shape[1:]), dtype=torch.float32, device=X.device)
+        lo, hi = (op.band_hi, op.band_lo) if transpose else (op.band_lo, op.band_hi)
+        rc = lib.tmgcn_mtransform_f32(_ptr(op.M), op.T, op.T, int(bool(transpose)), row_off, col_off,
+                                      T_out, T_in, lo, hi, _ptr(X), _ptr(Y), C_, _stream(X))
+        _lib.check(rc, "tmgcn_mtransform_f32")
+        return Y
+
+    # P2 ---------------------------------------------------------------------------------
+    def spmm(self, A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        _want(X, "spmm X")
+        if X.dim() != 3 or X.shape[0] != A.T or X.shape[1] != A.N:
+            raise RuntimeError(f"spmm: X {tuple(X.shape)} does not match adjacency T={A.T} N={A.N}")
+        if A.device != X.device:
+            raise RuntimeError("spmm: adjacency and X live on different devices")
+        F = X.shape[2]
+        Y = torch.empty_like(X)
+        rc = lib.tmgcn_spmm_csr_batched_f32_hint(_ptr(A.rowptr), _ptr(A.col), _ptr(A.val), _ptr(X), _ptr(Y),
+                                                 A.n_rows, A.N, F, C.c_float(A.avg_nnz_per_row), _stream(X))
+        _lib.check(rc, "tmgcn_spmm_csr_batched_f32")
+        return Y
+
+    # P3 ---------------------------------------------------------------------------------
+    def gemm(self, A: torch.Tensor, W: torch.Tensor, trans_w=False, act=None, want_pre=False):
+        """A [T,N,K] · W ([K,Nf] shared or [T,K,Nf] per slice; transposed if trans_w)."""
+        lib = _lib.load()
+        _want(A, "gemm A")
+        _want(W, "gemm W")
+        T, N, K = A.shape
+        per_slice = W.dim() == 3
+        wk, wn = (W.shape[-1], W.shape[-2]) if trans_w else (W.shape[-2], W.shape[-1])
+        if wk != K or (per_slice and W.shape[0] != T):
+            raise RuntimeError(f"gemm: size mismatch A {tuple(A.shape)} W {tuple(W.shape)} trans_w={trans_w}")
+        Y = torch.empty((T, N, wn), dtype=torch.float32, device=A.device)
+        act_id = _lib.ACT_IDS[act]
+        pre = torch.empty_like(Y) if (want_pre and act_id) else None
+        rc = lib.tmgcn_gemm_f32(_ptr(A), _ptr(W), _ptr(Y), _ptr(pre), T * N, K, wn, int(bool(trans_w)),
+                                N if per_slice else 0, W.shape[-1] * W.shape[-2] if per_slice else 0,
+                                act_id, _stream(A))
+        _lib.check(rc, "tmgcn_gemm_f32")
+        return (Y, pre) if want_pre else Y
+
+    def gemm_dw(self, A: torch.Tensor, dY: torch.Tensor, per_slice: bool) -> torch.Tensor:
+        lib = _lib.load()
+        _want(A, "gemm_dw A")
+        _want(dY, "gemm_dw dY")
+        T, N, K = A.shape
+        Nf = dY.shape[2]
+        R = T * N
+        rpb = N if per_slice else 0
+        need = int(lib.tmgcn_gemm_dw_workspace_bytes(R, K, Nf, rpb))
+        key = (A.device, torch.cuda.current_stream(A.device).cuda_stream)
+        ws = self._dw_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 1), dtype=torch.uint8, device=A.device)
+            self._dw_ws[key] = ws
+        dW = torch.empty((T, K, Nf) if per_slice else (K, Nf), dtype=torch.float32, device=A.device)
+        rc = lib.tmgcn_gemm_dw_f32(_ptr(A), _ptr(dY), _ptr(dW), R, K, Nf, rpb, _ptr(ws), ws.numel(), _stream(A))
+        _lib.check(rc, "tmgcn_gemm_dw_f32")
+        return dW
+
+    # P5 ---------------------------------------------------------------------------------
+    def act_fwd(self, x: torch.Tensor, act) -> torch.Tensor:
+        lib = _lib.load()
+        _want(x, "act x")
+        y = torch.empty_like(x)
+        _lib.check(lib.tmgcn_act_fwd_f32(_ptr(x), _ptr(y), x.numel(), _lib.ACT_IDS[act], _stream(x)), "tmgcn_act_fwd_f32")
+        return y
+
+    def act_bwd(self, x: torch.Tensor, dy: torch.Tensor, act) -> torch.Tensor:
+        lib = _lib.load()
+        _want(x, "act x")
+        _want(dy, "act dy")
+        dx = torch.empty_like(x)
+        _lib.check(lib.tmgcn_act_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _lib.ACT_IDS[act], _stream(x)),
+                   "tmgcn_act_bwd_f32")
+        return dx
+
+
+kernels = HipKernels()
+
+
+# ---------------------------------------------------------------------------------------
+# autograd
+# ---------------------------------------------------------------------------------------
+class _MTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, op, row_off, col_off, T_out):
+        ctx.op, ctx.row_off, ctx.col_off, ctx.T_in = op, row_off, col_off, X.shape[0]
+        return kernels.mtransform(op, X, False, row_off, col_off, T_out)
+
+    @staticmethod
+    def backward(ctx, dY):
+        # Y[k] = Σ_j M[ro+k][co+j] X[j]   =>   dX[j] = Σ_k Mᵀ[co+j][ro+k] dY[k]
+        dX = kernels.mtransform(ctx.op, dY.contiguous(), True, ctx.col_off, ctx.row_off, ctx.T_in)
+        return dX, None, None, None, None
+
+
+class _Spmm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, A):
+        ctx.A = A
+        return kernels.spmm(A, X)
+
+    @staticmethod
+    def backward(ctx, dY):
+        # sparse.mm backward: dX_k = Â_kᵀ dY_k (Â is a constant: no gradient, as in the reference)
+        return kernels.spmm(ctx.A.transpose(), dY.contiguous()), None
+
+
+class _FeatureGemm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, W, act):
+        ctx.act = act if _lib.ACT_IDS[act] else None
+        if ctx.act is not None:
+            Y, pre = kernels.gemm(A, W, act=act, want_pre=True)
+            ctx.save_for_backward(A, W, pre)
+        else:
+            Y = kernels.gemm(A, W)
+            ctx.save_for_backward(A, W)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        dY = dY.contiguous()
+        if ctx.act is not None:
+            A, W, pre = ctx.saved_tensors
+            dY = kernels.act_bwd(pre, dY, ctx.act)
+        else:
+            A, W = ctx.saved_tensors
+        dA = kernels.gemm(dY, W, trans_w=True) if ctx.needs_input_grad[0] else None
+        dW = kernels.gemm_dw(A, dY, per_slice=W.dim() == 3) if ctx.needs_input_grad[1] else None
+        return dA, dW, None
+
+
+class _Activation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        ctx.act = act
+        ctx.save_for_backward(x)
+        return kernels.act_fwd(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return kernels.act_bwd(x, dy.contiguous(), ctx.act), None
+
+
+def m_transform(X: torch.Tensor, op: MOperator, row_off=0, col_off=0, T_out=None) -> torch.Tensor:
+    """P1: Y[k] = Σ_j M[row_off+k][col_off+j] · X[j]  along the first (time) mode."""
+    return _MTransform.apply(X, op, row_off, col_off, T_out)
+
+
+def spmm(A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
+    """P2: Y[k] = Â_k · X[k] for all frontal slices in one launch."""
+    return _Spmm.apply(X, A)
+
+
+def feature_gemm(A: torch.Tensor, W: torch.Tensor, act=None) -> torch.Tensor:
+    """P3 (+ fused P5): act(A · W), W shared ([K,Nf]) or per slice ([T,K,Nf])."""
+    return _FeatureGemm.apply(A, W, act)
+
+
+def activation(x: torch.Tensor, act) -> torch.Tensor:
+    return _Activation.apply(x, act)

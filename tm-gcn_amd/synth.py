@@ -1,0 +1,207 @@
+"""Seeded synthetic inputs for the TM-GCN layer: the configurations of BASELINE.json / SURVEY §8d.
+
+There are no datasets in the container and no network, so the harness builds dynamic graphs of
+the reference scripts' shapes with the reference's preprocessing steps restated on scipy.sparse
+(vectorised — the reference's versions are per-slice / per-nnz Python loops):
+
+    symmetrise          read_data.m:172-180, read_data.py:88-111
+    edge-life window    read_data.m:183-187, read_data.py:116-125
+    add I, D^-1/2 C D^-1/2   read_data.m:190-199, read_data.py:130-169
+    band M              read_data.m:116-127 ("matlab": weight 1/d), read_data.py:55-62
+                        ("python": ones, row-normalised), SBM_our.py:88-96 ("sbm" = matlab)
+    M-product of Â      read_data.m:207-209, read_data.py:204-223, SBM_our.py:78-86
+    node features       ehf.create_node_features:597-609 (in/out degree -> F0 = 2)
+
+S4 (T=128, N=2M, deg 32, F=128) is generated directly on the device, slice by slice.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from .csr import BatchedCSR
+
+
+def band_M(T: int, no_diag: int = 20, kind: str = "matlab") -> np.ndarray:
+    """Lower-triangular band mixing matrix, fp64 [T,T]."""
+    M = np.zeros((T, T))
+    for d in range(min(no_diag, T)):
+        w = 1.0 if kind == "python" else 1.0 / (d + 1)
+        M[np.arange(d, T), np.arange(0, T - d)] = w
+    if kind == "python":
+        M = M / M.sum(axis=1, keepdims=True)
+    return M
+
+
+def random_slices(T: int, N: int, edges_per_slice: int, rng: np.random.Generator) -> List[sp.csr_matrix]:
+    """T raw directed adjacency slices with unit weights (duplicates merged)."""
+    out = []
+    for _ in range(T):
+        r = rng.integers(0, N, edges_per_slice)
+        c = rng.integers(0, N, edges_per_slice)
+        a = sp.coo_matrix((np.ones(edges_per_slice), (r, c)), shape=(N, N)).tocsr()
+        a.data[:] = 1.0
+        out.append(a)
+    return out
+
+
+def symmetrise(A: List[sp.spmatrix]) -> List[sp.csr_matrix]:
+    return [((a + a.T) / 2).tocsr() for a in A]
+
+
+def edge_life(A: List[sp.spmatrix], window: int = 10) -> List[sp.csr_matrix]:
+    """B[t] = sum of A[t-window+1 .. t]."""
+    out = []
+    for t in range(len(A)):
+        acc = A[t].copy()
+        for s in range(max(0, t - window + 1), t):
+            acc = acc + A[s]
+        out.append(acc.tocsr())
+    return out
+
+
+def normalise(B: List[sp.spmatrix]) -> List[sp.csr_matrix]:
+    """C = D^-1/2 (B + I) D^-1/2 with D = row sums of B + I."""
+    out = []
+    for b in B:
+        n = b.shape[0]
+        c = (b + sp.identity(n, format="csr")).tocsr()
+        d = 1.0 / np.sqrt(np.asarray(c.sum(axis=1)).ravel())
+        out.append((sp.diags(d) @ c @ sp.diags(d)).tocsr())
+    return out
+
+
+def m_product(C: List[sp.spmatrix], M: np.ndarray) -> List[sp.csr_matrix]:
+    """Mode-1 product of the sparse adjacency tensor: Ct[k] = sum_j M[k,j] C[j]."""
+    T = len(C)
+    out = []
+    for k in range(T):
+        acc = None
+        for j in np.nonzero(M[k])[0]:
+            term = C[j] * M[k, j]
+            acc = term if acc is None else acc + term
+        if acc is None:
+            acc = sp.csr_matrix(C[0].shape)
+        out.append(acc.tocsr())
+    return out
+
+
+def node_features(A: List[sp.spmatrix]) -> np.ndarray:
+    """X[t,:,0] = column sums, X[t,:,1] = row sums of the unweighted adjacency (fp64 [T,N,2])."""
+    T, N = len(A), A[0].shape[0]
+    X = np.zeros((T, N, 2))
+    for t, a in enumerate(A):
+        u = a.copy()
+        u.data[:] = 1.0
+        X[t, :, 0] = np.asarray(u.sum(axis=0)).ravel()
+        X[t, :, 1] = np.asarray(u.sum(axis=1)).ravel()
+    return X
+
+
+def to_coo_list(mats: List[sp.spmatrix], dtype=torch.float64) -> List[torch.Tensor]:
+    """scipy slices -> the reference's list of torch sparse COO matrices (explicit N×N size)."""
+    out = []
+    for m in mats:
+        m = m.tocoo()
+        idx = torch.from_numpy(np.stack([m.row, m.col]).astype(np.int64))
+        out.append(torch.sparse_coo_tensor(idx, torch.from_numpy(m.data).to(dtype), m.shape))
+    return out
+
+
+@dataclass
+class DynamicGraph:
+    T: int
+    N: int
+    A_raw: List[sp.csr_matrix]      # unweighted raw slices
+    C: List[sp.csr_matrix]          # normalised adjacency Ĉ (KWGCN input)
+    Ct: List[sp.csr_matrix]         # M-transformed adjacency Â (TM-GCN input)
+    M: np.ndarray                   # [T,T] fp64
+    X: np.ndarray                   # [T,N,F0] fp64
+    edges: np.ndarray               # [3,E] int64 (slice, src, dst)
+    labels: np.ndarray              # [E] int64
+
+    def At_list(self):
+        return to_coo_list(self.Ct)
+
+    def A_list(self):
+        return to_coo_list(self.C)
+
+
+def dynamic_graph(T: int, N: int, edges_per_slice: int, seed: int = 0, window: int = 10,
+                  no_diag: int = 20, m_kind: str = "matlab", F0: Optional[int] = None,
+                  neg_per_pos: int = 0) -> DynamicGraph:
+    """Reference-shaped dynamic graph: raw random slices -> Ĉ -> Â = M ×₁ Ĉ, features, labelled edges.
+
+    neg_per_pos = 0 : edge classification (labels random in {0,1}, the Bitcoin scripts' shape)
+    neg_per_pos > 0 : link prediction (positives label 0, ``neg_per_pos`` sampled non-edges label 1;
+                      ehf.augment_edges:500-526 with a seeded vectorised sampler)
+    """
+    rng = np.random.default_rng(seed)
+    A = random_slices(T, N, edges_per_slice, rng)
+    C = normalise(edge_life(symmetrise(A), window))
+    M = band_M(T, no_diag, m_kind)
+    Ct = m_product(C, M)
+    X = node_features(A) if F0 is None else rng.standard_normal((T, N, F0))
+    es, ls = [], []
+    for t, a in enumerate(A):
+        a = a.tocoo()
+        pos = np.stack([np.full(a.nnz, t), a.row, a.col]).astype(np.int64)
+        if neg_per_pos:
+            n_neg = neg_per_pos * a.nnz
+            r = rng.integers(0, N, n_neg)
+            c = rng.integers(0, N, n_neg)
+            keep = np.asarray(a.tocsr()[r, c]).ravel() == 0
+            neg = np.stack([np.full(int(keep.sum()), t), r[keep], c[keep]]).astype(np.int64)
+            es += [pos, neg]
+            ls += [np.zeros(pos.shape[1], np.int64), np.ones(neg.shape[1], np.int64)]
+        else:
+            es.append(pos)
+            ls.append(rng.integers(0, 2, pos.shape[1]).astype(np.int64))
+    return DynamicGraph(T, N, A, C, Ct, M, X, np.concatenate(es, axis=1), np.concatenate(ls))
+
+
+# Named stand-ins for the BASELINE configs (N and edges/slice are assumptions,
+# T / feature / hidden sizes are the scripts').
+CONFIGS = {
+    "S0": dict(T=10, N=500, edges_per_slice=1500, F0=16),                 # SBM-sized plumbing
+    "S1": dict(T=95, N=6000, edges_per_slice=250),                        # Bitcoin-OTC-shaped
+    "S2": dict(T=65, N=3800, edges_per_slice=2500, neg_per_pos=19),       # Reddit-LP-shaped
+    "S3": dict(T=150, N=1000, edges_per_slice=500),                       # AMLSim-shaped
+}
+
+
+# ---------------------------------------------------------------------------------------
+# S4: large synthetic layer input generated on the device
+# ---------------------------------------------------------------------------------------
+def device_er_csr(T: int, N: int, deg: int, device, first_slice: int = 0) -> BatchedCSR:
+    """T slices of a directed Erdős–Rényi-style graph: `deg` uniformly random out-neighbours per
+    row plus the self loop, values 1/(deg+1) (row-normalised), columns sorted inside each row.
+    Slice k is seeded with first_slice + k, so any rank can generate exactly its own slices."""
+    per = deg + 1
+    nnz_slice = N * per
+    col = torch.empty(T * nnz_slice, dtype=torch.int32, device=device)
+    g = torch.Generator(device=device)
+    for k in range(T):
+        g.manual_seed(1000003 * (first_slice + k) + 17)
+        c = torch.randint(0, N, (N, per), generator=g, device=device, dtype=torch.int32)
+        c[:, 0] = torch.arange(N, device=device, dtype=torch.int32)
+        c = torch.sort(c, dim=1).values
+        col[k * nnz_slice:(k + 1) * nnz_slice] = c.reshape(-1)
+        del c
+    val = torch.full((T * nnz_slice,), 1.0 / per, dtype=torch.float32, device=device)
+    rowptr = torch.arange(0, T * N + 1, dtype=torch.int64, device=device) * per
+    return BatchedCSR(rowptr, col, val, T, N)
+
+
+def device_features(T: int, N: int, F: int, device, first_slice: int = 0) -> torch.Tensor:
+    """X ~ U(0,1) fp32 [T,N,F], slice k seeded with first_slice + k."""
+    X = torch.empty(T, N, F, dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    for k in range(T):
+        g.manual_seed(7919 * (first_slice + k) + 3)
+        X[k].uniform_(0.0, 1.0, generator=g)
+    return X
