@@ -59,11 +59,17 @@ const char* tmgcn_last_error(void);
  * promises Mop[a][b] == 0 unless  a - band_lo <= b <= a + band_hi  (a, b are
  * indices into Mop, offsets included); pass band_lo = band_hi = Tm for a dense M.
  * Entries outside the promised band are never read.  X and Y must not overlap.
+ *
+ * x_group_rows / y_group_rows (0 = plain row order): group-interleaved row storage used as
+ * the send / receive layout of the slice<->node all-to-all of the sharded layer.  With
+ * g > 0, logical row k of a T-row tensor is stored at row (k % g) * (T / g) + k / g, i.e. as
+ * [g][T/g][C]: block kk holds row kk of every rank's slice range, contiguous per destination.
  */
 int tmgcn_mtransform_f32(const float* M, int32_t Tm, int32_t ldm, int32_t transpose,
                          int32_t row_off, int32_t col_off, int32_t T_out, int32_t T_in,
                          int32_t band_lo, int32_t band_hi,
-                         const float* X, float* Y, int64_t C, void* stream);
+                         const float* X, float* Y, int64_t C,
+                         int32_t x_group_rows, int32_t y_group_rows, void* stream);
 
 /* ---- P2: batched CSR SpMM (per-frontal-slice Â_k · X_k) -------------------------
  * Replaces the loops  for k in range(T): AtXt[k] = t.sparse.mm(At[k], Xt[k])

@@ -1,0 +1,210 @@
+"""GPU: every HIP kernel, called through the C-ABI, against the CPU oracle on seeded inputs.
+
+Tolerance: max|Δ| <= 1e-5 · max|ref| (fp32 kernels vs the oracle's fp64-accumulate / fp32-store;
+SURVEY §8c).  Integer/index work (CSR build) is bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _util import REL_TOL, assert_close, cptr, load_c_oracle
+from tmgcn_amd import ops, synth
+from tmgcn_amd.csr import BatchedCSR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rand_csr(T, N, avg_deg, seed, empty_rows=True):
+    g = torch.Generator().manual_seed(seed)
+    nnz = int(T * N * avg_deg)
+    k = torch.randint(0, T, (nnz,), generator=g)
+    i = torch.randint(0, N, (nnz,), generator=g)
+    j = torch.randint(0, N, (nnz,), generator=g)
+    if empty_rows and N > 3:
+        keep = i != 1  # row 1 of every slice stays empty
+        k, i, j = k[keep], i[keep], j[keep]
+    v = torch.randn(k.numel(), generator=g, dtype=torch.float64)
+    return BatchedCSR.from_coo(k, i, j, v, T, N)
+
+
+def ref_spmm(csr, X):
+    lib = load_c_oracle()
+    Y = torch.empty_like(X)
+    lib.ref_spmm(cptr(csr.rowptr), cptr(csr.col), cptr(csr.val), cptr(X), cptr(Y), csr.n_rows, csr.N, X.shape[2])
+    return Y
+
+
+# ------------------------------------------------------------------------------------- P2
+@pytest.mark.parametrize("F", [1, 2, 3, 4, 6, 8, 5, 12, 16, 20, 32, 64, 100, 128, 256, 260])
+@pytest.mark.parametrize("T,N,deg", [(3, 50, 4.0), (2, 301, 40.0), (1, 7, 1.5)])
+def test_spmm_vs_oracle(F, T, N, deg):
+    csr = rand_csr(T, N, deg, seed=F * 7 + N)
+    X = torch.randn(T, N, F, generator=torch.Generator().manual_seed(1))
+    Y = ops.kernels.spmm(csr.to(DEV), X.to(DEV))
+    assert_close(Y, ref_spmm(csr, X), REL_TOL, f"spmm F={F}")
+
+
+def test_spmm_long_rows_and_bitwise_reproducible():
+    # one hub row with 5000 non-zeros (several 64-wide batches) next to empty rows
+    T, N, F = 2, 400, 128
+    k = torch.cat([torch.zeros(5000, dtype=torch.long), torch.ones(10, dtype=torch.long)])
+    i = torch.cat([torch.full((5000,), 3), torch.arange(10)])
+    j = torch.randint(0, N, (5010,), generator=torch.Generator().manual_seed(5))
+    v = torch.randn(5010, generator=torch.Generator().manual_seed(6))
+    csr = BatchedCSR.from_coo(k, i, j, v, T, N)
+    X = torch.randn(T, N, F, generator=torch.Generator().manual_seed(7))
+    Y1 = ops.kernels.spmm(csr.to(DEV), X.to(DEV))
+    Y2 = ops.kernels.spmm(csr.to(DEV), X.to(DEV))
+    assert torch.equal(Y1, Y2)
+    assert_close(Y1, ref_spmm(csr, X), REL_TOL, "hub row")
+
+
+def test_spmm_transpose_is_adjoint():
+    T, N, F = 3, 120, 16
+    csr = rand_csr(T, N, 6.0, seed=3).to(DEV)
+    X = torch.randn(T, N, F, device=DEV)
+    Yb = torch.randn(T, N, F, device=DEV)
+    lhs = (ops.kernels.spmm(csr, X) * Yb).sum()
+    rhs = (X * ops.kernels.spmm(csr.transpose(), Yb)).sum()
+    assert abs(float(lhs - rhs)) <= 1e-4 * max(1.0, abs(float(lhs)))
+
+
+def test_spmm_empty_matrix():
+    csr = BatchedCSR.from_coo(torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long),
+                              torch.zeros(0, dtype=torch.long), torch.zeros(0), 2, 10).to(DEV)
+    Y = ops.kernels.spmm(csr, torch.randn(2, 10, 16, device=DEV))
+    assert float(Y.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------- P1
+def ref_mt(M64, X, transpose=False):
+    lib = load_c_oracle()
+    T = X.shape[0]
+    Y = torch.empty_like(X)
+    lib.ref_mtransform(cptr(M64), T, int(transpose), cptr(X), cptr(Y), X.numel() // T)
+    return Y
+
+
+@pytest.mark.parametrize("T,b", [(1, 1), (5, 3), (34, 20), (95, 20), (128, 20), (150, 7), (40, 40)])
+@pytest.mark.parametrize("N,F", [(37, 2), (64, 16), (11, 3)])
+@pytest.mark.parametrize("transpose", [False, True])
+def test_mtransform_band(T, b, N, F, transpose):
+    M = torch.from_numpy(synth.band_M(T, b, "matlab")).contiguous()
+    op = ops.MOperator(M, DEV)
+    assert op.band_lo == min(b, T) - 1 and op.band_hi == 0
+    X = torch.randn(T, N, F, generator=torch.Generator().manual_seed(T + N))
+    Y = ops.kernels.mtransform(op, X.to(DEV), transpose=transpose)
+    assert_close(Y, ref_mt(M, X, transpose), REL_TOL, f"mtransform T={T} b={b}")
+
+
+@pytest.mark.parametrize("T", [6, 64, 130])
+def test_mtransform_dense_and_inverse_roundtrip(T):
+    g = torch.Generator().manual_seed(T)
+    M = (torch.randn(T, T, generator=g, dtype=torch.float64) / T ** 0.5 + torch.eye(T, dtype=torch.float64) * 2).contiguous()
+    op = ops.MOperator(M, DEV)
+    X = torch.randn(T, 33, 4, generator=g)
+    Y = ops.kernels.mtransform(op, X.to(DEV))
+    assert_close(Y, ref_mt(M, X), REL_TOL, "dense M")
+    back = ops.kernels.mtransform(op.inverse(), Y)
+    assert_close(back, X, 1e-4, "Minv∘M = I")
+    # the reference's band M (read_data.m:116-124) has a dense lower-triangular inverse
+    Mb = torch.from_numpy(synth.band_M(T, 20, "matlab"))
+    opb = ops.MOperator(Mb, DEV)
+    back = ops.kernels.mtransform(opb.inverse(), ops.kernels.mtransform(opb, X.to(DEV)))
+    assert_close(back, X, 1e-4, "band Minv∘M = I")
+
+
+def test_mtransform_windowed_rows():
+    """row/col offsets: a rank computing only its own slices from the full X, and the adjoint."""
+    T, N, F = 24, 40, 4
+    M = torch.from_numpy(synth.band_M(T, 6, "matlab")).contiguous()
+    op = ops.MOperator(M, DEV)
+    X = torch.randn(T, N, F, generator=torch.Generator().manual_seed(9))
+    full = ref_mt(M, X)
+    part = ops.kernels.mtransform(op, X.to(DEV), row_off=8, col_off=0, T_out=8)
+    assert_close(part, full[8:16], REL_TOL, "row window")
+    # adjoint of that window: dX[j] = Σ_{k in window} M[8+k][j] dY[k]
+    dY = torch.randn(8, N, F, generator=torch.Generator().manual_seed(10))
+    pad = torch.zeros(T, N, F)
+    pad[8:16] = dY
+    dX = ops.kernels.mtransform(op, dY.to(DEV), transpose=True, row_off=0, col_off=8, T_out=T)
+    assert_close(dX, ref_mt(M, pad, True), REL_TOL, "adjoint window")
+
+
+# ------------------------------------------------------------------------------------- P3
+def ref_gemm(A, W, trans_w=False, per_slice=False):
+    lib = load_c_oracle()
+    T, N, K = A.shape
+    Nf = W.shape[-2] if trans_w else W.shape[-1]
+    Y = torch.empty(T, N, Nf)
+    lib.ref_gemm(cptr(A), cptr(W), cptr(Y), T * N, K, Nf, int(trans_w), N if per_slice else 0,
+                 W.shape[-1] * W.shape[-2] if per_slice else 0)
+    return Y
+
+
+@pytest.mark.parametrize("K,Nf", [(2, 6), (6, 6), (6, 2), (12, 2), (16, 16), (128, 128), (128, 64), (100, 50),
+                                  (32, 200), (300, 40), (7, 33), (64, 5)])
+@pytest.mark.parametrize("per_slice", [False, True])
+@pytest.mark.parametrize("trans_w", [False, True])
+def test_gemm(K, Nf, per_slice, trans_w):
+    T, N = 3, 150
+    g = torch.Generator().manual_seed(K * 31 + Nf)
+    A = torch.randn(T, N, K, generator=g)
+    wshape = ((Nf, K) if trans_w else (K, Nf))
+    W = torch.randn(*((T,) + wshape if per_slice else wshape), generator=g)
+    Y = ops.kernels.gemm(A.to(DEV), W.to(DEV), trans_w=trans_w)
+    assert_close(Y, ref_gemm(A, W, trans_w, per_slice), REL_TOL, f"gemm {K}x{Nf}")
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky", "selu"])
+@pytest.mark.parametrize("K,Nf", [(2, 6), (128, 128)])
+def test_gemm_fused_activation(act, K, Nf):
+    from oracle import tmgcn_oracle as orc
+    A = torch.randn(2, 100, K, generator=torch.Generator().manual_seed(1))
+    W = torch.randn(K, Nf, generator=torch.Generator().manual_seed(2))
+    Y, pre = ops.kernels.gemm(A.to(DEV), W.to(DEV), act=act, want_pre=True)
+    ref_pre = ref_gemm(A, W)
+    assert_close(pre, ref_pre, REL_TOL, "pre-activation")
+    assert_close(Y, orc.ACTS[act](pre.cpu()), 2e-6, "activation of the kernel's own pre-activation")
+    dy = torch.randn_like(ref_pre)
+    x = pre.cpu().clone().requires_grad_(True)
+    orc.ACTS[act](x).backward(dy)
+    assert_close(ops.kernels.act_bwd(pre, dy.to(DEV), act), x.grad, 2e-6, "activation backward")
+    assert_close(ops.kernels.act_fwd(pre, act), orc.ACTS[act](pre.cpu()), 2e-6, "activation forward")
+
+
+@pytest.mark.parametrize("K,Nf", [(2, 6), (6, 6), (12, 2), (16, 16), (128, 128), (100, 50), (300, 40), (64, 5)])
+@pytest.mark.parametrize("per_slice", [False, True])
+def test_gemm_dw(K, Nf, per_slice):
+    lib = load_c_oracle()
+    T, N = 3, 333
+    g = torch.Generator().manual_seed(K + Nf)
+    A = torch.randn(T, N, K, generator=g)
+    dY = torch.randn(T, N, Nf, generator=g)
+    ref = torch.empty((T, K, Nf) if per_slice else (K, Nf))
+    lib.ref_gemm_dw(cptr(A), cptr(dY), cptr(ref), T * N, K, Nf, N if per_slice else 0)
+    got = ops.kernels.gemm_dw(A.to(DEV), dY.to(DEV), per_slice)
+    assert_close(got, ref, REL_TOL, f"dW {K}x{Nf}")
+    assert torch.equal(got, ops.kernels.gemm_dw(A.to(DEV), dY.to(DEV), per_slice)), "dW not reproducible"
+
+
+def test_gemm_many_rows_persistent_loop():
+    """More tiles than the persistent grid (1024 blocks x 64 rows)."""
+    T, N, K, Nf = 2, 70000, 32, 32
+    g = torch.Generator().manual_seed(4)
+    A = torch.randn(T, N, K, generator=g)
+    W = torch.randn(K, Nf, generator=g)
+    assert_close(ops.kernels.gemm(A.to(DEV), W.to(DEV)), ref_gemm(A, W), REL_TOL, "persistent gemm")
+
+
+# ------------------------------------------------------------------------------------- errors
+def test_errors_are_runtime_errors():
+    with pytest.raises(RuntimeError):
+        ops.kernels.spmm(rand_csr(2, 10, 2.0, 1).to(DEV), torch.randn(2, 11, 4, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.kernels.spmm(rand_csr(2, 10, 2.0, 1).to(DEV), torch.randn(2, 10, 4))  # CPU tensor
+    with pytest.raises(RuntimeError):
+        ops.kernels.gemm(torch.randn(2, 10, 4, device=DEV), torch.randn(5, 3, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.kernels.spmm(rand_csr(2, 10, 2.0, 1).to(DEV), torch.randn(2, 10, 4, device=DEV).double())

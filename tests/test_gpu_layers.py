@@ -1,0 +1,169 @@
+"""GPU: the drop-in modules (tmgcn_amd.layers) against the golden fixtures captured from the
+real reference — logits, loss, parameter gradients, SGD trajectories — and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from _util import REL_TOL, assert_close, coo_list, golden, golden_names
+import tmgcn_amd.layers as ehf
+
+pytestmark = pytest.mark.gpu
+TOL = REL_TOL  # 1e-5 · max|ref|
+
+
+def _inputs(d, prefix=""):
+    X = torch.from_numpy(d[prefix + "X"])
+    T, N = X.shape[0], X.shape[1]
+    out = dict(T=T, N=N, X=X, M=torch.from_numpy(d[prefix + "M"]), edges=torch.from_numpy(d[prefix + "edges"]),
+               labels=torch.from_numpy(d[prefix + "labels"]), At=coo_list(d, "At", T, N, prefix=prefix))
+    if prefix + "A_k" in d:
+        out["A"] = coo_list(d, "A", T, N, prefix=prefix)
+    return out
+
+
+def _loss_grads(model, target, alpha=0.9):
+    crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([alpha, 1 - alpha], device="cuda"))
+    out = model()
+    loss = crit(out, target.cuda())
+    model.zero_grad()
+    loss.backward()
+    return out.detach(), float(loss.detach()), {n: p.grad for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("name", golden_names("g1_"))
+def test_g1_AtXt(name):
+    d = golden(name)
+    i = _inputs(d)
+    m = ehf.EmbeddingGCN(i["At"], i["X"], i["edges"], i["M"], hidden_feat=[3, 2], condensed_W=True, use_Minv=False)
+    assert m.AtXt.dtype == torch.float32 and m.AtXt.is_cuda
+    assert_close(m.AtXt, d["AtXt"], TOL, name)
+
+
+@pytest.mark.parametrize("name", golden_names("g2_"))
+def test_g2_gcn(name):
+    d = golden(name)
+    i = _inputs(d)
+    torch.manual_seed(int(d["seed"]))
+    m = ehf.EmbeddingGCN(i["At"], i["X"], i["edges"], i["M"], hidden_feat=[6, 2], condensed_W=d["W0"].ndim == 2,
+                         use_Minv=name.endswith("minv_fp32"))
+    # same seed => same initial weights as the reference (CPU generator, same draw order)
+    assert np.array_equal(m.W.detach().cpu().numpy(), d["W0"]) and np.array_equal(m.U.detach().cpu().numpy(), d["U0"])
+    out, loss, g = _loss_grads(m, i["labels"])
+    assert out.dtype == torch.float32 and tuple(out.shape) == d["logits"].shape
+    tol = 2e-5 if name.endswith("minv_fp32") else TOL  # that fixture is itself all-fp32 in the reference
+    assert_close(out, d["logits"], tol, name + " logits")
+    assert abs(loss - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    assert_close(g["W"], d["dW"], tol, name + " dW")
+    assert_close(g["U"], d["dU"], tol, name + " dU")
+
+
+@pytest.mark.parametrize("name", golden_names("g3_"))
+def test_g3_gcn2(name):
+    d = golden(name)
+    i, v = _inputs(d), _inputs(d, prefix="val_")
+    _, _, branch, nl, cond = name.split("_")
+    torch.manual_seed(int(d["seed"]))
+    m = ehf.EmbeddingGCN2(i["At"], i["X"], i["edges"], i["M"], hidden_feat=[6, 6, 2], condensed_W=cond.endswith("1"),
+                          use_Minv=False, apply_M_twice=branch in ("twice", "three"),
+                          apply_M_three_times=branch == "three", nonlin2=nl)
+    for k in ("W1", "W2", "U"):
+        assert np.array_equal(getattr(m, k).detach().cpu().numpy(), d[k + "0"]), k
+    out, loss, g = _loss_grads(m, i["labels"])
+    assert_close(out, d["logits"], TOL, name + " logits")
+    for k in ("W1", "W2", "U"):
+        assert_close(g[k], d["d" + k], TOL, name + " d" + k)
+    with torch.no_grad():  # validation call: layer 2 keeps the training adjacency (ehf:339-348)
+        out_val = m(v["At"], v["X"], v["edges"])
+    assert_close(out_val, d["logits_val"], TOL, name + " val logits")
+    # anything that is not (list, Tensor, Tensor) falls back to the cached tensors (ehf:316)
+    with torch.no_grad():
+        assert torch.equal(m(None, v["X"], v["edges"]), m())
+
+
+@pytest.mark.parametrize("name", golden_names("g4_"))
+def test_g4_kwgcn(name):
+    d = golden(name)
+    i = _inputs(d)
+    two = "2layer" in name
+    torch.manual_seed(int(d["seed"]))
+    m = ehf.EmbeddingKWGCN(i["A"], i["X"], i["edges"], hidden_feat=[6, 5, 2] if two else [6, 2], nonlin2=name.split("_")[-1])
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), d[n + "0"]), n
+    out, loss, g = _loss_grads(m, i["labels"])
+    assert_close(out, d["logits"], TOL, name)
+    for n in g:
+        assert_close(g[n], d["d" + n], TOL, name + " d" + n)
+
+
+def test_g5_chess():
+    d = golden("g5_chess_gcn2")
+    T, N = int(d["T"]), int(d["N"])
+    At = coo_list(d, "At", T, N)
+    torch.manual_seed(int(d["seed"]))
+    m = ehf.EmbeddingGCN2(At, torch.from_numpy(d["X"]), torch.from_numpy(d["edges"]), torch.from_numpy(d["M"]),
+                          hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False, nonlin2="selu")
+    out, loss, g = _loss_grads(m, torch.from_numpy(d["labels"]))
+    assert_close(out, d["logits"], TOL, "chess logits")
+    for k in ("W1", "W2", "U"):
+        assert_close(g[k], d["d" + k], TOL, "chess d" + k)
+
+
+@pytest.mark.parametrize("kind", ["gcn", "gcn2"])
+def test_g6_sgd_trajectory(kind):
+    """The reference's training loop (SGD lr .01 mom .9, weighted CE) runs unchanged on the module."""
+    d = golden("g6_sgd_" + kind)
+    i = _inputs(d)
+    torch.manual_seed(int(d["seed"]))
+    if kind == "gcn":
+        m = ehf.EmbeddingGCN(i["At"], i["X"], i["edges"], i["M"], hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
+    else:
+        m = ehf.EmbeddingGCN2(i["At"], i["X"], i["edges"], i["M"], hidden_feat=[6, 6, 2], condensed_W=True,
+                              use_Minv=False, nonlin2="selu")
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1], device="cuda"))
+    tgt = i["labels"].cuda()
+    losses = []
+    for _ in range(10):
+        opt.zero_grad()
+        loss = crit(m(), tgt)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert_close(np.array(losses), d["losses"], 1e-4, kind + " loss trajectory")
+    for n, p in m.named_parameters():
+        assert_close(p.detach(), d[n + "_final"], 1e-4, kind + " final " + n)
+
+
+def test_gcn2_use_minv_runs_and_matches_dense_math():
+    """EmbeddingGCN2(use_Minv=True) raises a dtype error in the reference for every input dtype
+    (SURVEY fact 3); here the math the code describes is computed.  Checked against fp64 einsum."""
+    d = golden("g3_gcn2_default_relu_condensed1")
+    i = _inputs(d)
+    torch.manual_seed(5)
+    m = ehf.EmbeddingGCN2(i["At"], i["X"], i["edges"], i["M"], hidden_feat=[6, 6, 2], condensed_W=True,
+                          use_Minv=True, nonlin2="relu")
+    out = m().detach().cpu().double()
+    A = m.At.to_dense().cpu().double()
+    M = i["M"]
+    Minv = torch.linalg.inv(M)
+    mt = lambda Q, Z: torch.einsum("kj,jnf->knf", Q, Z)
+    sp = lambda Z: torch.einsum("knm,kmf->knf", A, Z)
+    W1, W2, U = (p.detach().cpu().double() for p in (m.W1, m.W2, m.U))
+    Y = torch.relu(mt(Minv, sp(mt(M, i["X"])) @ W1))
+    Z = mt(Minv, sp(mt(M, Y)) @ W2).reshape(-1, 6)
+    e = i["edges"]
+    ref = torch.cat((Z[e[0] * i["N"] + e[1]], Z[e[0] * i["N"] + e[2]]), 1) @ U
+    assert_close(out, ref, 1e-4, "use_Minv 2-layer")
+
+
+def test_accepts_prebuilt_batched_csr_and_gpu_inputs():
+    from tmgcn_amd.csr import BatchedCSR
+    d = golden("g2_gcn_condensed1")
+    i = _inputs(d)
+    csr = BatchedCSR.from_coo_list(i["At"], N=i["N"], device="cuda")
+    torch.manual_seed(1)
+    a = ehf.EmbeddingGCN(i["At"], i["X"], i["edges"], i["M"], hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
+    torch.manual_seed(1)
+    b = ehf.EmbeddingGCN(csr, i["X"].cuda().float(), i["edges"].cuda(), i["M"], hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
+    assert torch.equal(a(), b())
+    assert torch.equal(a(i["At"], i["X"], i["edges"]), a())  # recompute branch == cached branch

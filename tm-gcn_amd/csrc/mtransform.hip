@@ -28,7 +28,14 @@ struct MtArgs {
   float* Y;
   int64_t C;  // columns (floats)
   int32_t rows_per_chunk;
+  int32_t x_tl, y_tl;  // group-interleaved row storage (0 = plain row order), see tmgcn.h
 };
+
+// storage position of logical row k of a tensor with T rows stored in groups of tl rows:
+// (k % tl) * (T / tl) + k / tl — the send/receive layout of the slice<->node all-to-all.
+__device__ __forceinline__ int64_t row_pos(int k, int T, int tl) {
+  return tl ? (int64_t)(k % tl) * (T / tl) + k / tl : k;
+}
 
 __device__ __forceinline__ float mop(const MtArgs& a, int k, int j) {
   const int64_t r = a.row_off + k, c = a.col_off + j;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256) void mtransform_band_kernel(MtArgs a) {
     for (int i = 0; i < W; ++i) {
       const int q = qb + i;  // slot i  <->  input row q  (q mod W == i since qb % W == 0)
       if (q >= q_first && q <= q_last) {
-        win[i] = (q >= 0 && q < a.T_in) ? CT::load(a.X + (int64_t)q * a.C + c) : CT::zero();
+        win[i] = (q >= 0 && q < a.T_in) ? CT::load(a.X + row_pos(q, a.T_in, a.x_tl) * a.C + c) : CT::zero();
         const int k = q - d_hi;  // output row completed by this input row
         if (k >= k_begin) {
           V acc = CT::zero();
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void mtransform_band_kernel(MtArgs a) {
               CT::fma(acc, mop(a, k, j), win[(i - d + W) % W]);
             }
           }
-          CT::store(a.Y + (int64_t)k * a.C + c, acc);
+          CT::store(a.Y + row_pos(k, a.T_out, a.y_tl) * a.C + c, acc);
         }
       }
     }
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256) void mtransform_dense_kernel(MtArgs a) {
   int j_hi = k0 + RT - 1 + d_hi;
   if (j_hi > a.T_in - 1) j_hi = a.T_in - 1;
   for (int j = j_lo; j <= j_hi; ++j) {
-    const V x = CT::load(a.X + (int64_t)j * a.C + c);
+    const V x = CT::load(a.X + row_pos(j, a.T_in, a.x_tl) * a.C + c);
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const int k = k0 + i;
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(256) void mtransform_dense_kernel(MtArgs a) {
 #pragma unroll
   for (int i = 0; i < RT; ++i) {
     const int k = k0 + i;
-    if (k < a.T_out) CT::store(a.Y + (int64_t)k * a.C + c, acc[i]);
+    if (k < a.T_out) CT::store(a.Y + row_pos(k, a.T_out, a.y_tl) * a.C + c, acc[i]);
   }
 }
 
@@ -194,7 +201,8 @@ using namespace tmgcn;
 extern "C" int tmgcn_mtransform_f32(const float* M, int32_t Tm, int32_t ldm, int32_t transpose,
                                      int32_t row_off, int32_t col_off, int32_t T_out,
                                      int32_t T_in, int32_t band_lo, int32_t band_hi,
-                                     const float* X, float* Y, int64_t C, void* stream) {
+                                     const float* X, float* Y, int64_t C, int32_t x_group_rows,
+                                     int32_t y_group_rows, void* stream) {
   TMGCN_REQUIRE(Tm > 0 && ldm >= Tm, "mtransform: bad operator shape Tm=%d ldm=%d", Tm, ldm);
   TMGCN_REQUIRE(T_out >= 0 && T_in >= 0 && C >= 0, "mtransform: negative extent");
   TMGCN_REQUIRE(row_off >= 0 && col_off >= 0 && row_off + T_out <= Tm && col_off + T_in <= Tm,
@@ -204,9 +212,13 @@ extern "C" int tmgcn_mtransform_f32(const float* M, int32_t Tm, int32_t ldm, int
   if (T_out == 0 || C == 0) return TMGCN_OK;
   TMGCN_REQUIRE(M && X && Y, "mtransform: null pointer");
   TMGCN_REQUIRE(X != Y, "mtransform: in-place transform is not supported");
+  TMGCN_REQUIRE(x_group_rows >= 0 && (x_group_rows == 0 || T_in % x_group_rows == 0),
+                "mtransform: x_group_rows=%d does not divide T_in=%d", x_group_rows, T_in);
+  TMGCN_REQUIRE(y_group_rows >= 0 && (y_group_rows == 0 || T_out % y_group_rows == 0),
+                "mtransform: y_group_rows=%d does not divide T_out=%d", y_group_rows, T_out);
   if (band_lo > Tm) band_lo = Tm;
   if (band_hi > Tm) band_hi = Tm;
-  MtArgs a{M, ldm, transpose, row_off, col_off, T_out, T_in, band_lo, band_hi, X, Y, C, T_out};
+  MtArgs a{M, ldm, transpose, row_off, col_off, T_out, T_in, band_lo, band_hi, X, Y, C, T_out, x_group_rows, y_group_rows};
   const bool vec_ok = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
   return vec_ok ? dispatch<4>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);

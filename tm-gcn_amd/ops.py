@@ -84,7 +84,7 @@ class HipKernels:
 
     # P1 ---------------------------------------------------------------------------------
     def mtransform(self, op: MOperator, X: torch.Tensor, transpose=False, row_off=0, col_off=0,
-                   T_out: Optional[int] = None) -> torch.Tensor:
+                   T_out: Optional[int] = None, x_group_rows=0, y_group_rows=0) -> torch.Tensor:
         lib = _lib.load()
         _want(X, "mtransform X")
         T_in = X.shape[0]
@@ -94,7 +94,8 @@ class HipKernels:
         Y = torch.empty((T_out,) + tuple(X.shape[1:]), dtype=torch.float32, device=X.device)
         lo, hi = (op.band_hi, op.band_lo) if transpose else (op.band_lo, op.band_hi)
         rc = lib.tmgcn_mtransform_f32(_ptr(op.M), op.T, op.T, int(bool(transpose)), row_off, col_off,
-                                      T_out, T_in, lo, hi, _ptr(X), _ptr(Y), C_, _stream(X))
+                                      T_out, T_in, lo, hi, _ptr(X), _ptr(Y), C_, x_group_rows, y_group_rows,
+                                      _stream(X))
         _lib.check(rc, "tmgcn_mtransform_f32")
         return Y
 
@@ -178,15 +179,17 @@ kernels = HipKernels()
 # ---------------------------------------------------------------------------------------
 class _MTransform(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, op, row_off, col_off, T_out):
+    def forward(ctx, X, op, row_off, col_off, T_out, x_group_rows, y_group_rows):
         ctx.op, ctx.row_off, ctx.col_off, ctx.T_in = op, row_off, col_off, X.shape[0]
-        return kernels.mtransform(op, X, False, row_off, col_off, T_out)
+        ctx.xg, ctx.yg = x_group_rows, y_group_rows
+        return kernels.mtransform(op, X, False, row_off, col_off, T_out, x_group_rows, y_group_rows)
 
     @staticmethod
     def backward(ctx, dY):
         # Y[k] = Σ_j M[ro+k][co+j] X[j]   =>   dX[j] = Σ_k Mᵀ[co+j][ro+k] dY[k]
-        dX = kernels.mtransform(ctx.op, dY.contiguous(), True, ctx.col_off, ctx.row_off, ctx.T_in)
-        return dX, None, None, None, None
+        dX = kernels.mtransform(ctx.op, dY.contiguous(), True, ctx.col_off, ctx.row_off, ctx.T_in,
+                                x_group_rows=ctx.yg, y_group_rows=ctx.xg)
+        return dX, None, None, None, None, None, None
 
 
 class _Spmm(torch.autograd.Function):
@@ -239,9 +242,11 @@ class _Activation(torch.autograd.Function):
         return kernels.act_bwd(x, dy.contiguous(), ctx.act), None
 
 
-def m_transform(X: torch.Tensor, op: MOperator, row_off=0, col_off=0, T_out=None) -> torch.Tensor:
-    """P1: Y[k] = Σ_j M[row_off+k][col_off+j] · X[j]  along the first (time) mode."""
-    return _MTransform.apply(X, op, row_off, col_off, T_out)
+def m_transform(X: torch.Tensor, op: MOperator, row_off=0, col_off=0, T_out=None, x_group_rows=0,
+                y_group_rows=0) -> torch.Tensor:
+    """P1: Y[k] = Σ_j M[row_off+k][col_off+j] · X[j]  along the first (time) mode.
+    x_group_rows / y_group_rows: group-interleaved row storage of X / Y (include/tmgcn.h)."""
+    return _MTransform.apply(X, op, row_off, col_off, T_out, x_group_rows, y_group_rows)
 
 
 def spmm(A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
