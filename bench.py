@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — TM-GCN layer forward+backward throughput, (edges×T)/s  (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input:
+    forward   Y  = ((Â ⋆ (M ×₁ X)) · W)            P1 -> [exchange] -> P2 -> P3
+    backward  dX, dW from a given dY               P3ᵀ (dA, dW) -> P2ᵀ -> [exchange] -> P1ᵀ
+Workload (SURVEY §8d "S4", the config the metric is quoted on): per GPU 16 frontal slices of an
+N = 2,000,000-node graph, 32 random out-neighbours per row + self loop (66 M stored non-zeros
+per slice), F = 128 -> 128 features, band M with 20 diagonals, fp32.  Weak scaling: T = 16·G.
+Inputs are generated on the device (seeded by global slice index) and are resident in HBM
+before the timed region.  One unit of work = one stored non-zero of one slice ("edge-slice").
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3
+
+Rank 0 prints ONE JSON line (driver contract) with `roofline` (dominant kernel = forward
+SpMM, HIP events on the launch stream) and `cpu_baseline` (the oracle executed the
+reference's way on the host cores, on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--nodes", type=int, default=2_000_000)
+    p.add_argument("--slices-per-gpu", type=int, default=16)
+    p.add_argument("--deg", type=int, default=32)
+    p.add_argument("--feat", type=int, default=128)
+    p.add_argument("--band", type=int, default=20)
+    p.add_argument("--exchange", choices=["a2a", "allgather"], default="a2a")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-nodes", type=int, default=500_000, help="N of the CPU-baseline sample")
+    return p.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle's layer fwd+bwd (list of COO fp64, one sparse.mm per slice, autograd) on the
+    host cores, on a bounded sample: 2 slices of the same degree/F at N = cpu-nodes."""
+    from oracle import tmgcn_oracle as orc
+    from tmgcn_amd import synth
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Tc, Nc, F = 2, min(args.nodes, args.cpu_nodes), args.feat
+    A = synth.device_er_csr(Tc, Nc, args.deg, "cpu")
+    At = A.to_coo_list(torch.float64)
+    X = synth.device_features(Tc, Nc, F, "cpu").double()
+    M = torch.from_numpy(synth.band_M(Tc, args.band, "matlab"))
+    g = torch.Generator().manual_seed(1)
+    W = torch.randn(F, F, generator=g) * 0.1
+    dY = torch.randn(Tc, Nc, F, generator=g)
+    orc.layer_fwd_bwd(M, At, X, W, dY)  # warm-up (allocator, thread pool)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        orc.layer_fwd_bwd(M, At, X, W, dY)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 5:
+            break
+    try:
+        model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": A.nnz * reps / el, "unit": "edge-slices/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x fwd+bwd of {Tc} slices, N={Nc}, deg={args.deg}+1, F={F}->{F} "
+                      f"(torch CPU, {cores} threads, {model}); {el / reps:.2f} s each"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from tmgcn_amd import _lib, ops, synth
+    from tmgcn_amd.dist import ShardedTMGCNLayer
+    _lib.load()  # fail loudly if the HIP library is missing
+
+    G, Tl, N, F = world, args.slices_per_gpu, args.nodes, args.feat
+    T = Tl * G
+    k0 = rank * Tl
+    A = synth.device_er_csr(Tl, N, args.deg, dev, first_slice=k0)
+    A.transpose()  # backward operand, built once (plan time, not timed)
+    M = synth.band_M(T, args.band, "matlab")
+    layer = ShardedTMGCNLayer(A, M, T, group=None, exchange=args.exchange)
+    shape = layer.input_shape(F)
+    if G > 1 and args.exchange == "a2a":
+        # node shard of the synthetic features: slice k seeded by k, columns of this rank's nodes
+        X = synth.device_features(T, shape[1], F, dev, first_slice=1000 * rank)
+    else:
+        X = synth.device_features(shape[0], N, F, dev, first_slice=k0)
+    X.requires_grad_(True)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    W = (torch.randn(F, F, device=dev, generator=g) * 0.1).requires_grad_(True)  # same on every rank
+    g.manual_seed(99 + rank)
+    dY = torch.randn(Tl, N, F, device=dev, generator=g)
+
+    def step():
+        X.grad = None
+        W.grad = None
+        Y = layer(X, W)
+        Y.backward(dY)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ops.kernels.timer = ops.KernelTimer()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kt = ops.kernels.timer.summary()
+    ops.kernels.timer = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        n = torch.tensor([A.nnz], device=dev, dtype=torch.int64)
+        dist.all_reduce(n)
+        total_nnz = int(n.item())
+    else:
+        total_nnz = A.nnz
+
+    if rank == 0:
+        # roofline of the dominant kernel (forward SpMM): SURVEY §8d no-reuse gather model,
+        # bytes per edge-slice = 8 (col+val) + F*4 (gathered row) + (4 + F*4)/d (rowptr + output row)
+        d = A.nnz / A.n_rows
+        bytes_per_unit = 8 + F * 4 + (4 + F * 4) / d
+        sp = kt["spmm"]
+        achieved = bytes_per_unit * A.nnz / (sp["avg_ms"] * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("nodes") == N and rec.get("feat") == F and rec.get("slices_per_gpu") == Tl:
+                    traffic = rec["spmm_hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "TM-GCN layer fwd+bwd throughput (edges x T)/s",
+            "value": total_nnz * args.steps / elapsed,
+            "unit": "edge-slices/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"S4 TM-GCN layer fwd+bwd: {Tl} slices/GPU (T={T}), N={N}, "
+                                   f"deg={args.deg}+self, F={F}->{F}, band-M b={args.band}, fp32",
+                       "exchange": args.exchange if world > 1 else "none",
+                       "edge_slices_per_step": total_nnz},
+            "roofline": {"kernel": "spmm_vec4 (forward P2)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "bytes_per_edge_slice": bytes_per_unit,
+                         "avg_launch_ms": sp["avg_ms"]},
+            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

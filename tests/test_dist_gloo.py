@@ -1,0 +1,110 @@
+"""CPU, world_size 2, gloo: the slice-sharded layer (tmgcn_amd.dist) reproduces the unsharded
+layer — forward, dX, dW — in both exchange modes.  The device kernels are substituted by the
+oracle here (no GPU in this environment); the collectives and the sharding arithmetic are the
+product's."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _setup(rank, world, port):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from tmgcn_amd import ops
+    from _oracle_kernels import OracleKernels
+    ops.kernels = OracleKernels()
+
+
+def _problem(T, N, F0, F1, b, condensed):
+    from tmgcn_amd import synth
+    g = synth.dynamic_graph(T, N, edges_per_slice=3 * N, seed=7, no_diag=b, F0=F0)
+    gen = torch.Generator().manual_seed(3)
+    W = torch.randn(F0, F1, generator=gen) if condensed else torch.randn(T, F0, F1, generator=gen)
+    dY = torch.randn(T, N, F1, generator=gen)
+    return g, torch.from_numpy(g.X).float(), W, dY
+
+
+def _worker(rank, world, port, exchange, condensed, act, ret):
+    try:
+        _setup(rank, world, port)
+        from tmgcn_amd.csr import BatchedCSR
+        from tmgcn_amd.dist import ShardedTMGCNLayer, even_bounds
+        T, N, F0, F1, b = 8, 30, 4, 6, 5
+        g, X, W, dY = _problem(T, N, F0, F1, b, condensed)
+        k0, k1 = even_bounds(T, world)[rank]
+        n0, n1 = even_bounds(N, world)[rank]
+        A_local = BatchedCSR.from_scipy_list(g.Ct).slices(k0, k1)
+        layer = ShardedTMGCNLayer(A_local, g.M, T, group=None, exchange=exchange)
+        assert layer.G == world and layer.k0 == k0
+        Xin = (X[:, n0:n1] if exchange == "a2a" else X[k0:k1]).contiguous().clone().requires_grad_(True)
+        Wl = (W if condensed else W[k0:k1]).contiguous().clone().requires_grad_(True)
+        Y = layer(Xin, Wl, act=act)
+        Y.backward(dY[k0:k1].contiguous())
+
+        # unsharded answer, computed redundantly on every rank
+        dist.barrier()
+        Yr, dXr, dWr = _reference_local(g, X, W, dY, act)
+        tol = 2e-5
+        def close(a, b, what):
+            err = float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+            assert err <= tol, f"{what}: {err:.2e}"
+        close(Y.detach(), Yr[k0:k1], "Y")
+        close(Xin.grad, dXr[:, n0:n1] if exchange == "a2a" else dXr[k0:k1], "dX")
+        close(Wl.grad, dWr if condensed else dWr[k0:k1], "dW")
+        if exchange == "a2a":  # slice-sharded output back to node-sharded (input of a next layer)
+            Yn = layer.to_node_sharded(Y.detach())
+            close(Yn, Yr[:, n0:n1], "to_node_sharded")
+        dist.barrier()
+        ret[rank] = "ok"
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _reference_local(g, X, W, dY, act):
+    """Unsharded layer on this process only (no collectives): dense fp64 einsum + autograd."""
+    from oracle import tmgcn_oracle as orc
+    from tmgcn_amd.csr import BatchedCSR
+    A = BatchedCSR.from_scipy_list(g.Ct).to_dense().double()
+    M = torch.from_numpy(g.M)
+    X = X.double().clone().requires_grad_(True)
+    W = W.double().clone().requires_grad_(True)
+    Xt = torch.einsum("kj,jnf->knf", M, X)
+    AX = torch.einsum("knm,kmf->knf", A, Xt)
+    pre = AX @ W if W.dim() == 2 else torch.einsum("knf,kfg->kng", AX, W)
+    Y = orc.ACTS[act](pre) if act else pre
+    Y.backward(dY.double())
+    return Y.detach(), X.grad, W.grad
+
+
+@pytest.mark.parametrize("exchange", ["a2a", "allgather"])
+@pytest.mark.parametrize("condensed,act", [(True, None), (False, "selu")])
+def test_sharded_layer_matches_unsharded(exchange, condensed, act):
+    world = 2
+    port = 29600 + (hash((exchange, condensed)) % 200)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, exchange, condensed, act, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", f"rank {r}:\n{ret.get(r)}"
+
+
+def test_even_bounds():
+    from tmgcn_amd.dist import even_bounds
+    assert even_bounds(128, 8)[3] == (48, 64)
+    b = even_bounds(10, 4)
+    assert b == [(0, 3), (3, 6), (6, 8), (8, 10)]

@@ -132,12 +132,32 @@ class BatchedCSR:
         return torch.repeat_interleave(torch.arange(self.n_rows, device=self.device), counts)
 
     def transpose(self) -> "BatchedCSR":
-        """Per-slice transpose (Â_kᵀ for every k), cached.  Used by the backward SpMM."""
+        """Per-slice transpose (Â_kᵀ for every k), cached.  Used by the backward SpMM.
+        Built slice by slice (one stable sort of nnz_k keys each) so the peak scratch is a few
+        times one slice, not the whole tensor; inside a transposed row the entries keep the
+        order of the original rows, so the backward sums are reproducible too."""
         if self._t is None:
-            rid = self.row_ids()
-            k = rid // self.N
-            i = rid - k * self.N
-            t = BatchedCSR.from_coo(k, self.col.to(torch.int64), i, self.val, self.T, self.N, device=self.device)
+            N, T, dev = self.N, self.T, self.device
+            counts = torch.zeros(T * N, dtype=torch.int64, device=dev)
+            col_t = torch.empty_like(self.col)
+            val_t = torch.empty_like(self.val)
+            bounds = self.rowptr[::N].tolist()  # nnz offset of every slice (T+1 host ints)
+            for k in range(T):
+                a, b = bounds[k], bounds[k + 1]
+                if a == b:
+                    continue
+                rp = self.rowptr[k * N:(k + 1) * N + 1] - a
+                rows = torch.repeat_interleave(torch.arange(N, device=dev, dtype=torch.int32),
+                                               rp[1:] - rp[:-1])
+                c = self.col[a:b]
+                order = torch.sort(c, stable=True).indices
+                counts[k * N:(k + 1) * N] = torch.bincount(c, minlength=N)
+                col_t[a:b] = rows[order]
+                val_t[a:b] = self.val[a:b][order]
+                del rows, order, c
+            rowptr_t = torch.zeros(T * N + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(counts, 0, out=rowptr_t[1:])
+            t = BatchedCSR(rowptr_t, col_t, val_t, T, N)
             t._t = self
             self._t = t
         return self._t

@@ -1,0 +1,200 @@
+"""Frontal-slice sharding of the TM-GCN layer across the GPUs of one node (RCCL over xGMI).
+
+Between P1 and the output of P3 the T frontal slices are independent (ehf:206-207, 222 loop
+over k with no cross-k term), so rank r owns the contiguous slice range [k0_r, k1_r): its block
+of the batched CSR, its rows of every [T,N,F] activation.  Only the M-transform mixes slices,
+so the layer needs exactly ONE exchange, placed in front of (or behind) P1, and its adjoint in
+the backward pass.  Two exchange modes (DESIGN.md §6 has the byte counts):
+
+  "a2a"        the layer input arrives NODE-sharded ([T, N/G, F]: all slices of this rank's
+               nodes).  P1 runs locally on full tube fibres (any M, dense or banded) and writes
+               its output in the all-to-all send layout; one all-to-all per local slice
+               re-partitions it to SLICE-sharded [T/G, N, F]; P2 and P3 are local.  Each rank
+               moves (G-1)/G of ITS OWN shard, spread over all 7 xGMI links.
+  "allgather"  the layer input arrives SLICE-sharded ([T/G, N, F]); one all-gather replicates
+               it, every rank transforms only its own output slices (row window of M), P2 and
+               P3 are local.  Backward is a reduce-scatter.  This is the north-star's literal
+               pattern; it materialises the whole [T,N,F] tensor on every GPU, so it is the
+               choice only when that fits (small N·F or small G).
+
+condensed_W (one shared weight) adds an all-reduce of dW — F0·F1 floats.
+The collectives used (all_to_all_single, all_gather_into_tensor, reduce_scatter_tensor,
+all_reduce) exist in both the RCCL ("nccl") and gloo backends, so the sharding logic is
+covered by world_size-2 CPU tests with the kernels substituted by the oracle.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .csr import BatchedCSR
+
+
+def even_bounds(n: int, parts: int) -> List[Tuple[int, int]]:
+    """Contiguous ranges of n items over `parts` ranks, sizes differing by at most one."""
+    base, rem = divmod(n, parts)
+    out, lo = [], 0
+    for r in range(parts):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _world(group):
+    if not dist.is_available() or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+# ---------------------------------------------------------------------------------------
+# exchanges (autograd-aware)
+# ---------------------------------------------------------------------------------------
+def _a2a_node_to_slice(send: torch.Tensor, Tl: int, N: int, group) -> torch.Tensor:
+    """send: [Tl][G][Nl][F] (block kk = row kk of every rank's slice range) -> [Tl][N][F]."""
+    G = dist.get_world_size(group)
+    Nl, F = send.shape[-2], send.shape[-1]
+    out = torch.empty(Tl, N, F, dtype=send.dtype, device=send.device)
+    for kk in range(Tl):
+        dist.all_to_all_single(out[kk].view(G, Nl, F), send[kk], group=group)
+    return out
+
+
+def _a2a_slice_to_node(x: torch.Tensor, G: int, group) -> torch.Tensor:
+    """x: [Tl][N][F] slice-sharded -> [Tl][G][Nl][F] in the group-interleaved layout."""
+    Tl, N, F = x.shape
+    Nl = N // G
+    out = torch.empty(Tl, G, Nl, F, dtype=x.dtype, device=x.device)
+    for kk in range(Tl):
+        dist.all_to_all_single(out[kk], x[kk].view(G, Nl, F), group=group)
+    return out
+
+
+class _NodeToSlice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, send, Tl, N, group):
+        ctx.group, ctx.G = group, dist.get_world_size(group)
+        return _a2a_node_to_slice(send, Tl, N, group)
+
+    @staticmethod
+    def backward(ctx, d):
+        return _a2a_slice_to_node(d.contiguous(), ctx.G, ctx.group), None, None, None
+
+
+class _SliceToNode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group, ctx.G = group, dist.get_world_size(group)
+        ctx.N = x.shape[1]
+        return _a2a_slice_to_node(x.contiguous(), ctx.G, group)
+
+    @staticmethod
+    def backward(ctx, d):
+        return _a2a_node_to_slice(d.contiguous(), d.shape[0], ctx.N, ctx.group), None
+
+
+class _AllGatherSlices(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        G = dist.get_world_size(group)
+        out = torch.empty((G * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        G = dist.get_world_size(ctx.group)
+        out = torch.empty((d.shape[0] // G,) + tuple(d.shape[1:]), dtype=d.dtype, device=d.device)
+        dist.reduce_scatter_tensor(out, d.contiguous(), op=dist.ReduceOp.SUM, group=ctx.group)
+        return out, None
+
+
+class _SharedWeight(torch.autograd.Function):
+    """Identity on a replicated weight; sums its gradient over the ranks."""
+
+    @staticmethod
+    def forward(ctx, w, group):
+        ctx.group = group
+        return w.view_as(w)
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous().clone()
+        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=ctx.group)
+        return d, None
+
+
+# ---------------------------------------------------------------------------------------
+# the sharded layer
+# ---------------------------------------------------------------------------------------
+class ShardedTMGCNLayer:
+    """Y = act((Â ⋆ (M ×₁ X)) · W) with the frontal slices sharded over `group`.
+
+    A_local : BatchedCSR of this rank's slices [k0,k1) (T_local x N x N)
+    M       : full [T,T] mixing matrix (replicated, tiny)
+    exchange: "a2a" (X node-sharded [T, N/G, F]) or "allgather" (X slice-sharded [T/G, N, F])
+    Output is slice-sharded [T/G, N, F1] in both modes.  World size 1 needs no process group.
+    Even splits are required (T % G == 0, and N % G == 0 for "a2a").
+    """
+
+    def __init__(self, A_local: BatchedCSR, M, T: int, group=None, exchange: str = "a2a",
+                 apply_m: bool = True):
+        self.rank, self.G = _world(group)
+        self.group = group
+        if exchange not in ("a2a", "allgather"):
+            raise RuntimeError(f"unknown exchange {exchange!r}")
+        if T % self.G:
+            raise RuntimeError(f"T={T} is not divisible by the world size {self.G}")
+        self.exchange = exchange
+        self.T, self.Tl, self.N = T, T // self.G, A_local.N
+        if A_local.T != self.Tl:
+            raise RuntimeError(f"rank {self.rank}: adjacency shard has {A_local.T} slices, expected {self.Tl}")
+        if exchange == "a2a" and self.N % self.G:
+            raise RuntimeError(f"N={self.N} is not divisible by the world size {self.G}")
+        self.k0 = self.rank * self.Tl
+        self.A = A_local
+        self.apply_m = apply_m
+        self.Mop = ops.MOperator(M, A_local.device) if apply_m else None
+        if apply_m and self.Mop.T != T:
+            raise RuntimeError(f"M is {self.Mop.T}x{self.Mop.T}, expected {T}x{T}")
+
+    def input_shape(self, F: int):
+        if self.G == 1 or self.exchange == "allgather":
+            return (self.Tl, self.N, F)
+        return (self.T, self.N // self.G, F)
+
+    def __call__(self, X: torch.Tensor, W: torch.Tensor, act=None) -> torch.Tensor:
+        if tuple(X.shape[:2]) != self.input_shape(X.shape[2])[:2]:
+            raise RuntimeError(f"rank {self.rank}: input {tuple(X.shape)} does not match the "
+                               f"'{self.exchange}' layout {self.input_shape(X.shape[2])}")
+        if self.G == 1:
+            Xt = ops.m_transform(X, self.Mop) if self.apply_m else X
+        elif self.exchange == "a2a":
+            Nl, F = X.shape[1], X.shape[2]
+            if self.apply_m:
+                # P1 on whole tube fibres, written straight into the send layout [Tl][G][Nl][F]
+                send = ops.m_transform(X, self.Mop, y_group_rows=self.Tl)
+            else:
+                send = X.view(self.G, self.Tl, Nl, F).transpose(0, 1).contiguous()
+            Xt = _NodeToSlice.apply(send.view(self.Tl, self.G, Nl, F), self.Tl, self.N, self.group)
+        else:
+            Xf = _AllGatherSlices.apply(X, self.group)
+            # own output slices only: rows [k0, k0+Tl) of M against all T input slices
+            Xt = ops.m_transform(Xf, self.Mop, row_off=self.k0, col_off=0, T_out=self.Tl) if self.apply_m \
+                else Xf[self.k0:self.k0 + self.Tl].contiguous()
+        AtXt = ops.spmm(self.A, Xt)
+        if W.dim() == 2 and self.G > 1:
+            W = _SharedWeight.apply(W, self.group)      # condensed_W: dW summed over ranks
+        return ops.feature_gemm(AtXt, W, act=act)
+
+    def to_node_sharded(self, Y: torch.Tensor) -> torch.Tensor:
+        """Slice-sharded [T/G, N, F] -> node-sharded [T, N/G, F] (input of a following "a2a" layer)."""
+        if self.G == 1:
+            return Y
+        Nl, F = self.N // self.G, Y.shape[2]
+        recv = _SliceToNode.apply(Y, self.group)          # [Tl][G][Nl][F], block kk = slice kk of every rank
+        return recv.transpose(0, 1).reshape(self.T, Nl, F)

@@ -74,6 +74,32 @@ class MOperator:
         return MOperator(self.M64[k0:k1, k0:k1], self.M.device)
 
 
+class KernelTimer:
+    """Optional per-launch timing with events recorded on the stream the kernels run on
+    (bench.py's roofline leg).  Off by default: `kernels.timer = None`."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def launch(self, tag, dev, fn):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        st = torch.cuda.current_stream(dev)
+        s.record(st)
+        rc = fn()
+        e.record(st)
+        self.spans.setdefault(tag, []).append((s, e))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, spans in self.spans.items():
+            ms = [a.elapsed_time(b) for a, b in spans]
+            out[tag] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms)}
+        return out
+
+
 class HipKernels:
     """Thin launchers: validate, allocate the output, call the C-ABI on the current stream."""
 
@@ -81,6 +107,10 @@ class HipKernels:
 
     def __init__(self):
         self._dw_ws = {}
+        self.timer: Optional[KernelTimer] = None
+
+    def _run(self, tag, dev, fn):
+        return self.timer.launch(tag, dev, fn) if self.timer is not None else fn()
 
     # P1 ---------------------------------------------------------------------------------
     def mtransform(self, op: MOperator, X: torch.Tensor, transpose=False, row_off=0, col_off=0,
@@ -93,14 +123,14 @@ class HipKernels:
         C_ = X.numel() // max(1, T_in)
         Y = torch.empty((T_out,) + tuple(X.shape[1:]), dtype=torch.float32, device=X.device)
         lo, hi = (op.band_hi, op.band_lo) if transpose else (op.band_lo, op.band_hi)
-        rc = lib.tmgcn_mtransform_f32(_ptr(op.M), op.T, op.T, int(bool(transpose)), row_off, col_off,
-                                      T_out, T_in, lo, hi, _ptr(X), _ptr(Y), C_, x_group_rows, y_group_rows,
-                                      _stream(X))
+        rc = self._run("mtransform_T" if transpose else "mtransform", X.device, lambda: lib.tmgcn_mtransform_f32(
+            _ptr(op.M), op.T, op.T, int(bool(transpose)), row_off, col_off, T_out, T_in, lo, hi, _ptr(X), _ptr(Y),
+            C_, x_group_rows, y_group_rows, _stream(X)))
         _lib.check(rc, "tmgcn_mtransform_f32")
         return Y
 
     # P2 ---------------------------------------------------------------------------------
-    def spmm(self, A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
+    def spmm(self, A: BatchedCSR, X: torch.Tensor, tag="spmm") -> torch.Tensor:
         lib = _lib.load()
         _want(X, "spmm X")
         if X.dim() != 3 or X.shape[0] != A.T or X.shape[1] != A.N:
@@ -109,8 +139,9 @@ class HipKernels:
             raise RuntimeError("spmm: adjacency and X live on different devices")
         F = X.shape[2]
         Y = torch.empty_like(X)
-        rc = lib.tmgcn_spmm_csr_batched_f32_hint(_ptr(A.rowptr), _ptr(A.col), _ptr(A.val), _ptr(X), _ptr(Y),
-                                                 A.n_rows, A.N, F, C.c_float(A.avg_nnz_per_row), _stream(X))
+        rc = self._run(tag, X.device, lambda: lib.tmgcn_spmm_csr_batched_f32_hint(
+            _ptr(A.rowptr), _ptr(A.col), _ptr(A.val), _ptr(X), _ptr(Y), A.n_rows, A.N, F,
+            C.c_float(A.avg_nnz_per_row), _stream(X)))
         _lib.check(rc, "tmgcn_spmm_csr_batched_f32")
         return Y
 
@@ -128,9 +159,9 @@ class HipKernels:
         Y = torch.empty((T, N, wn), dtype=torch.float32, device=A.device)
         act_id = _lib.ACT_IDS[act]
         pre = torch.empty_like(Y) if (want_pre and act_id) else None
-        rc = lib.tmgcn_gemm_f32(_ptr(A), _ptr(W), _ptr(Y), _ptr(pre), T * N, K, wn, int(bool(trans_w)),
-                                N if per_slice else 0, W.shape[-1] * W.shape[-2] if per_slice else 0,
-                                act_id, _stream(A))
+        rc = self._run("gemm_dA" if trans_w else "gemm", A.device, lambda: lib.tmgcn_gemm_f32(
+            _ptr(A), _ptr(W), _ptr(Y), _ptr(pre), T * N, K, wn, int(bool(trans_w)), N if per_slice else 0,
+            W.shape[-1] * W.shape[-2] if per_slice else 0, act_id, _stream(A)))
         _lib.check(rc, "tmgcn_gemm_f32")
         return (Y, pre) if want_pre else Y
 
@@ -149,7 +180,8 @@ class HipKernels:
             ws = torch.empty(max(need, 1), dtype=torch.uint8, device=A.device)
             self._dw_ws[key] = ws
         dW = torch.empty((T, K, Nf) if per_slice else (K, Nf), dtype=torch.float32, device=A.device)
-        rc = lib.tmgcn_gemm_dw_f32(_ptr(A), _ptr(dY), _ptr(dW), R, K, Nf, rpb, _ptr(ws), ws.numel(), _stream(A))
+        rc = self._run("gemm_dW", A.device, lambda: lib.tmgcn_gemm_dw_f32(
+            _ptr(A), _ptr(dY), _ptr(dW), R, K, Nf, rpb, _ptr(ws), ws.numel(), _stream(A)))
         _lib.check(rc, "tmgcn_gemm_dw_f32")
         return dW
 
@@ -201,7 +233,7 @@ class _Spmm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY):
         # sparse.mm backward: dX_k = Â_kᵀ dY_k (Â is a constant: no gradient, as in the reference)
-        return kernels.spmm(ctx.A.transpose(), dY.contiguous()), None
+        return kernels.spmm(ctx.A.transpose(), dY.contiguous(), tag="spmm_T"), None
 
 
 class _FeatureGemm(torch.autograd.Function):
