@@ -90,6 +90,21 @@ int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int32_t* col, c
                                     const float* X, float* Y, int64_t n_rows, int32_t N,
                                     int32_t F, float avg_nnz_per_row, void* stream);
 
+/* ---- P2+P3 fused: Y = act((Â ⋆ X) · Wop) in one launch ------------------------------
+ * Replaces the pair  sparse.mm loop + t.matmul(AtXt, W)  (ehf:206-207 + 222, 303-304 + 349,
+ * 471-472 + 486-489).  With the transposed CSR and trans_w=1 it is the backward pair, using
+ * Âᵀ(dY·Wᵀ) = (Âᵀ·dY)·Wᵀ.  X is [n_rows][K]; W, trans_w, rows_per_batch, w_batch_stride, act,
+ * pre_act as in tmgcn_gemm_f32.  AX (optional, may be NULL) receives the SpMM result
+ * [n_rows][K] itself (needed for dW).  Supported when tmgcn_spmm_gemm_supported(K, Nf) != 0
+ * (K in {16, 32, 64, 128}, Nf <= 128); otherwise call the two kernels separately.
+ */
+int tmgcn_spmm_gemm_supported(int32_t K, int32_t Nf);
+int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                        const float* X, int64_t n_rows, int32_t N, int32_t K,
+                        const float* W, int32_t Nf, int32_t trans_w,
+                        int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
+                        float* Y, float* AX, float* pre_act, void* stream);
+
 /* ---- P3: feature·weight contraction ----------------------------------------------
  * Replaces  t.matmul(AtXt, Wt)  ehf:222, 330, 340, 344, 349, 415, 486-489.
  *

@@ -208,3 +208,53 @@ def test_errors_are_runtime_errors():
         ops.kernels.gemm(torch.randn(2, 10, 4, device=DEV), torch.randn(5, 3, device=DEV))
     with pytest.raises(RuntimeError):
         ops.kernels.spmm(rand_csr(2, 10, 2.0, 1).to(DEV), torch.randn(2, 10, 4, device=DEV).double())
+
+
+# ------------------------------------------------------------------------------------- P2+P3 fused
+@pytest.mark.parametrize("K", [16, 32, 64, 128])
+@pytest.mark.parametrize("Nf", [1, 6, 32, 100, 128])
+@pytest.mark.parametrize("trans_w,per_slice", [(False, False), (True, False), (False, True)])
+def test_spmm_gemm_fused(K, Nf, trans_w, per_slice):
+    T, N = 3, 130  # N not a multiple of the 64-row tile: per-slice tiles are clipped
+    csr = rand_csr(T, N, 9.0, seed=K + Nf)
+    g = torch.Generator().manual_seed(K * 3 + Nf)
+    X = torch.randn(T, N, K, generator=g)
+    wshape = (Nf, K) if trans_w else (K, Nf)
+    W = torch.randn(*((T,) + wshape if per_slice else wshape), generator=g)
+    assert ops.kernels.spmm_gemm_supported(K, Nf)
+    Y, AX, _ = ops.kernels.spmm_gemm(csr.to(DEV), X.to(DEV), W.to(DEV), trans_w=trans_w, want_ax=True)
+    ref_ax = ref_spmm(csr, X)
+    assert_close(AX, ref_ax, REL_TOL, "fused: SpMM intermediate")
+    assert_close(Y, ref_gemm(ref_ax, W, trans_w, per_slice), REL_TOL, f"fused K={K} Nf={Nf}")
+    Y2, _, _ = ops.kernels.spmm_gemm(csr.to(DEV), X.to(DEV), W.to(DEV), trans_w=trans_w)
+    assert torch.equal(Y, Y2), "fused kernel not reproducible"
+
+
+@pytest.mark.parametrize("act", [None, "selu"])
+def test_spmm_gemm_autograd_matches_unfused(act):
+    """Fused op (backward = (ÂᵀdY)Wᵀ) against the two-kernel path (backward = Âᵀ(dY Wᵀ))."""
+    T, N, K, Nf = 4, 200, 32, 64
+    csr = rand_csr(T, N, 8.0, seed=11).to(DEV)
+    g = torch.Generator().manual_seed(12)
+    X0 = torch.randn(T, N, K, generator=g).to(DEV)
+    W0 = (torch.randn(K, Nf, generator=g) * 0.2).to(DEV)
+    dY = torch.randn(T, N, Nf, generator=g).to(DEV)
+    res = []
+    for fuse in (True, False):
+        X = X0.clone().requires_grad_(True)
+        W = W0.clone().requires_grad_(True)
+        Y = ops.spmm_feature_gemm(csr, X, W, act=act, fuse=fuse)
+        Y.backward(dY)
+        res.append((Y.detach(), X.grad, W.grad))
+    for a, b, what in zip(res[0], res[1], ("Y", "dX", "dW")):
+        assert_close(a, b, REL_TOL, f"fused vs unfused {what} act={act}")
+
+
+def test_spmm_gemm_unsupported_width_raises():
+    csr = rand_csr(2, 20, 3.0, seed=1).to(DEV)
+    assert not ops.kernels.spmm_gemm_supported(20, 8)
+    with pytest.raises(RuntimeError):
+        ops.kernels.spmm_gemm(csr, torch.randn(2, 20, 20, device=DEV), torch.randn(20, 8, device=DEV))
+    # the dispatcher falls back to the two-kernel path
+    Y = ops.spmm_feature_gemm(csr, torch.randn(2, 20, 20, device=DEV), torch.randn(20, 8, device=DEV))
+    assert tuple(Y.shape) == (2, 20, 8)

@@ -167,3 +167,28 @@ def test_accepts_prebuilt_batched_csr_and_gpu_inputs():
     b = ehf.EmbeddingGCN(csr, i["X"].cuda().float(), i["edges"].cuda(), i["M"], hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
     assert torch.equal(a(), b())
     assert torch.equal(a(i["At"], i["X"], i["edges"]), a())  # recompute branch == cached branch
+
+
+@pytest.mark.parametrize("branch", ["default", "twice"])
+def test_wide_features_use_fused_kernel_and_match_oracle(branch):
+    """F = 16 -> 32 -> 16: layer 2 runs the fused P2+P3 kernel; compare with the oracle executed
+    the reference's way (list of COO fp64, sparse.mm per slice) incl. all parameter gradients."""
+    from oracle import tmgcn_oracle as orc
+    from tmgcn_amd import synth
+    g = synth.dynamic_graph(T=8, N=150, edges_per_slice=300, seed=5, no_diag=4, F0=16)
+    At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
+    edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels)
+    torch.manual_seed(3)
+    m = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=[32, 16, 2], condensed_W=True, use_Minv=False,
+                          apply_M_twice=branch == "twice", nonlin2="leaky")
+    with torch.no_grad():  # N(0,1) weights at these widths blow the activations up; scale down
+        m.W1.mul_(0.2); m.W2.mul_(0.2)
+    out, loss, grads = _loss_grads(m, labels)
+    p = {n: q.detach().cpu().clone().requires_grad_(True) for n, q in m.named_parameters()}
+    src, dst = orc.flat_edge_index(edges, g.N)
+    ref = orc.gcn2_forward(orc.compute_AtXt(M, At, X), At, M, p["W1"], p["W2"], p["U"], src, dst,
+                           nonlin="leaky", apply_M_twice=branch == "twice")
+    torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1]))(ref, labels).backward()
+    assert_close(out, ref.detach(), TOL, "logits")
+    for n in p:
+        assert_close(grads[n], p[n].grad, TOL, "d" + n)

@@ -28,6 +28,30 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// Grid size of a persistent kernel: CUs x resident blocks per CU (occupancy API, capped at 4:
+// MI355X_MICROARCH.md warns the API can over-report by one for SGPR-heavy kernels; a persistent
+// grid that is not fully resident runs its tail blocks serially).  Cached per kernel.
+template <typename K>
+inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0) {
+  static int cached = 0;  // one instance per kernel type/instantiation site
+  static const void* cached_for = nullptr;
+  const void* key = reinterpret_cast<const void*>(kernel);
+  if (cached && cached_for == key) return cached;
+  int dev = 0, cus = 256, per_cu = 1;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dyn_smem) != hipSuccess ||
+      per_cu < 1)
+    per_cu = 1;
+  if (per_cu > 4) per_cu = 4;
+  (void)hipGetLastError();
+  cached = cus * per_cu;
+  cached_for = key;
+  return cached;
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
   // torch.nn.ReLU / LeakyReLU(0.01) / SELU constants (ehf:284-289)
   switch (act) {

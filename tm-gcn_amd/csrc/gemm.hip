@@ -368,7 +368,8 @@ extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* p
   a.tiles_per_batch = (br + BM - 1) / BM;
   a.n_tiles = nb * a.tiles_per_batch;
   const unsigned gy = (unsigned)((Nf + 127) / 128);
-  int64_t gx = a.n_tiles < 1024 ? a.n_tiles : 1024;
+  int64_t gx = persistent_grid(gemm_mfma_kernel, 256);
+  if (gx > a.n_tiles) gx = a.n_tiles;
   hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
   return check_launch("gemm_mfma");
 }
@@ -393,7 +394,7 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
   int chunks;
   dw_plan(R, rows_per_batch, &nb, &chunks, &rpc);
   if (R == 0) {
-    hipMemsetAsync(dW, 0, (size_t)K * Nf * sizeof(float), st);
+    (void)hipMemsetAsync(dW, 0, (size_t)K * Nf * sizeof(float), st);
     return check_launch("gemm_dw memset");
   }
   TMGCN_REQUIRE(A && dY, "gemm_dw: null pointer");

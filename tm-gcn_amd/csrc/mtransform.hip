@@ -61,6 +61,12 @@ struct Cols<4> {
     acc.z = fmaf(m, x.z, acc.z);
     acc.w = fmaf(m, x.w, acc.w);
   }
+  static __device__ __forceinline__ void mask(T& v, unsigned bits) {
+    v.x = __uint_as_float(__float_as_uint(v.x) & bits);
+    v.y = __uint_as_float(__float_as_uint(v.y) & bits);
+    v.z = __uint_as_float(__float_as_uint(v.z) & bits);
+    v.w = __uint_as_float(__float_as_uint(v.w) & bits);
+  }
 };
 template <>
 struct Cols<1> {
@@ -69,56 +75,110 @@ struct Cols<1> {
   static __device__ __forceinline__ T load(const float* p) { return *p; }
   static __device__ __forceinline__ void store(float* p, const T& v) { *p = v; }
   static __device__ __forceinline__ void fma(T& acc, float m, const T& x) { acc = fmaf(m, x, acc); }
+  static __device__ __forceinline__ void mask(T& v, unsigned bits) {
+    v = __uint_as_float(__float_as_uint(v) & bits);
+  }
 };
 
-// Sliding-window band kernel.  Window slot of input row j is (j + JB) mod W with JB chosen
-// so that slots are compile-time constants inside the unrolled body.
-template <int W, int VEC>
-__global__ __launch_bounds__(256) void mtransform_band_kernel(MtArgs a) {
+// Sliding-window band kernel.  Each lane owns VEC columns and keeps a ring of W = WIDTH + PF
+// input rows in registers: WIDTH rows feed the current output row while the next PF rows are
+// already in flight, so X is read once, Y written once, and every lane keeps PF 16-B loads
+// outstanding.  Rows are numbered locally, u = 0.. (u = 0 is the oldest row the chunk's first
+// output needs); row u lives in ring slot u mod W.  Three phases keep the steady state free of
+// control flow (conditional loads would force s_waitcnt vmcnt(0) and serialise the stream):
+//   fill    rows 0..WIDTH-2 and the first PF look-ahead rows: loads only, fully unrolled
+//   steady  groups of W output rows, fully unrolled, unconditional loads (row index clamped
+//           into the tensor, out-of-range rows selected to zero), one store per row
+//   tail    the last < W rows, same body under wave-uniform branches
+template <int WIDTH, int PF, int VEC, bool PERM>
+struct BandBody {
+  static constexpr int W = WIDTH + PF;
   using CT = Cols<VEC>;
   using V = typename CT::T;
-  const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
-  if (c >= a.C) return;
+
+  // input row of local index u
+  static __device__ __forceinline__ V fetch(const MtArgs& a, const float* __restrict__ X, int q0,
+                                            int u, int u_max, int64_t c) {
+    const int uc = u < u_max ? u : u_max;  // never run past the rows this chunk needs
+    const int q = q0 + uc;
+    const int qc = q < 0 ? 0 : (q >= a.T_in ? a.T_in - 1 : q);
+    const int64_t pos = PERM ? row_pos(qc, a.T_in, a.x_tl) : (int64_t)qc;
+    V v = CT::load(X + pos * a.C + c);
+    CT::mask(v, q == qc ? 0xFFFFFFFFu : 0u);  // rows outside the tensor are zero (bit mask: no branch)
+    return v;
+  }
+
+  // output row o of the chunk, completed by the row in ring slot i; taps from the LDS table
+  static __device__ __forceinline__ void emit(const MtArgs& a, float* __restrict__ Y, const V (&win)[W],
+                                              const float* coef, int i, int o, int k, int64_t c, bool live) {
+    V acc = CT::zero();
+    float m[WIDTH];
+#pragma unroll
+    for (int d = 0; d < WIDTH; ++d) m[d] = coef[o * WIDTH + d];  // wave-uniform: LDS broadcast
+#pragma unroll
+    for (int d = 0; d < WIDTH; ++d) CT::fma(acc, m[d], win[(i - d + 2 * W) % W]);
+    const int64_t pos = PERM ? row_pos(k, a.T_out, a.y_tl) : (int64_t)k;
+    if (live) CT::store(Y + pos * a.C + c, acc);
+  }
+};
+
+constexpr int kBandMaxChunkRows = 512;  // LDS tap table: 512 x 20 x 4 B = 40 KB
+
+template <int WIDTH, int PF, int VEC, bool PERM>
+__global__ __launch_bounds__(256) void mtransform_band_kernel(MtArgs a) {
+  using B = BandBody<WIDTH, PF, VEC, PERM>;
+  using CT = Cols<VEC>;
+  using V = typename CT::T;
+  constexpr int W = B::W;
+  extern __shared__ float coef[];  // [n_out][WIDTH] taps of this chunk, zero outside the band
   const int k_begin = blockIdx.y * a.rows_per_chunk;
   int k_end = k_begin + a.rows_per_chunk;
   if (k_end > a.T_out) k_end = a.T_out;
-  if (k_begin >= k_end) return;
+  const int n_out = k_end - k_begin;
+  if (n_out <= 0) return;  // whole block
+  int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  const bool live = c < a.C;
+  if (!live) c = 0;  // idle lanes of the last block shadow column 0 and never store
+  const float* __restrict__ X = a.X;
+  float* __restrict__ Y = a.Y;
 
-  // output row k reads input rows j in [k + d_lo, k + d_hi]
+  // output row k reads input rows [k + d_lo, k + d_hi]; tap d of row k is input row k + d_hi - d
   const int d_lo = (a.row_off - a.col_off) - a.band_lo;
-  const int d_hi = (a.row_off - a.col_off) + a.band_hi;  // d_hi - d_lo + 1 <= W
+  const int d_hi = (a.row_off - a.col_off) + a.band_hi;
+  for (int t = threadIdx.x; t < n_out * WIDTH; t += blockDim.x) {
+    const int o = t / WIDTH, d = t % WIDTH;
+    const int k = k_begin + o, j = k + d_hi - d;
+    coef[t] = (j >= k + d_lo && j >= 0 && j < a.T_in) ? mop(a, k, j) : 0.f;
+  }
+  __syncthreads();
+
+  const int q0 = k_begin + d_hi - (WIDTH - 1);  // input row of local index 0
+  const int u_max = n_out + WIDTH - 2;          // newest local row any output needs
 
   V win[W];
+  // ---- fill: local rows 0 .. WIDTH-2+PF go to slots 0 .. W-2
 #pragma unroll
-  for (int i = 0; i < W; ++i) win[i] = CT::zero();
+  for (int u = 0; u < WIDTH - 1 + PF; ++u) win[u] = B::fetch(a, X, q0, u, u_max, c);
 
-  // q walks the input rows, starting at the oldest row the first output row needs.
-  // q is kept congruent to the unrolled index i modulo W:  q = qb + i.
-  const int q_first = k_begin + d_lo;
-  // floor to a multiple of W (q_first may be negative)
-  int qb = q_first >= 0 ? (q_first / W) * W : -(((-q_first) + W - 1) / W) * W;
-  const int q_last = k_end - 1 + d_hi;
-
-  for (; qb <= q_last; qb += W) {
+  // ---- steady: output o is completed by local row u = WIDTH-1+o in slot (WIDTH-1+o) % W.
+  //      Row u + PF is fetched first, into slot (u + PF) % W = (u - WIDTH) % W: the row that
+  //      lived there is older than anything output o (or any later one) reads.
+  int o = 0;
+  for (; o + W <= n_out; o += W) {
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-      const int q = qb + i;  // slot i  <->  input row q  (q mod W == i since qb % W == 0)
-      if (q >= q_first && q <= q_last) {
-        win[i] = (q >= 0 && q < a.T_in) ? CT::load(a.X + row_pos(q, a.T_in, a.x_tl) * a.C + c) : CT::zero();
-        const int k = q - d_hi;  // output row completed by this input row
-        if (k >= k_begin) {
-          V acc = CT::zero();
+      const int u = WIDTH - 1 + o + i;
+      win[(WIDTH - 1 + i + PF) % W] = B::fetch(a, X, q0, u + PF, u_max, c);
+      B::emit(a, Y, win, coef, (WIDTH - 1 + i) % W, o + i, k_begin + o + i, c, live);
+    }
+  }
+  // ---- tail: fewer than W outputs left (wave-uniform branches)
 #pragma unroll
-          for (int d = 0; d < W; ++d) {
-            // input row j = q - d lives in slot (i - d) mod W
-            const int j = q - d;
-            if (j >= k + d_lo && j >= 0 && j < a.T_in) {
-              CT::fma(acc, mop(a, k, j), win[(i - d + W) % W]);
-            }
-          }
-          CT::store(a.Y + row_pos(k, a.T_out, a.y_tl) * a.C + c, acc);
-        }
-      }
+  for (int i = 0; i < W - 1; ++i) {
+    if (o + i < n_out) {
+      const int u = WIDTH - 1 + o + i;
+      if (u + PF <= u_max) win[(WIDTH - 1 + i + PF) % W] = B::fetch(a, X, q0, u + PF, u_max, c);
+      B::emit(a, Y, win, coef, (WIDTH - 1 + i) % W, o + i, k_begin + o + i, c, live);
     }
   }
 }
@@ -157,9 +217,14 @@ __global__ __launch_bounds__(256) void mtransform_dense_kernel(MtArgs a) {
   }
 }
 
-template <int W, int VEC>
+template <int WIDTH, int VEC>
 static void launch_band(const MtArgs& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((mtransform_band_kernel<W, VEC>), grid, dim3(256), 0, st, a);
+  constexpr int PF = 4;  // rows in flight per lane
+  const size_t smem = (size_t)a.rows_per_chunk * WIDTH * sizeof(float);
+  if (a.x_tl || a.y_tl)
+    hipLaunchKernelGGL((mtransform_band_kernel<WIDTH, PF, VEC, true>), grid, dim3(256), smem, st, a);
+  else
+    hipLaunchKernelGGL((mtransform_band_kernel<WIDTH, PF, VEC, false>), grid, dim3(256), smem, st, a);
 }
 
 template <int VEC>
@@ -176,6 +241,8 @@ static int dispatch(MtArgs a, hipStream_t st) {
       if (chunks > max_chunks) chunks = max_chunks;
       if (chunks < 1) chunks = 1;
     }
+    const int min_chunks = (a.T_out + kBandMaxChunkRows - 1) / kBandMaxChunkRows;
+    if (chunks < min_chunks) chunks = min_chunks;
     a.rows_per_chunk = (a.T_out + chunks - 1) / chunks;
     chunks = (a.T_out + a.rows_per_chunk - 1) / a.rows_per_chunk;
     dim3 grid(col_blocks, chunks);

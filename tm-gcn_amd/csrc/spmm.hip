@@ -15,6 +15,7 @@
 //   spmm_generic any other F           lanes across F, scalar loads
 // No atomics anywhere: every row is summed in a fixed order.
 #include "common.h"
+#include "spmm_row.h"
 
 namespace tmgcn {
 
@@ -30,62 +31,16 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float4* __restrict__ X, float4* __restrict__ Y,
     int64_t n_rows, int32_t N, int32_t F4, int32_t rows_per_block) {
-  constexpr int S = kWave / LPR;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int sub = lane / LPR;  // which non-zero stream
-  const int fl = lane % LPR;   // which float4 of the feature row
-  const bool f_ok = fl < F4;
-
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
   int64_t r_end = r_begin + rows_per_block;
   if (r_end > n_rows) r_end = n_rows;
-
   for (int64_t r = r_begin + wave; r < r_end; r += 4) {
-    const int64_t beg = rowptr[r];
-    const int64_t end = rowptr[r + 1];
     const int64_t slice = r / N;
-    const float4* __restrict__ Xs = X + slice * (int64_t)N * F4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    for (int64_t base = beg; base < end; base += kWave) {
-      const int n = (int)((end - base) < kWave ? (end - base) : kWave);
-      int c = 0;
-      float v = 0.f;
-      if (lane < n) {
-        c = col[base + lane];
-        v = val[base + lane];
-      }
-      for (int p = 0; p < n; p += S * U) {
-        float4 x[U];
-        float vv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int idx = p + u * S + sub;
-          const int cc = __shfl(c, idx & 63);
-          vv[u] = __shfl(v, idx & 63);
-          x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (idx < n && f_ok) x[u] = Xs[(int64_t)cc * F4 + fl];
-          if (idx >= n) vv[u] = 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          acc.x = fmaf(vv[u], x[u].x, acc.x);
-          acc.y = fmaf(vv[u], x[u].y, acc.y);
-          acc.z = fmaf(vv[u], x[u].z, acc.z);
-          acc.w = fmaf(vv[u], x[u].w, acc.w);
-        }
-      }
-    }
-    // combine the S streams (fixed butterfly order)
-#pragma unroll
-    for (int o = LPR; o < kWave; o <<= 1) {
-      acc.x += __shfl_xor(acc.x, o);
-      acc.y += __shfl_xor(acc.y, o);
-      acc.z += __shfl_xor(acc.z, o);
-      acc.w += __shfl_xor(acc.w, o);
-    }
-    if (sub == 0 && f_ok) Y[r * F4 + fl] = acc;
+    const float4 acc = gather_row<LPR, U>(col, val, X + slice * (int64_t)N * F4, rowptr[r],
+                                          rowptr[r + 1], F4, lane);
+    if (lane < LPR && lane < F4) Y[r * F4 + lane] = acc;
   }
 }
 

@@ -1,0 +1,200 @@
+// P2+P3 fused — Y = act((Â ⋆ X) · Wop), one launch, the SpMM result never leaves the CU
+// on its way to the GEMM   (gfx950 / CDNA4)
+//
+// Replaces the pair  AtXt[k] = t.sparse.mm(At[k], Xt[k]) ; t.matmul(AtXt, W)
+// (embedding_help_functions.py:206-207 + 222, 303-304 + 349, 471-472 + 486-489) and, fed the
+// transposed CSR and Wᵀ, the backward pair: by associativity  Âᵀ(dY·Wᵀ) = (Âᵀ·dY)·Wᵀ,
+// so the backward is the same kernel run on dY.
+//
+// Why fuse: the SpMM is an HBM-bound gather (MFMA idle), the f32 GEMM at F=128 is MFMA-bound
+// (HBM idle); run back to back they cost the sum, fused the GEMM hides under the gather and
+// the [T,N,F] intermediate is not re-read (it is still written once when the caller needs it
+// for dW).  Structure per 64-row tile of a persistent 256-thread block:
+//   phase 1  each wave gathers 16 rows (spmm_row.h), row sums go to an LDS tile [64][K+4]
+//   phase 2  exact-f32 MFMA (v_mfma_f32_32x32x2_f32): wave w owns output columns
+//            [32w, 32w+32); its B fragments (a 32-column strip of W) stay in registers for the
+//            whole launch; A fragments come from the LDS tile with conflict-free ds_read_b128.
+#include "common.h"
+#include "spmm_row.h"
+
+namespace tmgcn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FBM = 64;         // rows per tile
+constexpr int FKC = 128;        // max K (feature width of X)
+constexpr int FLDA = FKC + 4;   // LDS row stride in floats
+
+struct FusedArgs {
+  const int64_t* rowptr;
+  const int32_t* col;
+  const float* val;
+  const float4* X;
+  int64_t n_rows;
+  int32_t N;
+  int32_t K;        // feature width of X (multiple of 4, <= 128)
+  const float* W;
+  int32_t Nf;       // output width (<= 128)
+  int32_t trans_w;
+  int64_t rows_per_batch;  // 0: one shared W; N: one W per slice
+  int64_t w_batch_stride;
+  float* Y;
+  float* AX;        // optional: the SpMM result itself ([n_rows][K]), for dW
+  float* pre;       // optional: pre-activation
+  int32_t act;
+  int64_t tiles_per_batch;
+  int64_t n_tiles;
+};
+
+template <int LPR, int U, int NJ>  // NJ = K / 8 (K is a multiple of 8 here)
+__global__ __launch_bounds__(256, 3) void spmm_gemm_kernel(FusedArgs a) {
+  __shared__ float As[FBM * FLDA];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int F4 = a.K / 4;
+  constexpr int nj = NJ;
+  const int n0 = wave * 32;
+  const int64_t batch_rows = a.rows_per_batch ? a.rows_per_batch : a.n_rows;
+
+  float wreg[NJ][4];
+  int64_t cur_batch = -1;
+
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int64_t batch = tile / a.tiles_per_batch;
+    const int64_t row0 = batch * batch_rows + (tile % a.tiles_per_batch) * FBM;
+    int64_t row_end = (batch + 1) * batch_rows;
+    if (row_end > a.n_rows) row_end = a.n_rows;
+
+    if (batch != cur_batch) {
+      const float* Wb = a.W + (a.rows_per_batch ? batch * a.w_batch_stride : 0);
+      const int n = n0 + li;
+      const int nc = n < a.Nf ? n : 0;  // clamp: out-of-range columns load column 0, zeroed below
+      const float* Wl = a.trans_w ? Wb + (int64_t)nc * a.K + 4 * lh : Wb + (int64_t)(4 * lh) * a.Nf + nc;
+      const int64_t sk = a.trans_w ? 1 : a.Nf;  // stride of k
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float w = Wl[(int64_t)(8 * j + s) * sk];
+          wreg[j][s] = n < a.Nf ? w : 0.f;
+        }
+      cur_batch = batch;
+    }
+
+    // ---- phase 1: gather 16 rows per wave into the LDS tile
+    for (int rr = wave; rr < FBM; rr += 4) {
+      const int64_t r = row0 + rr;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < row_end) {
+        const int64_t slice = r / a.N;
+        acc = gather_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, a.rowptr[r],
+                                 a.rowptr[r + 1], F4, lane);
+      }
+      if (lane < LPR && lane < F4) {
+        *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
+        if (a.AX && r < row_end) reinterpret_cast<float4*>(a.AX)[r * F4 + lane] = acc;
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 2: tile · Wop on the matrix cores
+    if (n0 < a.Nf) {
+      f32x16 acc[FBM / 32];
+#pragma unroll
+      for (int mb = 0; mb < FBM / 32; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
+      // A fragments are fetched one k-group ahead of the MFMAs that use them; the
+      // sched_barrier keeps hipcc from hoisting all 32 ds_read_b128 (128 VGPRs) to the top.
+      const float* Arow = &As[li * FLDA + 4 * lh];
+      float4 av_next = *reinterpret_cast<const float4*>(Arow);
+#pragma unroll
+      for (int mb = 0; mb < FBM / 32; ++mb) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          {
+            const float4 av = av_next;
+            const bool last = (j + 1 >= nj);
+            if (!(last && mb + 1 == FBM / 32)) {
+              const int mbn = last ? mb + 1 : mb, jn = last ? 0 : j + 1;
+              av_next = *reinterpret_cast<const float4*>(Arow + mbn * 32 * FLDA + 8 * jn);
+            }
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wreg[j][0], acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wreg[j][1], acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wreg[j][2], acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wreg[j][3], acc[mb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      const int n = n0 + li;
+      if (n < a.Nf) {
+#pragma unroll
+        for (int mb = 0; mb < FBM / 32; ++mb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int64_t r = row0 + mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            if (r < row_end) {
+              const float s = acc[mb][i];
+              if (a.pre) a.pre[r * a.Nf + n] = s;
+              a.Y[r * a.Nf + n] = act_apply(s, a.act);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // tile consumed before the next phase 1 overwrites it
+  }
+}
+
+}  // namespace tmgcn
+
+using namespace tmgcn;
+
+extern "C" int tmgcn_spmm_gemm_supported(int32_t K, int32_t Nf) {
+  return ((K == 16 || K == 32 || K == 64 || K == 128) && Nf >= 1 && Nf <= 128) ? 1 : 0;
+}
+
+extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                                    const float* X, int64_t n_rows, int32_t N, int32_t K,
+                                    const float* W, int32_t Nf, int32_t trans_w,
+                                    int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
+                                    float* Y, float* AX, float* pre_act, void* stream) {
+  TMGCN_REQUIRE(n_rows >= 0 && N > 0, "spmm_gemm: bad shape n_rows=%lld N=%d", (long long)n_rows, N);
+  TMGCN_REQUIRE(tmgcn_spmm_gemm_supported(K, Nf),
+                "spmm_gemm: unsupported widths K=%d Nf=%d (need K in {16,32,64,128}, Nf <= 128); "
+                "use tmgcn_spmm_csr_batched_f32 + tmgcn_gemm_f32", K, Nf);
+  TMGCN_REQUIRE(act >= TMGCN_ACT_NONE && act <= TMGCN_ACT_SELU, "spmm_gemm: unknown activation %d", act);
+  TMGCN_REQUIRE(rows_per_batch >= 0, "spmm_gemm: negative rows_per_batch");
+  if (n_rows == 0) return TMGCN_OK;
+  TMGCN_REQUIRE(rowptr && X && W && Y, "spmm_gemm: null pointer");
+  TMGCN_REQUIRE(n_rows % N == 0, "spmm_gemm: n_rows=%lld is not a multiple of N=%d", (long long)n_rows, N);
+  TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 && (!AX || reinterpret_cast<uintptr_t>(AX) % 16 == 0),
+                "spmm_gemm: X / AX must be 16-byte aligned");
+  FusedArgs a{rowptr, col, val, reinterpret_cast<const float4*>(X), n_rows, N, K, W, Nf, trans_w,
+              rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0};
+  const int64_t br = rows_per_batch ? rows_per_batch : n_rows;
+  const int64_t nb = (n_rows + br - 1) / br;
+  a.tiles_per_batch = (br + FBM - 1) / FBM;
+  a.n_tiles = nb * a.tiles_per_batch;
+  // persistent blocks: up to 4 per CU (LDS 33.8 KB each); tiles are dealt round-robin so the
+  // blocks resident at any moment work on neighbouring rows of the same slice
+  hipStream_t st = (hipStream_t)stream;
+#define TMGCN_FUSED_CASE(KK, L, UU)                                                              \
+  case KK: {                                                                                     \
+    int64_t gx = persistent_grid(spmm_gemm_kernel<L, UU, KK / 8>, 256);                          \
+    if (gx > a.n_tiles) gx = a.n_tiles;                                                          \
+    hipLaunchKernelGGL((spmm_gemm_kernel<L, UU, KK / 8>), dim3((unsigned)gx), dim3(256), 0, st, a); \
+    break;                                                                                       \
+  }
+  switch (K) {
+    TMGCN_FUSED_CASE(16, 4, 2)
+    TMGCN_FUSED_CASE(32, 8, 2)
+    TMGCN_FUSED_CASE(64, 16, 4)
+    TMGCN_FUSED_CASE(128, 32, 4)
+  }
+#undef TMGCN_FUSED_CASE
+  return check_launch("spmm_gemm");
+}

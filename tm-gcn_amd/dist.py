@@ -142,7 +142,7 @@ class ShardedTMGCNLayer:
     """
 
     def __init__(self, A_local: BatchedCSR, M, T: int, group=None, exchange: str = "a2a",
-                 apply_m: bool = True):
+                 apply_m: bool = True, fuse: Optional[bool] = None):
         self.rank, self.G = _world(group)
         self.group = group
         if exchange not in ("a2a", "allgather"):
@@ -158,6 +158,7 @@ class ShardedTMGCNLayer:
         self.k0 = self.rank * self.Tl
         self.A = A_local
         self.apply_m = apply_m
+        self.fuse = fuse  # None: fused P2+P3 kernel whenever it supports the widths
         self.Mop = ops.MOperator(M, A_local.device) if apply_m else None
         if apply_m and self.Mop.T != T:
             raise RuntimeError(f"M is {self.Mop.T}x{self.Mop.T}, expected {T}x{T}")
@@ -186,10 +187,9 @@ class ShardedTMGCNLayer:
             # own output slices only: rows [k0, k0+Tl) of M against all T input slices
             Xt = ops.m_transform(Xf, self.Mop, row_off=self.k0, col_off=0, T_out=self.Tl) if self.apply_m \
                 else Xf[self.k0:self.k0 + self.Tl].contiguous()
-        AtXt = ops.spmm(self.A, Xt)
         if W.dim() == 2 and self.G > 1:
             W = _SharedWeight.apply(W, self.group)      # condensed_W: dW summed over ranks
-        return ops.feature_gemm(AtXt, W, act=act)
+        return ops.spmm_feature_gemm(self.A, Xt, W, act=act, fuse=self.fuse)
 
     def to_node_sharded(self, Y: torch.Tensor) -> torch.Tensor:
         """Slice-sharded [T/G, N, F] -> node-sharded [T, N/G, F] (input of a following "a2a" layer)."""

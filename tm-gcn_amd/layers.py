@@ -165,13 +165,13 @@ class EmbeddingGCN2(nn.Module):
             Y = ops.feature_gemm(AtXt, self.W1, act=self.nonlin2)
         # second layer — always the training adjacency self.At (ehf:339, 343, 348)
         if self.use_Minv:
-            Z = ops.m_transform(ops.feature_gemm(self.compute_AtXt(self.At, Y), self.W2), self.Minv)
+            Z = ops.m_transform(ops.spmm_feature_gemm(self.At, ops.m_transform(Y, self.Mop), self.W2), self.Minv)
         elif self.apply_M_twice:
-            Z = ops.feature_gemm(self.compute_AtXt(self.At, Y), self.W2)
+            Z = ops.spmm_feature_gemm(self.At, ops.m_transform(Y, self.Mop), self.W2)
             if self.apply_M_three_times:
                 Z = ops.m_transform(Z, self.Mop)                                   # ehf:346
         else:
-            Z = ops.feature_gemm(self.compute_AX(self.At, Y), self.W2)             # ehf:348-349
+            Z = ops.spmm_feature_gemm(self.At, Y, self.W2)                         # ehf:348-349
         return _edge_head(Z, eidx, self.U)
 
 
@@ -211,7 +211,7 @@ class EmbeddingKWGCN(nn.Module):
             AX, eidx = self.AX, self._edges
         if self.no_layers == 2:
             Y = ops.feature_gemm(AX, self.W1, act=self.nonlin2)                    # ehf:486
-            Z = ops.feature_gemm(self.compute_AX(self.A, Y), self.W2)              # ehf:487
+            Z = ops.spmm_feature_gemm(self.A, Y, self.W2)                          # ehf:487
         else:
             Z = ops.feature_gemm(AX, self.W1)                                      # ehf:489
         return _edge_head(Z, eidx, self.U)

@@ -145,6 +145,34 @@ class HipKernels:
         _lib.check(rc, "tmgcn_spmm_csr_batched_f32")
         return Y
 
+    # P2+P3 fused ----------------------------------------------------------------------
+    def spmm_gemm_supported(self, K: int, Nf: int) -> bool:
+        return bool(_lib.load().tmgcn_spmm_gemm_supported(K, Nf))
+
+    def spmm_gemm(self, A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, trans_w=False, act=None,
+                  want_ax=False, want_pre=False, tag="spmm_gemm"):
+        """act((Â ⋆ X) · Wop) in one launch.  Returns (Y, AX or None, pre or None)."""
+        lib = _lib.load()
+        _want(X, "spmm_gemm X")
+        _want(W, "spmm_gemm W")
+        if X.dim() != 3 or X.shape[0] != A.T or X.shape[1] != A.N:
+            raise RuntimeError(f"spmm_gemm: X {tuple(X.shape)} does not match adjacency T={A.T} N={A.N}")
+        T, N, K = X.shape
+        per_slice = W.dim() == 3
+        wk, wn = (W.shape[-1], W.shape[-2]) if trans_w else (W.shape[-2], W.shape[-1])
+        if wk != K or (per_slice and W.shape[0] != T):
+            raise RuntimeError(f"spmm_gemm: size mismatch X {tuple(X.shape)} W {tuple(W.shape)} trans_w={trans_w}")
+        act_id = _lib.ACT_IDS[act]
+        Y = torch.empty((T, N, wn), dtype=torch.float32, device=X.device)
+        AX = torch.empty_like(X) if want_ax else None
+        pre = torch.empty_like(Y) if (want_pre and act_id) else None
+        rc = self._run(tag, X.device, lambda: lib.tmgcn_spmm_gemm_f32(
+            _ptr(A.rowptr), _ptr(A.col), _ptr(A.val), _ptr(X), A.n_rows, A.N, K, _ptr(W), wn,
+            int(bool(trans_w)), N if per_slice else 0, W.shape[-1] * W.shape[-2] if per_slice else 0, act_id,
+            _ptr(Y), _ptr(AX), _ptr(pre), _stream(X)))
+        _lib.check(rc, "tmgcn_spmm_gemm_f32")
+        return Y, AX, pre
+
     # P3 ---------------------------------------------------------------------------------
     def gemm(self, A: torch.Tensor, W: torch.Tensor, trans_w=False, act=None, want_pre=False):
         """A [T,N,K] · W ([K,Nf] shared or [T,K,Nf] per slice; transposed if trans_w)."""
@@ -261,6 +289,33 @@ class _FeatureGemm(torch.autograd.Function):
         return dA, dW, None
 
 
+class _SpmmGemm(torch.autograd.Function):
+    """Fused P2+P3.  Backward uses Âᵀ(dY·Wᵀ) = (Âᵀ·dY)·Wᵀ: the same fused kernel on dY."""
+
+    @staticmethod
+    def forward(ctx, X, W, A, act):
+        ctx.A = A
+        ctx.act = act if _lib.ACT_IDS[act] else None
+        need_w = ctx.needs_input_grad[1]
+        Y, AX, pre = kernels.spmm_gemm(A, X, W, act=act, want_ax=need_w, want_pre=True)
+        ctx.save_for_backward(W, AX if AX is not None else torch.empty(0, device=X.device),
+                              pre if pre is not None else torch.empty(0, device=X.device))
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        W, AX, pre = ctx.saved_tensors
+        dY = dY.contiguous()
+        if ctx.act is not None:
+            dY = kernels.act_bwd(pre, dY, ctx.act)
+        dX = dW = None
+        if ctx.needs_input_grad[0]:
+            dX, _, _ = kernels.spmm_gemm(ctx.A.transpose(), dY, W, trans_w=True, tag="spmm_gemm_T")
+        if ctx.needs_input_grad[1]:
+            dW = kernels.gemm_dw(AX, dY, per_slice=W.dim() == 3)
+        return dX, dW, None, None
+
+
 class _Activation(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act):
@@ -289,6 +344,20 @@ def spmm(A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
 def feature_gemm(A: torch.Tensor, W: torch.Tensor, act=None) -> torch.Tensor:
     """P3 (+ fused P5): act(A · W), W shared ([K,Nf]) or per slice ([T,K,Nf])."""
     return _FeatureGemm.apply(A, W, act)
+
+
+def spmm_feature_gemm(A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, act=None, fuse: Optional[bool] = None):
+    """P2 then P3 (+P5): act((Â ⋆ X) · W).  One fused launch when the kernel supports the
+    widths (K in {16,32,64,128}, Nf <= 128), else the two kernels back to back."""
+    K, Nf = X.shape[-1], W.shape[-1]
+    can = hasattr(kernels, "spmm_gemm_supported") and kernels.spmm_gemm_supported(K, Nf)
+    if fuse is None:
+        fuse = can
+    if fuse and not can:
+        raise RuntimeError(f"fused SpMM+GEMM does not support K={K}, Nf={Nf}")
+    if fuse:
+        return _SpmmGemm.apply(X, W, A, act)
+    return feature_gemm(spmm(A, X), W, act=act)
 
 
 def activation(x: torch.Tensor, act) -> torch.Tensor:
