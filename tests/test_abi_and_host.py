@@ -1,0 +1,129 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tmgcn.h declares (no compute
+calls without a GPU), the ctypes table mirrors the header, and the host-side logic (batched CSR
+ingest/transpose/sharding, band detection, the no-CPU-fallback rule) behaves."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from _util import ROOT, coo_list, golden
+import tmgcn_amd
+from tmgcn_amd import _lib, ops, synth
+from tmgcn_amd.csr import BatchedCSR
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "tmgcn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tmgcn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_functions()
+    assert len(names) >= 12
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tmgcn.h but not exported by libtmgcn_hip.so"
+
+
+def test_ctypes_table_matches_header():
+    assert sorted(_lib.SIGNATURES) == header_functions()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "tmgcn.h")).read(), flags=re.S)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(name + r"\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(args), f"{name}: header has {len(params)} parameters, ctypes table {len(args)}"
+
+
+def test_abi_version_and_error_string():
+    lib = _lib.load()
+    assert lib.tmgcn_abi_version() == 1
+    assert isinstance(lib.tmgcn_last_error(), bytes)
+    # argument validation happens before any device work: callable without a GPU
+    rc = lib.tmgcn_spmm_csr_batched_f32(None, None, None, None, None, 10, 3, 4, None)
+    assert rc == -1 and b"multiple" in lib.tmgcn_last_error() or b"null" in lib.tmgcn_last_error()
+    assert lib.tmgcn_gemm_dw_workspace_bytes(1000, 6, 6, 0) > 0
+    assert lib.tmgcn_spmm_gemm_supported(128, 128) == 1 and lib.tmgcn_spmm_gemm_supported(6, 6) == 0
+
+
+def test_no_cpu_fallback():
+    """The product path fails loudly on CPU tensors / without a device."""
+    d = golden("g2_gcn_condensed1")
+    X = torch.from_numpy(d["X"])
+    At = coo_list(d, "At", X.shape[0], X.shape[1])
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU"):
+            tmgcn_amd.EmbeddingGCN(At, X, torch.from_numpy(d["edges"]), torch.from_numpy(d["M"]), hidden_feat=[6, 2],
+                                   condensed_W=True, use_Minv=False)
+    csr = BatchedCSR.from_coo_list(At, N=X.shape[1])
+    with pytest.raises(RuntimeError, match="ROCm"):
+        ops.kernels.spmm(csr, X.float())
+    with pytest.raises(RuntimeError, match="ROCm"):
+        ops.kernels.mtransform(ops.MOperator(d["M"], "cpu"), X.float())
+
+
+def test_batched_csr_ingest_matches_reference_format():
+    d = golden("g3_gcn2_default_relu_condensed1")
+    X = torch.from_numpy(d["X"])
+    T, N = X.shape[0], X.shape[1]
+    At = coo_list(d, "At", T, N)
+    csr = BatchedCSR.from_coo_list(At, N=N)
+    assert csr.T == T and csr.N == N and csr.rowptr.numel() == T * N + 1
+    dense = torch.stack([a.to_dense() for a in At]).float()
+    assert torch.equal(csr.to_dense(), dense)
+    # columns sorted inside every row; rowptr monotone
+    assert bool((csr.rowptr[1:] >= csr.rowptr[:-1]).all())
+    rid = csr.row_ids()
+    same_row = rid[1:] == rid[:-1]
+    assert bool((csr.col[1:][same_row] >= csr.col[:-1][same_row]).all())
+    # transpose, slices, round trip to the list-of-COO form
+    assert torch.equal(csr.transpose().to_dense(), dense.transpose(1, 2))
+    assert csr.transpose().transpose() is csr
+    assert torch.equal(csr.slices(2, 5).to_dense(), dense[2:5])
+    back = csr.to_coo_list()
+    assert all(torch.equal(b.to_dense().float(), a.to_dense().float()) for a, b in zip(At, back))
+
+
+def test_csr_duplicates_empty_rows_and_bad_indices():
+    k = torch.tensor([0, 0, 0, 1])
+    i = torch.tensor([2, 2, 0, 3])
+    j = torch.tensor([1, 1, 3, 3])  # a duplicate entry (2,1) in slice 0
+    v = torch.tensor([1.0, 2.0, 4.0, 8.0])
+    csr = BatchedCSR.from_coo(k, i, j, v, T=2, N=4)
+    assert csr.nnz == 4  # duplicates kept; they sum in the product like uncoalesced COO in sparse.mm
+    assert float(csr.to_dense()[0, 2, 1]) == 3.0
+    assert int(csr.rowptr[2]) - int(csr.rowptr[1]) == 0  # empty row
+    with pytest.raises(RuntimeError, match="out of range"):
+        BatchedCSR.from_coo(k, i, torch.tensor([1, 1, 3, 4]), v, T=2, N=4)
+    with pytest.raises(RuntimeError):
+        BatchedCSR.from_coo_list([], N=4)
+
+
+def test_moperator_band_detection():
+    for T, b in ((34, 20), (5, 3), (10, 1), (8, 30)):
+        for kind in ("matlab", "python"):
+            op = ops.MOperator(synth.band_M(T, b, kind), "cpu")
+            assert (op.band_lo, op.band_hi) == (min(b, T) - 1, 0)
+    dense = ops.MOperator(torch.randn(6, 6, dtype=torch.float64), "cpu")
+    assert (dense.band_lo, dense.band_hi) == (5, 5)
+    inv = ops.MOperator(synth.band_M(12, 4, "matlab"), "cpu").inverse()
+    assert inv.band_hi == 0 and inv.band_lo == 11  # lower-triangular, dense below the diagonal
+    assert np.allclose(inv.M64.numpy() @ synth.band_M(12, 4, "matlab"), np.eye(12), atol=1e-12)
+    w = ops.MOperator(synth.band_M(12, 4, "matlab"), "cpu").window(0, 11)  # the scripts' M[:-1,:-1]
+    assert w.T == 11 and w.band_lo == 3
+
+
+def test_synth_configs_have_the_scripts_shapes():
+    g = synth.dynamic_graph(**synth.CONFIGS["S0"], seed=0)
+    assert g.X.shape == (10, 500, 16) and len(g.Ct) == 10 and g.M.shape == (10, 10)
+    # every Â slice has the full diagonal (the reference's size inference needs it)
+    assert all(c.diagonal().min() > 0 for c in g.Ct)
+    lp = synth.dynamic_graph(T=6, N=80, edges_per_slice=40, seed=1, neg_per_pos=3)
+    assert set(np.unique(lp.labels)) == {0, 1} and lp.edges.shape[0] == 3
+    a = synth.device_er_csr(2, 1000, 32, "cpu", first_slice=5)
+    b = synth.device_er_csr(1, 1000, 32, "cpu", first_slice=6)
+    assert a.nnz == 2 * 1000 * 33 and torch.equal(a.slices(1, 2).col, b.col)  # seeded by global slice index
