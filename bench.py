@@ -46,6 +46,9 @@ def parse():
     p.add_argument("--exchange", choices=["a2a", "allgather"], default="a2a")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-fuse", action="store_true", help="run P2 and P3 as separate kernels")
+    p.add_argument("--no-pipeline", action="store_true", help="exchange all slices before computing")
+    p.add_argument("--force-collectives", action="store_true",
+                   help="run the exchange (RCCL) code path even at --gpus 1 (diagnostic)")
     p.add_argument("--cpu-nodes", type=int, default=500_000, help="N of the CPU-baseline sample")
     return p.parse_args()
 
@@ -95,8 +98,9 @@ def main():
     dev = torch.device("cuda", local)
 
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from tmgcn_amd import _lib, ops, synth
@@ -109,9 +113,10 @@ def main():
     A = synth.device_er_csr(Tl, N, args.deg, dev, first_slice=k0)
     A.transpose()  # backward operand, built once (plan time, not timed)
     M = synth.band_M(T, args.band, "matlab")
-    layer = ShardedTMGCNLayer(A, M, T, group=None, exchange=args.exchange, fuse=False if args.no_fuse else None)
+    layer = ShardedTMGCNLayer(A, M, T, group=None, exchange=args.exchange, fuse=False if args.no_fuse else None,
+                              pipeline=not args.no_pipeline, force_collectives=args.force_collectives)
     shape = layer.input_shape(F)
-    if G > 1 and args.exchange == "a2a":
+    if layer.collective and args.exchange == "a2a":
         # node shard of the synthetic features: slice k seeded by k, columns of this rank's nodes
         X = synth.device_features(T, shape[1], F, dev, first_slice=1000 * rank)
     else:
@@ -184,7 +189,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S4 TM-GCN layer fwd+bwd: {Tl} slices/GPU (T={T}), N={N}, "
                                    f"deg={args.deg}+self, F={F}->{F}, band-M b={args.band}, fp32",
-                       "exchange": args.exchange if world > 1 else "none",
+                       "exchange": args.exchange if layer.collective else "none",
                        "edge_slices_per_step": total_nnz},
             "roofline": {"kernel": "spmm_gemm_kernel (forward P2 + fused P3)" if dom == "spmm_gemm" else "spmm_vec4_kernel (forward P2)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -195,7 +200,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

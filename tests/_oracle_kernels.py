@@ -14,6 +14,18 @@ def _perm(T, tl):
     return pos, inv
 
 
+def _view_coo(A):
+    """list-of-COO (fp64) of a BatchedCSR or of one of its slice views (shared col/val storage)."""
+    out = []
+    for k in range(A.T):
+        rp = A.rowptr[k * A.N:(k + 1) * A.N + 1]
+        a, b = int(rp[0]), int(rp[-1])
+        rows = torch.repeat_interleave(torch.arange(A.N), rp[1:] - rp[:-1])
+        idx = torch.stack([rows, A.col[a:b].long()])
+        out.append(torch.sparse_coo_tensor(idx, A.val[a:b].double(), (A.N, A.N)))
+    return out
+
+
 class OracleKernels:
     name = "oracle"
 
@@ -34,7 +46,23 @@ class OracleKernels:
         return Y
 
     def spmm(self, A, X, tag=None):
-        return orc.slice_spmm(A.to_coo_list(), X.double())
+        return orc.slice_spmm(_view_coo(A), X.double())
+
+    def spmm_gemm_supported(self, K, Nf):
+        return K in (16, 32, 64, 128) and Nf <= 128  # mirror the device rule so the same paths run
+
+    def spmm_gemm(self, A, X, W, trans_w=False, act=None, want_ax=False, want_pre=False, tag=None, out=None):
+        lists = _view_coo(A)
+        AX = orc.slice_spmm(lists, X.double())
+        Y, pre = self.gemm(AX, W, trans_w=trans_w, act=act, want_pre=True)
+        if out is not None:
+            out[0].copy_(Y)
+            if out[1] is not None:
+                out[1].copy_(AX)
+            if out[2] is not None and pre is not None:
+                out[2].copy_(pre)
+            return out
+        return Y, (AX if want_ax else None), (pre if want_pre else None)
 
     def gemm(self, A, W, trans_w=False, act=None, want_pre=False):
         Wd = W.double().transpose(-1, -2) if trans_w else W.double()

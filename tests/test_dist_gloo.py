@@ -35,12 +35,12 @@ def _problem(T, N, F0, F1, b, condensed):
     return g, torch.from_numpy(g.X).float(), W, dY
 
 
-def _worker(rank, world, port, exchange, condensed, act, ret):
+def _worker(rank, world, port, exchange, condensed, act, F0, ret):
     try:
         _setup(rank, world, port)
         from tmgcn_amd.csr import BatchedCSR
         from tmgcn_amd.dist import ShardedTMGCNLayer, even_bounds
-        T, N, F0, F1, b = 8, 30, 4, 6, 5
+        T, N, F1, b = 8, 30, 6, 5
         g, X, W, dY = _problem(T, N, F0, F1, b, condensed)
         k0, k1 = even_bounds(T, world)[rank]
         n0, n1 = even_bounds(N, world)[rank]
@@ -93,12 +93,13 @@ def _reference_local(g, X, W, dY, act):
 
 @pytest.mark.parametrize("exchange", ["a2a", "allgather"])
 @pytest.mark.parametrize("condensed,act", [(True, None), (False, "selu")])
-def test_sharded_layer_matches_unsharded(exchange, condensed, act):
+@pytest.mark.parametrize("F0", [4, 16])  # 16: widths the fused kernel takes -> pipelined per-slice exchange
+def test_sharded_layer_matches_unsharded(exchange, condensed, act, F0):
     world = 2
-    port = 29600 + (hash((exchange, condensed)) % 200)
+    port = 29600 + (abs(hash((exchange, condensed, F0))) % 300)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, exchange, condensed, act, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, exchange, condensed, act, F0, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", f"rank {r}:\n{ret.get(r)}"
 

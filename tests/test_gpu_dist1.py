@@ -1,0 +1,52 @@
+"""GPU: the sharded layer's exchange code path through RCCL at world size 1 (the GPU box has one
+GPU; world_size-2 logic is covered on CPU by test_dist_gloo.py).  Checks that the pipelined
+per-slice all-to-all + fused kernel path, the plain a2a path and the all-gather path all
+reproduce the unsharded layer on the device."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from _util import REL_TOL, assert_close
+from tmgcn_amd import synth
+from tmgcn_amd.csr import BatchedCSR
+from tmgcn_amd.dist import ShardedTMGCNLayer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange,pipeline,F0", [("a2a", True, 16), ("a2a", False, 16), ("a2a", True, 6), ("allgather", True, 16)])
+@pytest.mark.parametrize("condensed,act", [(True, None), (False, "leaky")])
+def test_world1_rccl_paths_match_unsharded(pg, exchange, pipeline, F0, condensed, act):
+    T, N, F1 = 6, 120, 32
+    g = synth.dynamic_graph(T, N, edges_per_slice=300, seed=2, no_diag=4, F0=F0)
+    A = BatchedCSR.from_scipy_list(g.Ct, device="cuda")
+    gen = torch.Generator().manual_seed(4)
+    X0 = torch.from_numpy(g.X).float().cuda()
+    W0 = (torch.randn(*(() if condensed else (T,)), F0, F1, generator=gen) * 0.3).cuda()
+    dY = torch.randn(T, N, F1, generator=gen).cuda()
+    res = []
+    for force in (False, True):
+        layer = ShardedTMGCNLayer(A, g.M, T, exchange=exchange, pipeline=pipeline, force_collectives=force)
+        assert layer.collective == force
+        X = X0.clone().requires_grad_(True)
+        W = W0.clone().requires_grad_(True)
+        Y = layer(X, W, act=act)
+        Y.backward(dY)
+        torch.cuda.synchronize()
+        res.append((Y.detach(), X.grad, W.grad))
+        if force and exchange == "a2a":
+            assert_close(layer.to_node_sharded(Y.detach()), Y.detach(), 0.0, "to_node_sharded at G=1")
+    for a, b, what in zip(res[1], res[0], ("Y", "dX", "dW")):
+        assert_close(a, b, REL_TOL, f"{exchange} pipeline={pipeline} {what}")

@@ -171,8 +171,26 @@ class BatchedCSR:
         return BatchedCSR((self.rowptr[lo:hi + 1] - base).clone(), self.col[base:end].clone(),
                           self.val[base:end].clone(), k1 - k0, self.N)
 
+    def slice_views(self) -> List["BatchedCSR"]:
+        """One single-slice BatchedCSR per slice, sharing this object's storage (no copies): the
+        rowptr window of slice k keeps its global offsets into the full col/val arrays.  Used to
+        launch slice by slice so that compute on slice k overlaps the exchange of slice k+1."""
+        out = []
+        bounds = self.rowptr[::self.N].tolist()
+        for k in range(self.T):
+            v = BatchedCSR.__new__(BatchedCSR)
+            v.rowptr = self.rowptr[k * self.N:(k + 1) * self.N + 1]
+            v.col, v.val = self.col, self.val
+            v.T, v.N = 1, self.N
+            v.nnz = bounds[k + 1] - bounds[k]
+            v._t = None
+            out.append(v)
+        return out
+
     def to_coo_list(self, dtype=torch.float64) -> List[torch.Tensor]:
         """Back to the reference's list-of-COO form (CPU), for the oracle / CPU baseline."""
+        if int(self.rowptr[0]) != 0 or int(self.rowptr[-1]) != self.col.numel():
+            raise RuntimeError("to_coo_list: call on the owning BatchedCSR, not on a slice view")
         rid = self.row_ids().cpu()
         col = self.col.cpu().to(torch.int64)
         val = self.val.cpu().to(dtype)

@@ -128,6 +128,92 @@ class _SharedWeight(torch.autograd.Function):
         return d, None
 
 
+class _PipelinedCore(torch.autograd.Function):
+    """"a2a" mode, fused kernel available: the per-slice all-to-alls run on a side stream while
+    the fused P2+P3 kernel works through the slices that have already arrived (forward), and
+    the slices the backward kernel has finished leave while it works on the next ones.
+    One slice of S4 is ~6 ms of gather and ~2 GB of exchange, so after the first slice the
+    exchange is hidden behind compute.  On CPU tensors (gloo tests) the same code runs
+    without streams."""
+
+    @staticmethod
+    def forward(ctx, send, W, layer, act):
+        G, Tl, N = layer.G, layer.Tl, layer.N
+        Nl, F = send.shape[-2], send.shape[-1]
+        K = ops.kernels
+        per_slice_w = W.dim() == 3
+        Nf = W.shape[-1]
+        dev = send.device
+        use_streams = send.is_cuda
+        need_w = ctx.needs_input_grad[1]
+        act_on = bool(act) and act != "none"
+        Xt = torch.empty(Tl, N, F, dtype=send.dtype, device=dev)
+        Y = torch.empty(Tl, N, Nf, dtype=send.dtype, device=dev)
+        AX = torch.empty(Tl, N, F, dtype=send.dtype, device=dev) if need_w else None
+        pre = torch.empty(Tl, N, Nf, dtype=send.dtype, device=dev) if act_on else None
+        if use_streams:
+            main = torch.cuda.current_stream(dev)
+            comm = layer.comm_stream()
+            comm.wait_stream(main)  # the send buffer (P1 output) is complete
+            evs = []
+            with torch.cuda.stream(comm):
+                for kk in range(Tl):
+                    dist.all_to_all_single(Xt[kk].view(G, Nl, F), send[kk], group=layer.group)
+                    ev = torch.cuda.Event()
+                    ev.record(comm)
+                    evs.append(ev)
+        for kk in range(Tl):
+            if use_streams:
+                main.wait_event(evs[kk])
+            else:
+                dist.all_to_all_single(Xt[kk].view(G, Nl, F), send[kk], group=layer.group)
+            Wk = W[kk:kk + 1] if per_slice_w else W
+            K.spmm_gemm(layer.A_views[kk], Xt[kk:kk + 1], Wk, act=act, want_ax=need_w, want_pre=act_on,
+                        out=(Y[kk:kk + 1], AX[kk:kk + 1] if need_w else None, pre[kk:kk + 1] if act_on else None))
+        ctx.layer, ctx.act, ctx.shape = layer, (act if act_on else None), (Tl, G, Nl, F)
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(W, AX if need_w else empty, pre if act_on else empty)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        layer = ctx.layer
+        W, AX, pre = ctx.saved_tensors
+        Tl, G, Nl, F = ctx.shape
+        K = ops.kernels
+        dY = dY.contiguous()
+        if ctx.act is not None:
+            dY = K.act_bwd(pre, dY, ctx.act)
+        per_slice_w = W.dim() == 3
+        dsend = dW = None
+        if ctx.needs_input_grad[0]:
+            dev = dY.device
+            use_streams = dY.is_cuda
+            dXt = torch.empty(Tl, layer.N, F, dtype=dY.dtype, device=dev)
+            dsend = torch.empty(Tl, G, Nl, F, dtype=dY.dtype, device=dev)
+            if use_streams:
+                main = torch.cuda.current_stream(dev)
+                comm = layer.comm_stream()
+                comm.wait_stream(main)  # dsend/dXt allocations and earlier work are ordered before the exchange
+            for kk in range(Tl):
+                Wk = W[kk:kk + 1] if per_slice_w else W
+                K.spmm_gemm(layer.At_views[kk], dY[kk:kk + 1], Wk, trans_w=True, tag="spmm_gemm_T",
+                            out=(dXt[kk:kk + 1], None, None))
+                if use_streams:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    comm.wait_event(ev)
+                    with torch.cuda.stream(comm):
+                        dist.all_to_all_single(dsend[kk], dXt[kk].view(G, Nl, F), group=layer.group)
+                else:
+                    dist.all_to_all_single(dsend[kk], dXt[kk].view(G, Nl, F), group=layer.group)
+            if use_streams:
+                main.wait_stream(comm)
+        if ctx.needs_input_grad[1]:
+            dW = K.gemm_dw(AX, dY, per_slice=per_slice_w)
+        return dsend, dW, None, None
+
+
 # ---------------------------------------------------------------------------------------
 # the sharded layer
 # ---------------------------------------------------------------------------------------
@@ -142,8 +228,15 @@ class ShardedTMGCNLayer:
     """
 
     def __init__(self, A_local: BatchedCSR, M, T: int, group=None, exchange: str = "a2a",
-                 apply_m: bool = True, fuse: Optional[bool] = None):
+                 apply_m: bool = True, fuse: Optional[bool] = None, pipeline: bool = True,
+                 force_collectives: bool = False):
         self.rank, self.G = _world(group)
+        # force_collectives: run the exchange code at world size 1 too (exercises the RCCL path on
+        # a single GPU; needs an initialised process group)
+        self.collective = self.G > 1 or (force_collectives and dist.is_initialized())
+        self.pipeline = pipeline
+        self._comm_stream = None
+        self._views = None
         self.group = group
         if exchange not in ("a2a", "allgather"):
             raise RuntimeError(f"unknown exchange {exchange!r}")
@@ -163,8 +256,24 @@ class ShardedTMGCNLayer:
         if apply_m and self.Mop.T != T:
             raise RuntimeError(f"M is {self.Mop.T}x{self.Mop.T}, expected {T}x{T}")
 
+    def comm_stream(self):
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.A.device)
+        return self._comm_stream
+
+    @property
+    def A_views(self):
+        if self._views is None:
+            self._views = (self.A.slice_views(), self.A.transpose().slice_views())
+        return self._views[0]
+
+    @property
+    def At_views(self):
+        self.A_views
+        return self._views[1]
+
     def input_shape(self, F: int):
-        if self.G == 1 or self.exchange == "allgather":
+        if not self.collective or self.exchange == "allgather":
             return (self.Tl, self.N, F)
         return (self.T, self.N // self.G, F)
 
@@ -172,7 +281,8 @@ class ShardedTMGCNLayer:
         if tuple(X.shape[:2]) != self.input_shape(X.shape[2])[:2]:
             raise RuntimeError(f"rank {self.rank}: input {tuple(X.shape)} does not match the "
                                f"'{self.exchange}' layout {self.input_shape(X.shape[2])}")
-        if self.G == 1:
+        shared_w = W.dim() == 2
+        if not self.collective:
             Xt = ops.m_transform(X, self.Mop) if self.apply_m else X
         elif self.exchange == "a2a":
             Nl, F = X.shape[1], X.shape[2]
@@ -181,19 +291,26 @@ class ShardedTMGCNLayer:
                 send = ops.m_transform(X, self.Mop, y_group_rows=self.Tl)
             else:
                 send = X.view(self.G, self.Tl, Nl, F).transpose(0, 1).contiguous()
-            Xt = _NodeToSlice.apply(send.view(self.Tl, self.G, Nl, F), self.Tl, self.N, self.group)
+            send = send.view(self.Tl, self.G, Nl, F)
+            can_fuse = hasattr(ops.kernels, "spmm_gemm_supported") and \
+                ops.kernels.spmm_gemm_supported(F, W.shape[-1])
+            if self.pipeline and can_fuse and self.fuse is not False:
+                if shared_w:
+                    W = _SharedWeight.apply(W, self.group)
+                return _PipelinedCore.apply(send, W, self, act)
+            Xt = _NodeToSlice.apply(send, self.Tl, self.N, self.group)
         else:
             Xf = _AllGatherSlices.apply(X, self.group)
             # own output slices only: rows [k0, k0+Tl) of M against all T input slices
             Xt = ops.m_transform(Xf, self.Mop, row_off=self.k0, col_off=0, T_out=self.Tl) if self.apply_m \
                 else Xf[self.k0:self.k0 + self.Tl].contiguous()
-        if W.dim() == 2 and self.G > 1:
+        if shared_w and self.collective:
             W = _SharedWeight.apply(W, self.group)      # condensed_W: dW summed over ranks
         return ops.spmm_feature_gemm(self.A, Xt, W, act=act, fuse=self.fuse)
 
     def to_node_sharded(self, Y: torch.Tensor) -> torch.Tensor:
         """Slice-sharded [T/G, N, F] -> node-sharded [T, N/G, F] (input of a following "a2a" layer)."""
-        if self.G == 1:
+        if not self.collective:
             return Y
         Nl, F = self.N // self.G, Y.shape[2]
         recv = _SliceToNode.apply(Y, self.group)          # [Tl][G][Nl][F], block kk = slice kk of every rank

@@ -150,8 +150,9 @@ class HipKernels:
         return bool(_lib.load().tmgcn_spmm_gemm_supported(K, Nf))
 
     def spmm_gemm(self, A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, trans_w=False, act=None,
-                  want_ax=False, want_pre=False, tag="spmm_gemm"):
-        """act((Â ⋆ X) · Wop) in one launch.  Returns (Y, AX or None, pre or None)."""
+                  want_ax=False, want_pre=False, tag="spmm_gemm", out=None):
+        """act((Â ⋆ X) · Wop) in one launch.  Returns (Y, AX or None, pre or None).
+        out = (Y, AX, pre) writes into caller-provided (views of) tensors instead of allocating."""
         lib = _lib.load()
         _want(X, "spmm_gemm X")
         _want(W, "spmm_gemm W")
@@ -163,9 +164,15 @@ class HipKernels:
         if wk != K or (per_slice and W.shape[0] != T):
             raise RuntimeError(f"spmm_gemm: size mismatch X {tuple(X.shape)} W {tuple(W.shape)} trans_w={trans_w}")
         act_id = _lib.ACT_IDS[act]
-        Y = torch.empty((T, N, wn), dtype=torch.float32, device=X.device)
-        AX = torch.empty_like(X) if want_ax else None
-        pre = torch.empty_like(Y) if (want_pre and act_id) else None
+        if out is not None:
+            Y, AX, pre = out
+            _want(Y, "spmm_gemm out Y")
+            if tuple(Y.shape) != (T, N, wn):
+                raise RuntimeError(f"spmm_gemm: out Y {tuple(Y.shape)} != {(T, N, wn)}")
+        else:
+            Y = torch.empty((T, N, wn), dtype=torch.float32, device=X.device)
+            AX = torch.empty_like(X) if want_ax else None
+            pre = torch.empty_like(Y) if (want_pre and act_id) else None
         rc = self._run(tag, X.device, lambda: lib.tmgcn_spmm_gemm_f32(
             _ptr(A.rowptr), _ptr(A.col), _ptr(A.val), _ptr(X), A.n_rows, A.N, K, _ptr(W), wn,
             int(bool(trans_w)), N if per_slice else 0, W.shape[-1] * W.shape[-2] if per_slice else 0, act_id,
