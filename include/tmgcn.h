@@ -136,6 +136,28 @@ int tmgcn_act_fwd_f32(const float* x, float* y, int64_t n, int32_t act, void* st
 int tmgcn_act_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, int32_t act,
                       void* stream);
 
+/* ---- P4: edge head  (ehf:228-232, 351-355, 491-495) --------------------------------
+ *   out[e][c] = sum_{f<F} Z[src[e]][f] * U[f][c] + sum_{f<F} Z[dst[e]][f] * U[F+f][c]
+ * src/dst are the flat row indices t*N+node built at ehf:196-198.  Z is [R][F], U is [2F][C].
+ * Supported when tmgcn_edge_head_supported(F, C) != 0 (F <= 32, C <= 8); wider heads use the
+ * caller's own gather + GEMM.
+ * Backward (autograd of the same statements), no atomics, fixed summation order:
+ *   dZ[r][f] (every row written, rows without edges get 0) and dU[2F][C].
+ *   eptr[R+1] / eidx[2E]: inverted edge index — the entries of row r are eidx[eptr[r]..eptr[r+1]),
+ *   entry = 2*edge + role (role 0: r is the edge's src, 1: its dst); built once per edge set.
+ *   dZ or dU may be NULL to skip that gradient.
+ */
+int tmgcn_edge_head_supported(int32_t F, int32_t C);
+int tmgcn_edge_head_fwd_f32(const float* Z, const int64_t* src, const int64_t* dst,
+                            const float* U, float* out, int64_t E, int32_t F, int32_t C,
+                            void* stream);
+int64_t tmgcn_edge_head_bwd_workspace_bytes(int64_t E, int32_t F, int32_t C);
+int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const int64_t* dst,
+                            const float* U, const float* dout,
+                            const int64_t* eptr, const int64_t* eidx,
+                            float* dZ, float* dU, int64_t R, int64_t E, int32_t F, int32_t C,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,10 +36,16 @@ def m_transform(M: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
     return torch.matmul(M, X.reshape(T, -1)).reshape(X.size())
 
 
+# The reference rounds P1/P2 results into fp32 buffers (`t.zeros(...)`, ehf:205, 302, 309, 470).
+# Tests that need an fp64 "truth" of the same math (to judge fp32 reduction noise at full size)
+# switch this to torch.float64; the reference-faithful value is float32.
+BUFFER_DTYPE = torch.float32
+
+
 def slice_spmm(A: Sequence[torch.Tensor], X: torch.Tensor) -> torch.Tensor:
     """P2, ehf:206-207 / 303-304 / 310-311 / 471-472: per-slice sparse·dense into an fp32 buffer."""
     T, N = len(A), X.shape[1]
-    out = torch.zeros(T, N, X.shape[-1])  # fp32, as `t.zeros(...)` in the reference
+    out = torch.zeros(T, N, X.shape[-1], dtype=BUFFER_DTYPE)  # fp32, as `t.zeros(...)` in the reference
     for k in range(T):
         out[k] = torch.sparse.mm(A[k], X[k])
     return out
@@ -59,7 +65,7 @@ def flat_edge_index(edges: torch.Tensor, N: int):
 def edge_head(Z: torch.Tensor, src, dst, U: torch.Tensor) -> torch.Tensor:
     """P4, ehf:228-232 / 351-355 / 491-495."""
     Zf = Z.reshape(-1, Z.shape[-1])
-    return torch.matmul(torch.cat((Zf[src], Zf[dst]), dim=1).float(), U)
+    return torch.matmul(torch.cat((Zf[src], Zf[dst]), dim=1).to(U.dtype), U)  # `.float()` in the reference (U is fp32)
 
 
 def draw_params(kind: str, T: int, F: List[int], condensed_W: bool = True):

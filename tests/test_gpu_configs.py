@@ -1,0 +1,136 @@
+"""GPU: parity at the sizes of the BASELINE configs.
+
+S1-S3 (reference-shaped real configs): the scripts' model on the full-size synthetic
+stand-in vs the oracle run the reference's way (logits + all gradients).
+S4-shaped (large N, F=128): size-independent properties — the oracle would take minutes there:
+constants are preserved by a row-normalised Â and by P1 (row sums of M), linearity, and the
+adjoint identity <Y, dY> = <X, dX> that ties forward and backward together."""
+import pytest
+import torch
+
+from _util import REL_TOL, assert_close
+import tmgcn_amd.layers as ehf
+from tmgcn_amd import ops, synth
+from tmgcn_amd.dist import ShardedTMGCNLayer
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(orc, kind, g, At, X, M, edges, labels, params, nonlin, dtype, dlogits=None):
+    """Oracle forward+backward with parameters/buffers in `dtype` (fp32 = the reference's way,
+    fp64 = the same math without fp32 reduction noise).  With `dlogits` the backward starts from
+    that upstream gradient instead of the loss."""
+    orc.BUFFER_DTYPE = dtype
+    try:
+        p = {n: q.to(dtype).clone().requires_grad_(True) for n, q in params.items()}
+        src, dst = orc.flat_edge_index(edges, g.N)
+        AtXt = orc.compute_AtXt(M, At, X)
+        if kind == "gcn":
+            ref = orc.gcn_forward(AtXt, p["W"], p["U"], src, dst)
+        else:
+            ref = orc.gcn2_forward(AtXt, At, M, p["W1"], p["W2"], p["U"], src, dst, nonlin=nonlin)
+        if dlogits is None:
+            ref.retain_grad()
+            torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1], dtype=dtype))(ref, labels).backward()
+            dlogits = ref.grad
+        else:
+            ref.backward(dlogits.to(dtype))
+    finally:
+        orc.BUFFER_DTYPE = torch.float32
+    return ref.detach(), {n: q.grad for n, q in p.items()}, dlogits
+
+
+def _check(got, ref32, truth, what):
+    """Bar at full size: within the stated 1e-5 of the reference-way fp32 result, OR at least as
+    close to the fp64 truth as twice the reference's own fp32 result is (sums over 10^5-10^6 terms:
+    the reference's fp32 reduction order is itself only good to a few 1e-5 there)."""
+    from _util import max_rel_err
+    e_ref = max_rel_err(got, ref32)
+    e_truth = max_rel_err(got, truth)
+    e_ref_truth = max_rel_err(ref32, truth)
+    assert e_ref <= REL_TOL or e_truth <= max(REL_TOL, 2 * e_ref_truth), \
+        f"{what}: vs reference-fp32 {e_ref:.2e}, vs fp64 truth {e_truth:.2e} (reference itself {e_ref_truth:.2e})"
+
+
+def _run_model(name, kind, hidden, nonlin="selu", param_dtype=torch.float32, scale=1.0):
+    from oracle import tmgcn_oracle as orc
+    g = synth.dynamic_graph(**synth.CONFIGS[name], seed=0)
+    At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
+    edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels)
+    torch.manual_seed(1)
+    kw = dict(condensed_W=True, use_Minv=False, param_dtype=param_dtype)
+    if kind == "gcn":
+        m = ehf.EmbeddingGCN(At, X, edges, M, hidden_feat=hidden, **kw)
+    else:
+        m = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=hidden, nonlin2=nonlin, **kw)
+    out = m()
+    params = {n: q.detach().float().cpu() for n, q in m.named_parameters()}
+    # The backward of the PATH is checked from one common upstream gradient: the weighted-CE
+    # gradient the reference's loss gives at its own logits (CPU).  torch-ROCm's weighted-mean
+    # CrossEntropyLoss over 3.2 M edges normalises in fp32 and is itself 2.6e-5 off the fp64
+    # value at the S2 size (measured; it is the scripts' untouched loss code, not this path).
+    ref32, g32, dlogits = _oracle(orc, kind, g, At, X, M, edges, labels, params, nonlin, torch.float32)
+    ref64, g64, _ = _oracle(orc, kind, g, At, X, M, edges, labels, params, nonlin, torch.float64, dlogits)
+    out.backward(dlogits.cuda())
+    return m, out, (ref32, g32), (ref64, g64)
+
+
+def test_S1_bitcoin_shaped_2layer_fp32():
+    m, out, (ref32, g32), (ref64, g64) = _run_model("S1", "gcn2", [6, 6, 2])
+    _check(out, ref32, ref64, "S1 logits")
+    for n, q in m.named_parameters():
+        _check(q.grad, g32[n], g64[n], "S1 d" + n)
+
+
+def test_S2_reddit_lp_shaped_1layer_fp32():
+    m, out, (ref32, g32), (ref64, g64) = _run_model("S2", "gcn", [6, 2])
+    assert out.shape[0] > 3_000_000  # 20x the real edges are labelled (19 negatives per positive)
+    _check(out, ref32, ref64, "S2 logits")
+    for n, q in m.named_parameters():
+        _check(q.grad, g32[n], g64[n], "S2 d" + n)
+
+
+def test_S3_amlsim_shaped_bf16_weights():
+    """bf16-stored weights, fp32 kernels.  The oracle is fed the same (bf16-representable) weight
+    values, so the forward matches at the fp32 tolerance; gradients are rounded to bf16 once
+    (<= 2^-8 relative), inside the stated bf16 tolerance 2e-2."""
+    m, out, (ref32, g32), (ref64, g64) = _run_model("S3", "gcn2", [6, 6, 2], param_dtype=torch.bfloat16)
+    assert all(q.dtype == torch.bfloat16 for q in m.parameters())
+    _check(out, ref32, ref64, "S3 logits")
+    for n, q in m.named_parameters():
+        assert q.grad.dtype == torch.bfloat16
+        assert_close(q.grad.float(), g32[n], 2e-2, "S3 d" + n)
+
+
+def test_S4_shaped_properties_large():
+    T, N, F, deg = 2, 500_000, 128, 32
+    dev = "cuda"
+    A = synth.device_er_csr(T, N, deg, dev)
+    M = synth.band_M(T, 20, "matlab")
+    layer = ShardedTMGCNLayer(A, M, T)
+    g = torch.Generator(device=dev).manual_seed(0)
+    W = torch.randn(F, F, device=dev, generator=g) * 0.1
+    # 1. constants: Â is row-normalised (rows sum to 1) so Â·1 = 1; P1 of a constant scales by M's row sums
+    ones = torch.ones(T, N, F, device=dev)
+    Y = layer(ones, W)
+    rowsum_M = torch.from_numpy(M).sum(1).float().to(dev)
+    expect = rowsum_M[:, None, None] * W.sum(0)[None, None, :]
+    assert_close(Y, expect.expand_as(Y), 2e-6, "constant input")
+    # 2. linearity
+    X1 = torch.rand(T, N, F, device=dev, generator=g)
+    X2 = torch.rand(T, N, F, device=dev, generator=g)
+    assert_close(layer(2.0 * X1 - 0.5 * X2, W), 2.0 * layer(X1, W) - 0.5 * layer(X2, W), 1e-5, "linearity")
+    # 3. adjoint identity: <layer(X), dY> = <X, dX>, and dW from the same pass
+    X = X1.clone().requires_grad_(True)
+    Wg = W.clone().requires_grad_(True)
+    dY = torch.randn(T, N, F, device=dev, generator=g)
+    Yg = layer(X, Wg)
+    Yg.backward(dY)
+    lhs = float((Yg.detach().double() * dY.double()).sum())
+    rhs = float((X.detach().double() * X.grad.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs), (lhs, rhs)
+    rhs_w = float((Wg.detach().double() * Wg.grad.double()).sum())
+    assert abs(lhs - rhs_w) <= 1e-5 * abs(lhs), (lhs, rhs_w)
+    # 4. fused and unfused paths agree at this size
+    un = ShardedTMGCNLayer(A, M, T, fuse=False)
+    assert_close(un(X1, W), layer(X1, W), 1e-6, "fused vs unfused")

@@ -258,3 +258,52 @@ def test_spmm_gemm_unsupported_width_raises():
     # the dispatcher falls back to the two-kernel path
     Y = ops.spmm_feature_gemm(csr, torch.randn(2, 20, 20, device=DEV), torch.randn(20, 8, device=DEV))
     assert tuple(Y.shape) == (2, 20, 8)
+
+
+# ------------------------------------------------------------------------------------- P4 edge head
+@pytest.mark.parametrize("F,C", [(2, 2), (6, 2), (6, 3), (16, 8), (32, 2), (5, 1)])
+@pytest.mark.parametrize("E", [0, 1, 1000, 70001])
+def test_edge_head_fwd_bwd(F, C, E):
+    T, N = 3, 97
+    g = torch.Generator().manual_seed(F * 100 + C + E)
+    Z = torch.randn(T, N, F, generator=g)
+    U = torch.randn(2 * F, C, generator=g)
+    edges = torch.stack([torch.randint(0, T, (E,), generator=g), torch.randint(0, N, (E,), generator=g),
+                         torch.randint(0, N, (E,), generator=g)])
+    if E > 10:
+        edges[:, 1] = edges[:, 0]  # a duplicated edge
+        edges[1, 2:9] = 5          # a hub row
+    dout = torch.randn(E, C, generator=g)
+    # fp64 reference of the reference's statements (ehf:228-232) and autograd through them
+    Zr = Z.double().clone().requires_grad_(True)
+    Ur = U.double().clone().requires_grad_(True)
+    Zf = Zr.reshape(-1, F)
+    ref = torch.cat((Zf[edges[0] * N + edges[1]], Zf[edges[0] * N + edges[2]]), dim=1) @ Ur
+    ref.backward(dout.double())
+    eidx = ops.EdgeIndex(edges, N, DEV)
+    Zg = Z.to(DEV).requires_grad_(True)
+    Ug = U.to(DEV).requires_grad_(True)
+    assert ops.kernels.edge_head_supported(F, C)
+    out = ops.edge_head(Zg, eidx, Ug, fuse=True)
+    out.backward(dout.to(DEV))
+    if E:
+        assert_close(out, ref.detach(), REL_TOL, "edge head logits")
+        assert_close(Zg.grad, Zr.grad, REL_TOL, "edge head dZ")
+        assert_close(Ug.grad, Ur.grad, REL_TOL, "edge head dU")
+    else:
+        assert out.shape == (0, C) and float(Zg.grad.abs().max()) == 0.0 and float(Ug.grad.abs().max()) == 0.0
+    # bitwise reproducible (no atomics), and identical to the unfused torch path within tolerance
+    Z2 = Z.to(DEV).requires_grad_(True)
+    U2 = U.to(DEV).requires_grad_(True)
+    ops.edge_head(Z2, eidx, U2, fuse=True).backward(dout.to(DEV))
+    assert torch.equal(Z2.grad, Zg.grad) and torch.equal(U2.grad, Ug.grad)
+
+
+def test_edge_head_wide_falls_back():
+    assert not ops.kernels.edge_head_supported(128, 2)
+    Z = torch.randn(2, 10, 128, device=DEV)
+    U = torch.randn(256, 2, device=DEV)
+    e = ops.EdgeIndex(torch.tensor([[0, 1], [1, 2], [3, 4]]), 10, DEV)
+    assert tuple(ops.edge_head(Z, e, U).shape) == (2, 2)
+    with pytest.raises(RuntimeError):
+        ops.edge_head(Z, e, U, fuse=True)

@@ -1,0 +1,240 @@
+// P4 — edge head: out[e] = [Z[src[e]] , Z[dst[e]]] · U  and its backward   (gfx950 / CDNA4)
+//
+// Replaces  Y.reshape(-1,F)[edge_src_nodes], [edge_trg_nodes], t.cat(...,1), t.matmul(.,U)
+// (embedding_help_functions.py:228-232, 351-355, 491-495) and autograd through them
+// (index backward = scatter-add into dZ, dU = catᵀ·dout).
+//
+// Link-prediction configs label 20x the real edges (E ≈ 3.2 M at the Reddit-shaped size,
+// F = 6, C = 2): as separate torch ops this is eight full passes over E-sized tensors plus an
+// atomic scatter; here it is one gather-and-dot kernel forward, and backward two kernels that
+// use no atomics:
+//   dZ   per row r:  S_src[c] = Σ_{e: src[e]=r} dout[e][c],  S_dst likewise (inverted edge index,
+//        built once per edge set), then  dZ[r][f] = Σ_c S_src[c]·U[f][c] + S_dst[c]·U[F+f][c]
+//        — the sum over edges is taken BEFORE the product with U, so the work is E·C, not E·F.
+//   dU   row-chunk slabs of  [Z[src[e]], Z[dst[e]]]ᵀ · dout[e]  with fp64 running sums, reduced
+//        in fixed order.
+// Everything is summed in a fixed order: bitwise reproducible (torch's index_put backward on
+// the GPU uses float atomics and is not).
+#include "common.h"
+
+namespace tmgcn {
+
+constexpr int kMaxC = 8;    // classes
+constexpr int kMaxF = 32;   // embedding width handled by the fused head
+
+struct EdgeArgs {
+  const float* Z;       // [R][F]
+  const int64_t* src;   // [E] flat row index t*N+node (ehf:196-198)
+  const int64_t* dst;   // [E]
+  const float* U;       // [2F][C]
+  float* out;           // [E][C]
+  int64_t E;
+  int32_t F, C;
+};
+
+__global__ __launch_bounds__(256) void edge_head_fwd_kernel(EdgeArgs a) {
+  __shared__ float Us[2 * kMaxF * kMaxC];
+  for (int t = threadIdx.x; t < 2 * a.F * a.C; t += 256) Us[t] = a.U[t];
+  __syncthreads();
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.E) return;
+  const float* zs = a.Z + a.src[e] * a.F;
+  const float* zd = a.Z + a.dst[e] * a.F;
+  float acc[kMaxC];
+#pragma unroll
+  for (int c = 0; c < kMaxC; ++c) acc[c] = 0.f;
+  for (int f = 0; f < a.F; ++f) {
+    const float s = zs[f], d = zd[f];
+    const float* us = Us + f * a.C;
+    const float* ud = Us + (a.F + f) * a.C;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < a.C) acc[c] = fmaf(d, ud[c], fmaf(s, us[c], acc[c]));
+  }
+#pragma unroll
+  for (int c = 0; c < kMaxC; ++c)
+    if (c < a.C) a.out[e * a.C + c] = acc[c];
+}
+
+struct EdgeBwdArgs {
+  const float* Z;
+  const int64_t* src;
+  const int64_t* dst;
+  const float* U;
+  const float* dout;     // [E][C]
+  const int64_t* eptr;   // [R+1] inverted index: entries of row r are eidx[eptr[r] .. eptr[r+1])
+  const int64_t* eidx;   // [2E]  entry = 2*edge + role (0: the row is the edge's src, 1: its dst)
+  float* dZ;             // [R][F]
+  float* part;           // dU slabs [chunks][2F][C]
+  int64_t R, E;
+  int32_t F, C;
+  int32_t chunks;
+  int64_t edges_per_chunk;
+};
+
+__global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
+  __shared__ float Us[2 * kMaxF * kMaxC];
+  for (int t = threadIdx.x; t < 2 * a.F * a.C; t += 256) Us[t] = a.U[t];
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.R) return;
+  double S[2][kMaxC];
+#pragma unroll
+  for (int c = 0; c < kMaxC; ++c) S[0][c] = S[1][c] = 0.0;
+  for (int64_t p = a.eptr[r]; p < a.eptr[r + 1]; ++p) {
+    const int64_t x = a.eidx[p];
+    const float* g = a.dout + (x >> 1) * a.C;
+    const bool is_dst = x & 1;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < a.C) {
+        const double v = (double)g[c];
+        if (is_dst) S[1][c] += v; else S[0][c] += v;
+      }
+  }
+  float s0[kMaxC], s1[kMaxC];
+#pragma unroll
+  for (int c = 0; c < kMaxC; ++c) {
+    s0[c] = (float)S[0][c];
+    s1[c] = (float)S[1][c];
+  }
+  for (int f = 0; f < a.F; ++f) {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < a.C) v = fmaf(s1[c], Us[(a.F + f) * a.C + c], fmaf(s0[c], Us[f * a.C + c], v));
+    a.dZ[r * a.F + f] = v;
+  }
+}
+
+// dU slabs: one output element (k, c), k in [0, 2F), per thread slot; edges staged through LDS.
+constexpr int DU_EDGES = 64;
+__global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
+  __shared__ float sz[DU_EDGES * 2 * kMaxF];
+  __shared__ float sd[DU_EDGES * kMaxC];
+  const int K = 2 * a.F;
+  const int n_out = K * a.C;  // <= 512
+  const int64_t e0 = (int64_t)blockIdx.x * a.edges_per_chunk;
+  int64_t e1 = e0 + a.edges_per_chunk;
+  if (e1 > a.E) e1 = a.E;
+  double acc[2] = {0.0, 0.0};
+  int ok_[2], oc_[2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int idx = threadIdx.x + o * 256;
+    ok_[o] = idx < n_out ? idx / a.C : -1;
+    oc_[o] = idx < n_out ? idx % a.C : 0;
+  }
+  for (int64_t e = e0; e < e1; e += DU_EDGES) {
+    const int ne = (int)((e1 - e) < DU_EDGES ? (e1 - e) : DU_EDGES);
+    __syncthreads();
+    for (int t = threadIdx.x; t < ne * K; t += 256) {
+      const int i = t / K, k = t % K;
+      const int64_t row = k < a.F ? a.src[e + i] : a.dst[e + i];
+      sz[t] = a.Z[row * a.F + (k < a.F ? k : k - a.F)];
+    }
+    for (int t = threadIdx.x; t < ne * a.C; t += 256) sd[t] = a.dout[e * a.C + t];
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+      if (ok_[o] >= 0) {
+        double s = acc[o];
+        for (int i = 0; i < ne; ++i) s += (double)sz[i * K + ok_[o]] * (double)sd[i * a.C + oc_[o]];
+        acc[o] = s;
+      }
+  }
+  float* P = a.part + (int64_t)blockIdx.x * n_out;
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+    if (ok_[o] >= 0) P[threadIdx.x + o * 256] = (float)acc[o];
+}
+
+__global__ void edge_head_du_reduce_kernel(const float* __restrict__ part, float* __restrict__ dU,
+                                           int n_out, int chunks) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  double s = 0.0;
+  for (int c = 0; c < chunks; ++c) s += (double)part[(int64_t)c * n_out + o];
+  dU[o] = (float)s;
+}
+
+static void du_plan(int64_t E, int* chunks, int64_t* per) {
+  int64_t c = (E + 4095) / 4096;
+  if (c > 2048) c = 2048;
+  if (c < 1) c = 1;
+  int64_t p = (E + c - 1) / c;
+  p = (p + DU_EDGES - 1) / DU_EDGES * DU_EDGES;
+  c = p ? (E + p - 1) / p : 1;
+  if (c < 1) c = 1;
+  *chunks = (int)c;
+  *per = p;
+}
+
+}  // namespace tmgcn
+
+using namespace tmgcn;
+
+extern "C" int tmgcn_edge_head_supported(int32_t F, int32_t C) {
+  return (F >= 1 && F <= kMaxF && C >= 1 && C <= kMaxC) ? 1 : 0;
+}
+
+extern "C" int tmgcn_edge_head_fwd_f32(const float* Z, const int64_t* src, const int64_t* dst,
+                                        const float* U, float* out, int64_t E, int32_t F, int32_t C,
+                                        void* stream) {
+  TMGCN_REQUIRE(tmgcn_edge_head_supported(F, C), "edge_head: unsupported widths F=%d C=%d (F <= %d, C <= %d)", F, C,
+                kMaxF, kMaxC);
+  TMGCN_REQUIRE(E >= 0, "edge_head: negative E");
+  if (E == 0) return TMGCN_OK;
+  TMGCN_REQUIRE(Z && src && dst && U && out, "edge_head: null pointer");
+  EdgeArgs a{Z, src, dst, U, out, E, F, C};
+  hipLaunchKernelGGL(edge_head_fwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("edge_head_fwd");
+}
+
+extern "C" int64_t tmgcn_edge_head_bwd_workspace_bytes(int64_t E, int32_t F, int32_t C) {
+  if (E <= 0 || F <= 0 || C <= 0) return 0;
+  int chunks;
+  int64_t per;
+  du_plan(E, &chunks, &per);
+  return (int64_t)chunks * 2 * F * C * (int64_t)sizeof(float);
+}
+
+extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const int64_t* dst,
+                                        const float* U, const float* dout, const int64_t* eptr,
+                                        const int64_t* eidx, float* dZ, float* dU, int64_t R, int64_t E,
+                                        int32_t F, int32_t C, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
+  TMGCN_REQUIRE(tmgcn_edge_head_supported(F, C), "edge_head_bwd: unsupported widths F=%d C=%d", F, C);
+  TMGCN_REQUIRE(R >= 0 && E >= 0, "edge_head_bwd: negative extent");
+  hipStream_t st = (hipStream_t)stream;
+  int chunks;
+  int64_t per;
+  du_plan(E, &chunks, &per);
+  EdgeBwdArgs a{Z, src, dst, U, dout, eptr, eidx, dZ, (float*)workspace, R, E, F, C, chunks, per};
+  if (dZ && R > 0) {
+    TMGCN_REQUIRE(eptr && (E == 0 || (eidx && dout)) && U, "edge_head_bwd: null pointer (dZ)");
+    hipLaunchKernelGGL(edge_head_dz_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, a);
+    int rc = check_launch("edge_head_dz");
+    if (rc) return rc;
+  }
+  if (dU) {
+    if (E == 0) {
+      (void)hipMemsetAsync(dU, 0, (size_t)2 * F * C * sizeof(float), st);
+      return check_launch("edge_head_du memset");
+    }
+    TMGCN_REQUIRE(Z && src && dst && dout, "edge_head_bwd: null pointer (dU)");
+    const int64_t need = (int64_t)chunks * 2 * F * C * (int64_t)sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+      set_error("edge_head_bwd: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
+      return TMGCN_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(edge_head_du_kernel, dim3((unsigned)chunks), dim3(256), 0, st, a);
+    int rc = check_launch("edge_head_du");
+    if (rc) return rc;
+    const int n_out = 2 * F * C;
+    hipLaunchKernelGGL(edge_head_du_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st,
+                       (const float*)workspace, dU, n_out, chunks);
+    return check_launch("edge_head_du_reduce");
+  }
+  return TMGCN_OK;
+}

@@ -276,11 +276,11 @@ __global__ __launch_bounds__(256) void gemm_dw_small_kernel(DwArgs a) {
   if (r1 > b1) r1 = b1;
   const int n_out = a.K * a.Nf;
   constexpr int OMAX = 4;  // n_out <= 1024
-  float acc[OMAX];
+  double acc[OMAX];  // fp64 running sums: free at these sizes, and keeps 10^5-10^6-row reductions exact to fp32
   int ok_[OMAX], on_[OMAX];
 #pragma unroll
   for (int o = 0; o < OMAX; ++o) {
-    acc[o] = 0.f;
+    acc[o] = 0.0;
     const int idx = threadIdx.x + o * 256;
     ok_[o] = idx < n_out ? idx / a.Nf : -1;
     on_[o] = idx < n_out ? idx % a.Nf : 0;
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) void gemm_dw_small_kernel(DwArgs a) {
 #pragma unroll
     for (int o = 0; o < OMAX; ++o) {
       if (ok_[o] >= 0) {
-        float s = acc[o];
-        for (int i = 0; i < nr; ++i) s = fmaf(sa[i * a.K + ok_[o]], sd[i * a.Nf + on_[o]], s);
+        double s = acc[o];
+        for (int i = 0; i < nr; ++i) s += (double)sa[i * a.K + ok_[o]] * (double)sd[i * a.Nf + on_[o]];
         acc[o] = s;
       }
     }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm_dw_small_kernel(DwArgs a) {
   float* P = a.part + ((int64_t)blockIdx.x) * n_out;
 #pragma unroll
   for (int o = 0; o < OMAX; ++o)
-    if (ok_[o] >= 0) P[threadIdx.x + o * 256] = acc[o];
+    if (ok_[o] >= 0) P[threadIdx.x + o * 256] = (float)acc[o];
 }
 
 // dW[b][o] = sum over chunks (ascending) of part[b][chunk][o]
@@ -313,9 +313,9 @@ __global__ void gemm_dw_reduce_kernel(const float* __restrict__ part, float* __r
   if (idx >= total) return;
   const int64_t b = idx / n_out, o = idx % n_out;
   const float* p = part + b * chunks * n_out + o;
-  float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += p[(int64_t)c * n_out];
-  dW[idx] = s;
+  double s = 0.0;
+  for (int c = 0; c < chunks; ++c) s += (double)p[(int64_t)c * n_out];
+  dW[idx] = (float)s;
 }
 
 static bool use_small(int K, int Nf) { return (K < 16 || Nf < 16) && K <= 64 && Nf <= 64; }

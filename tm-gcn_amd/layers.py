@@ -58,29 +58,35 @@ def _is_recompute_call(At, X, edges) -> bool:
     return (type(At) == list or isinstance(At, BatchedCSR)) and type(X) == torch.Tensor and type(edges) == torch.Tensor
 
 
-class _EdgeIndex:
-    """Flat row indices t*N+node of every labelled edge (ehf:196-198)."""
-
-    def __init__(self, edges: torch.Tensor, N: int, device):
-        e = edges.detach().to(device=device, dtype=torch.int64)
-        self.src = (e[0] * N + e[1]).contiguous()
-        self.dst = (e[0] * N + e[2]).contiguous()
+_EdgeIndex = ops.EdgeIndex
 
 
-def _edge_head(Z: torch.Tensor, idx: _EdgeIndex, U: torch.Tensor) -> torch.Tensor:
-    # ehf:228-232 / 351-355 / 491-495 (P4: stock torch-ROCm gather + matmul for now)
-    Zf = Z.reshape(-1, Z.shape[-1])
-    return torch.matmul(torch.cat((Zf[idx.src], Zf[idx.dst]), dim=1), U)
+def _edge_head(Z: torch.Tensor, idx, U: torch.Tensor) -> torch.Tensor:
+    # ehf:228-232 / 351-355 / 491-495 (P4)
+    return ops.edge_head(Z, idx, U)
 
 
 _NONLIN = ("relu", "leaky", "selu")
+
+
+def _param(t: torch.Tensor, dev, dtype) -> nn.Parameter:
+    """A parameter drawn on the CPU generator (reference order/values), stored on the device in
+    `dtype` (fp32, or bf16 for the "bf16 weights" config)."""
+    return nn.Parameter(t.to(device=dev, dtype=dtype))
+
+
+def _w(p: torch.Tensor) -> torch.Tensor:
+    """Parameters enter the kernels in fp32 (a bf16 parameter is widened; its gradient is
+    rounded back to bf16 by autograd)."""
+    return p if p.dtype == torch.float32 else p.float()
 
 
 class EmbeddingGCN(nn.Module):
     """1-layer TM-GCN (ehf:156-234)."""
 
     def __init__(self, At: AdjLike, X: torch.Tensor, edges: torch.Tensor, M: torch.Tensor,
-                 hidden_feat=[2, 2], condensed_W=False, use_Minv=True, device=None):
+                 hidden_feat=[2, 2], condensed_W=False, use_Minv=True, device=None,
+                 param_dtype=torch.float32):
         super().__init__()
         dev = torch.device(device) if device is not None else _default_device()
         self.use_Minv = use_Minv
@@ -92,8 +98,8 @@ class EmbeddingGCN(nn.Module):
         if use_Minv:
             self.Minv = self.Mop.inverse()
         w_shape = (self.F[0], self.F[1]) if condensed_W else (self.T, self.F[0], self.F[1])
-        self.W = nn.Parameter(torch.randn(*w_shape).to(dev))           # ehf:189/191
-        self.U = nn.Parameter(torch.randn(2 * self.F[1], self.F[2]).to(dev))  # ehf:192
+        self.W = _param(torch.randn(*w_shape), dev, param_dtype)                      # ehf:189/191
+        self.U = _param(torch.randn(2 * self.F[1], self.F[2]), dev, param_dtype)     # ehf:192
         self.AtXt = self.compute_AtXt(_adj(At, self.N, dev), _feat(X, dev))   # ehf:195
         self._edges = _EdgeIndex(edges, self.N, dev)
         self.dev = dev
@@ -108,10 +114,10 @@ class EmbeddingGCN(nn.Module):
             eidx = _EdgeIndex(edges, self.N, self.dev)
         else:
             AtXt, eidx = self.AtXt, self._edges
-        Y = ops.feature_gemm(AtXt, self.W)                                   # ehf:222
+        Y = ops.feature_gemm(AtXt, _w(self.W))                               # ehf:222
         if self.use_Minv:
             Y = ops.m_transform(Y, self.Minv)                                # ehf:224
-        return _edge_head(Y, eidx, self.U)
+        return _edge_head(Y, eidx, _w(self.U))
 
 
 class EmbeddingGCN2(nn.Module):
@@ -119,7 +125,7 @@ class EmbeddingGCN2(nn.Module):
 
     def __init__(self, At: AdjLike, X: torch.Tensor, edges: torch.Tensor, M: torch.Tensor,
                  hidden_feat=[2, 2, 2], condensed_W=False, use_Minv=True, apply_M_twice=False,
-                 apply_M_three_times=False, nonlin2="relu", device=None):
+                 apply_M_three_times=False, nonlin2="relu", device=None, param_dtype=torch.float32):
         super().__init__()
         dev = torch.device(device) if device is not None else _default_device()
         if nonlin2 not in _NONLIN:
@@ -136,9 +142,9 @@ class EmbeddingGCN2(nn.Module):
         if use_Minv:
             self.Minv = self.Mop.inverse()
         lead = () if condensed_W else (self.T,)
-        self.W1 = nn.Parameter(torch.randn(*lead, self.F[0], self.F[1]).to(dev))  # ehf:278/281
-        self.W2 = nn.Parameter(torch.randn(*lead, self.F[1], self.F[2]).to(dev))  # ehf:279/282
-        self.U = nn.Parameter(torch.randn(self.F[2] * 2, self.F[3]).to(dev))      # ehf:283
+        self.W1 = _param(torch.randn(*lead, self.F[0], self.F[1]), dev, param_dtype)  # ehf:278/281
+        self.W2 = _param(torch.randn(*lead, self.F[1], self.F[2]), dev, param_dtype)  # ehf:279/282
+        self.U = _param(torch.randn(self.F[2] * 2, self.F[3]), dev, param_dtype)      # ehf:283
         self.At = _adj(At, self.N, dev)                                            # ehf:267
         self.AtXt = self.compute_AtXt(self.At, _feat(X, dev))                      # ehf:293
         self._edges = _EdgeIndex(edges, self.N, dev)
@@ -158,28 +164,29 @@ class EmbeddingGCN2(nn.Module):
             eidx = _EdgeIndex(edges, self.N, self.dev)
         else:
             AtXt, eidx = self.AtXt, self._edges
+        W1, W2, U = _w(self.W1), _w(self.W2), _w(self.U)
         # first layer (ehf:330-335)
         if self.use_Minv:
-            Y = ops.activation(ops.m_transform(ops.feature_gemm(AtXt, self.W1), self.Minv), self.nonlin2)
+            Y = ops.activation(ops.m_transform(ops.feature_gemm(AtXt, W1), self.Minv), self.nonlin2)
         else:
-            Y = ops.feature_gemm(AtXt, self.W1, act=self.nonlin2)
+            Y = ops.feature_gemm(AtXt, W1, act=self.nonlin2)
         # second layer — always the training adjacency self.At (ehf:339, 343, 348)
         if self.use_Minv:
-            Z = ops.m_transform(ops.spmm_feature_gemm(self.At, ops.m_transform(Y, self.Mop), self.W2), self.Minv)
+            Z = ops.m_transform(ops.spmm_feature_gemm(self.At, ops.m_transform(Y, self.Mop), W2), self.Minv)
         elif self.apply_M_twice:
-            Z = ops.spmm_feature_gemm(self.At, ops.m_transform(Y, self.Mop), self.W2)
+            Z = ops.spmm_feature_gemm(self.At, ops.m_transform(Y, self.Mop), W2)
             if self.apply_M_three_times:
                 Z = ops.m_transform(Z, self.Mop)                                   # ehf:346
         else:
-            Z = ops.spmm_feature_gemm(self.At, Y, self.W2)                         # ehf:348-349
-        return _edge_head(Z, eidx, self.U)
+            Z = ops.spmm_feature_gemm(self.At, Y, W2)                              # ehf:348-349
+        return _edge_head(Z, eidx, U)
 
 
 class EmbeddingKWGCN(nn.Module):
     """Baseline GCN without the M-product, 1 or 2 layers (ehf:425-497)."""
 
     def __init__(self, A: AdjLike, X: torch.Tensor, edges: torch.Tensor, hidden_feat=[2, 2],
-                 nonlin2="relu", device=None):
+                 nonlin2="relu", device=None, param_dtype=torch.float32):
         super().__init__()
         dev = torch.device(device) if device is not None else _default_device()
         if nonlin2 not in _NONLIN:
@@ -189,9 +196,9 @@ class EmbeddingKWGCN(nn.Module):
         self.T, self.N = int(X.shape[0]), int(X.shape[1])
         self.F = [int(X.shape[-1])] + list(hidden_feat)
         if self.no_layers == 2:
-            self.W2 = nn.Parameter(torch.randn(self.F[1], self.F[2]).to(dev))     # ehf:452 (drawn first)
-        self.W1 = nn.Parameter(torch.randn(self.F[0], self.F[1]).to(dev))         # ehf:453
-        self.U = nn.Parameter(torch.randn(self.F[-2] * 2, self.F[-1]).to(dev))    # ehf:454
+            self.W2 = _param(torch.randn(self.F[1], self.F[2]), dev, param_dtype)     # ehf:452 (drawn first)
+        self.W1 = _param(torch.randn(self.F[0], self.F[1]), dev, param_dtype)         # ehf:453
+        self.U = _param(torch.randn(self.F[-2] * 2, self.F[-1]), dev, param_dtype)    # ehf:454
         self.A = _adj(A, self.N, dev)
         if self.A.T != self.T:
             raise RuntimeError(f"adjacency has {self.A.T} slices but X has T={self.T}")
@@ -210,8 +217,8 @@ class EmbeddingKWGCN(nn.Module):
         else:
             AX, eidx = self.AX, self._edges
         if self.no_layers == 2:
-            Y = ops.feature_gemm(AX, self.W1, act=self.nonlin2)                    # ehf:486
-            Z = ops.spmm_feature_gemm(self.A, Y, self.W2)                          # ehf:487
+            Y = ops.feature_gemm(AX, _w(self.W1), act=self.nonlin2)                # ehf:486
+            Z = ops.spmm_feature_gemm(self.A, Y, _w(self.W2))                      # ehf:487
         else:
-            Z = ops.feature_gemm(AX, self.W1)                                      # ehf:489
-        return _edge_head(Z, eidx, self.U)
+            Z = ops.feature_gemm(AX, _w(self.W1))                                  # ehf:489
+        return _edge_head(Z, eidx, _w(self.U))

@@ -43,6 +43,33 @@ def _want(t: torch.Tensor, name: str, dtype=torch.float32):
     return t
 
 
+class EdgeIndex:
+    """Flat row indices t*N+node of every labelled edge (ehf:196-198), plus — built lazily, once
+    per edge set — the inverted index the atomic-free head backward walks."""
+
+    def __init__(self, edges: torch.Tensor, N: int, device):
+        e = edges.detach().to(device=device, dtype=torch.int64)
+        self.src = (e[0] * N + e[1]).contiguous()
+        self.dst = (e[0] * N + e[2]).contiguous()
+        self.E = int(self.src.numel())
+        self._inv = None
+
+    def inverted(self, R: int):
+        """(eptr[R+1], eidx[2E]): entries of row r = 2*edge + role, ascending (fixed sum order)."""
+        if self._inv is None or self._inv[0] != R:
+            if self.E and (int(self.src.max()) >= R or int(self.dst.max()) >= R or
+                           int(self.src.min()) < 0 or int(self.dst.min()) < 0):
+                raise RuntimeError("edge index out of range for the embedding matrix")
+            ids = torch.arange(self.E, device=self.src.device, dtype=torch.int64) * 2
+            rows = torch.cat((self.src, self.dst))
+            ent = torch.cat((ids, ids + 1))
+            order = torch.sort(rows, stable=True).indices
+            eptr = torch.zeros(R + 1, dtype=torch.int64, device=self.src.device)
+            torch.cumsum(torch.bincount(rows, minlength=R), 0, out=eptr[1:])
+            self._inv = (R, eptr, ent[order].contiguous())
+        return self._inv[1], self._inv[2]
+
+
 class MOperator:
     """The T×T mixing matrix M of the M-product, resident on the device in fp32, with the
     band structure the kernels exploit (read_data.m:116-124 builds a lower band of 20)."""
@@ -220,6 +247,39 @@ class HipKernels:
         _lib.check(rc, "tmgcn_gemm_dw_f32")
         return dW
 
+    # P4 ---------------------------------------------------------------------------------
+    def edge_head_supported(self, F: int, Cn: int) -> bool:
+        return bool(_lib.load().tmgcn_edge_head_supported(F, Cn))
+
+    def edge_head_fwd(self, Z2: torch.Tensor, edges: "EdgeIndex", U: torch.Tensor) -> torch.Tensor:
+        lib = _lib.load()
+        _want(Z2, "edge_head Z")
+        _want(U, "edge_head U")
+        F, Cn = Z2.shape[1], U.shape[1]
+        if U.shape[0] != 2 * F:
+            raise RuntimeError(f"edge_head: U {tuple(U.shape)} does not match F={F}")
+        out = torch.empty(edges.E, Cn, dtype=torch.float32, device=Z2.device)
+        rc = self._run("edge_head", Z2.device, lambda: lib.tmgcn_edge_head_fwd_f32(
+            _ptr(Z2), _ptr(edges.src), _ptr(edges.dst), _ptr(U), _ptr(out), edges.E, F, Cn, _stream(Z2)))
+        _lib.check(rc, "tmgcn_edge_head_fwd_f32")
+        return out
+
+    def edge_head_bwd(self, Z2, edges: "EdgeIndex", U, dout, need_dz=True, need_du=True):
+        lib = _lib.load()
+        _want(dout, "edge_head dout")
+        R, F = Z2.shape
+        Cn = U.shape[1]
+        eptr, eidx = edges.inverted(R)
+        dZ = torch.empty_like(Z2) if need_dz else None
+        dU = torch.empty_like(U) if need_du else None
+        need = int(lib.tmgcn_edge_head_bwd_workspace_bytes(edges.E, F, Cn))
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=Z2.device)
+        rc = self._run("edge_head_bwd", Z2.device, lambda: lib.tmgcn_edge_head_bwd_f32(
+            _ptr(Z2), _ptr(edges.src), _ptr(edges.dst), _ptr(U), _ptr(dout), _ptr(eptr), _ptr(eidx),
+            _ptr(dZ), _ptr(dU), R, edges.E, F, Cn, _ptr(ws), ws.numel(), _stream(Z2)))
+        _lib.check(rc, "tmgcn_edge_head_bwd_f32")
+        return dZ, dU
+
     # P5 ---------------------------------------------------------------------------------
     def act_fwd(self, x: torch.Tensor, act) -> torch.Tensor:
         lib = _lib.load()
@@ -323,6 +383,22 @@ class _SpmmGemm(torch.autograd.Function):
         return dX, dW, None, None
 
 
+class _EdgeHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Z, U, edges):
+        Z2 = Z.reshape(-1, Z.shape[-1])
+        ctx.edges, ctx.zshape = edges, Z.shape
+        ctx.save_for_backward(Z2, U)
+        return kernels.edge_head_fwd(Z2, edges, U)
+
+    @staticmethod
+    def backward(ctx, dout):
+        Z2, U = ctx.saved_tensors
+        dZ, dU = kernels.edge_head_bwd(Z2, ctx.edges, U, dout.contiguous(), ctx.needs_input_grad[0],
+                                       ctx.needs_input_grad[1])
+        return (dZ.reshape(ctx.zshape) if dZ is not None else None), dU, None
+
+
 class _Activation(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act):
@@ -365,6 +441,21 @@ def spmm_feature_gemm(A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, act=None,
     if fuse:
         return _SpmmGemm.apply(X, W, A, act)
     return feature_gemm(spmm(A, X), W, act=act)
+
+
+def edge_head(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, fuse: Optional[bool] = None) -> torch.Tensor:
+    """P4: logits[e] = [Z[src[e]], Z[dst[e]]] · U  (ehf:228-232).  One fused gather-and-dot kernel
+    (atomic-free backward) when F <= 32 and C <= 8, else stock gather + matmul."""
+    F, Cn = Z.shape[-1], U.shape[-1]
+    can = hasattr(kernels, "edge_head_supported") and kernels.edge_head_supported(F, Cn)
+    if fuse is None:
+        fuse = can
+    if fuse and not can:
+        raise RuntimeError(f"fused edge head does not support F={F}, C={Cn}")
+    if fuse:
+        return _EdgeHead.apply(Z.contiguous(), U.contiguous(), edges)
+    Zf = Z.reshape(-1, F)
+    return torch.matmul(torch.cat((Zf[edges.src], Zf[edges.dst]), dim=1), U)
 
 
 def activation(x: torch.Tensor, act) -> torch.Tensor:
