@@ -107,13 +107,18 @@ __global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
   }
 }
 
-// dU slabs: one output element (k, c), k in [0, 2F), per thread slot; edges staged through LDS.
+// dU slabs: edges staged through LDS in tiles of DU_EDGES.  n_out = 2F*C outputs (k, c); with
+// n_out <= 128 the threads form 256/n_out edge groups so every lane works (the real head is
+// 12 x 2 = 24 outputs); fp64 running sums, groups combined through LDS in fixed order.
 constexpr int DU_EDGES = 64;
 __global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
   __shared__ float sz[DU_EDGES * 2 * kMaxF];
   __shared__ float sd[DU_EDGES * kMaxC];
+  __shared__ double red[256];
   const int K = 2 * a.F;
   const int n_out = K * a.C;  // <= 512
+  const int groups = n_out <= 128 ? 256 / n_out : 1;
+  const int grp = groups > 1 ? threadIdx.x / n_out : 0;
   const int64_t e0 = (int64_t)blockIdx.x * a.edges_per_chunk;
   int64_t e1 = e0 + a.edges_per_chunk;
   if (e1 > a.E) e1 = a.E;
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
   int ok_[2], oc_[2];
 #pragma unroll
   for (int o = 0; o < 2; ++o) {
-    const int idx = threadIdx.x + o * 256;
+    const int idx = groups > 1 ? (o == 0 && grp < groups ? (int)(threadIdx.x % n_out) : n_out) : threadIdx.x + o * 256;
     ok_[o] = idx < n_out ? idx / a.C : -1;
     oc_[o] = idx < n_out ? idx % a.C : 0;
   }
@@ -139,27 +144,42 @@ __global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
     for (int o = 0; o < 2; ++o)
       if (ok_[o] >= 0) {
         double s = acc[o];
-        for (int i = 0; i < ne; ++i) s += (double)sz[i * K + ok_[o]] * (double)sd[i * a.C + oc_[o]];
+        for (int i = grp; i < ne; i += groups) s += (double)sz[i * K + ok_[o]] * (double)sd[i * a.C + oc_[o]];
         acc[o] = s;
       }
   }
   float* P = a.part + (int64_t)blockIdx.x * n_out;
+  if (groups > 1) {
+    __syncthreads();
+    red[threadIdx.x] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < n_out) {
+      double s = 0.0;
+      for (int g = 0; g < groups; ++g) s += red[g * n_out + threadIdx.x];
+      P[threadIdx.x] = (float)s;
+    }
+  } else {
 #pragma unroll
-  for (int o = 0; o < 2; ++o)
-    if (ok_[o] >= 0) P[threadIdx.x + o * 256] = (float)acc[o];
+    for (int o = 0; o < 2; ++o)
+      if (ok_[o] >= 0) P[threadIdx.x + o * 256] = (float)acc[o];
+  }
 }
 
-__global__ void edge_head_du_reduce_kernel(const float* __restrict__ part, float* __restrict__ dU,
-                                           int n_out, int chunks) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= n_out) return;
+// one wave per output element: lanes stride over the chunk slabs, fixed butterfly
+__global__ __launch_bounds__(256) void edge_head_du_reduce_kernel(const float* __restrict__ part,
+                                                                   float* __restrict__ dU, int n_out, int chunks) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= n_out) return;  // whole wave
   double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += (double)part[(int64_t)c * n_out + o];
-  dU[o] = (float)s;
+  for (int c = lane; c < chunks; c += kWave) s += (double)part[(int64_t)c * n_out + o];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) dU[o] = (float)s;
 }
 
 static void du_plan(int64_t E, int* chunks, int64_t* per) {
-  int64_t c = (E + 4095) / 4096;
+  int64_t c = (E + 255) / 256;  // >= 256 edges per chunk, <= 2048 slabs
   if (c > 2048) c = 2048;
   if (c < 1) c = 1;
   int64_t p = (E + c - 1) / c;
@@ -232,7 +252,7 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
     int rc = check_launch("edge_head_du");
     if (rc) return rc;
     const int n_out = 2 * F * C;
-    hipLaunchKernelGGL(edge_head_du_reduce_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st,
+    hipLaunchKernelGGL(edge_head_du_reduce_kernel, dim3((n_out + 3) / 4), dim3(256), 0, st,
                        (const float*)workspace, dU, n_out, chunks);
     return check_launch("edge_head_du_reduce");
   }

@@ -260,10 +260,14 @@ __global__ __launch_bounds__(256) void gemm_dw_mfma_kernel(DwArgs a) {
   }
 }
 
-// small dW: one output element per thread-slot, rows staged through LDS.
+// small dW: rows staged through LDS in tiles of DW_ROWS.  With few outputs (K*Nf <= 128, the
+// reference's 2x6 / 6x6) the 256 threads form 256/(K*Nf) row groups that each take every g-th row
+// of the tile, so all lanes work; with more outputs each thread owns up to 4 output elements.
+// fp64 running sums (free at these sizes), groups combined through LDS in fixed order.
 constexpr int DW_ROWS = 64;
 __global__ __launch_bounds__(256) void gemm_dw_small_kernel(DwArgs a) {
   extern __shared__ float sm[];  // [DW_ROWS][K] then [DW_ROWS][Nf]
+  __shared__ double red[256];
   float* sa = sm;
   float* sd = sm + DW_ROWS * a.K;
   const int64_t batch = blockIdx.x / a.chunks;
@@ -275,13 +279,15 @@ __global__ __launch_bounds__(256) void gemm_dw_small_kernel(DwArgs a) {
   int64_t r1 = r0 + a.rows_per_chunk;
   if (r1 > b1) r1 = b1;
   const int n_out = a.K * a.Nf;
-  constexpr int OMAX = 4;  // n_out <= 1024
-  double acc[OMAX];  // fp64 running sums: free at these sizes, and keeps 10^5-10^6-row reductions exact to fp32
+  const int groups = n_out <= 128 ? 256 / n_out : 1;   // row groups (few outputs)
+  const int grp = groups > 1 ? threadIdx.x / n_out : 0;
+  constexpr int OMAX = 4;                                // output slots per thread (many outputs)
+  double acc[OMAX];
   int ok_[OMAX], on_[OMAX];
 #pragma unroll
   for (int o = 0; o < OMAX; ++o) {
     acc[o] = 0.0;
-    const int idx = threadIdx.x + o * 256;
+    int idx = groups > 1 ? (o == 0 && grp < groups ? (int)(threadIdx.x % n_out) : n_out) : threadIdx.x + o * 256;
     ok_[o] = idx < n_out ? idx / a.Nf : -1;
     on_[o] = idx < n_out ? idx % a.Nf : 0;
   }
@@ -295,27 +301,41 @@ __global__ __launch_bounds__(256) void gemm_dw_small_kernel(DwArgs a) {
     for (int o = 0; o < OMAX; ++o) {
       if (ok_[o] >= 0) {
         double s = acc[o];
-        for (int i = 0; i < nr; ++i) s += (double)sa[i * a.K + ok_[o]] * (double)sd[i * a.Nf + on_[o]];
+        for (int i = grp; i < nr; i += groups) s += (double)sa[i * a.K + ok_[o]] * (double)sd[i * a.Nf + on_[o]];
         acc[o] = s;
       }
     }
   }
   float* P = a.part + ((int64_t)blockIdx.x) * n_out;
+  if (groups > 1) {
+    __syncthreads();
+    red[threadIdx.x] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < n_out) {
+      double s = 0.0;
+      for (int g = 0; g < groups; ++g) s += red[g * n_out + threadIdx.x];
+      P[threadIdx.x] = (float)s;
+    }
+  } else {
 #pragma unroll
-  for (int o = 0; o < OMAX; ++o)
-    if (ok_[o] >= 0) P[threadIdx.x + o * 256] = (float)acc[o];
+    for (int o = 0; o < OMAX; ++o)
+      if (ok_[o] >= 0) P[threadIdx.x + o * 256] = (float)acc[o];
+  }
 }
 
-// dW[b][o] = sum over chunks (ascending) of part[b][chunk][o]
-__global__ void gemm_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
-                                      int64_t n_out, int32_t chunks, int64_t total) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+// dW[b][o] = sum over chunks (ascending lanes, fixed butterfly) of part[b][chunk][o]: one wave per output
+__global__ __launch_bounds__(256) void gemm_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
+                                                              int64_t n_out, int32_t chunks, int64_t total) {
+  const int lane = threadIdx.x & 63;
+  const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (idx >= total) return;  // whole wave
   const int64_t b = idx / n_out, o = idx % n_out;
   const float* p = part + b * chunks * n_out + o;
   double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += (double)p[(int64_t)c * n_out];
-  dW[idx] = (float)s;
+  for (int c = lane; c < chunks; c += kWave) s += (double)p[(int64_t)c * n_out];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) dW[idx] = (float)s;
 }
 
 static bool use_small(int K, int Nf) { return (K < 16 || Nf < 16) && K <= 64 && Nf <= 64; }
@@ -324,7 +344,7 @@ static void dw_plan(int64_t R, int64_t rows_per_batch, int64_t* n_batch, int* ch
                     int64_t* rows_per_chunk) {
   const int64_t br = rows_per_batch ? rows_per_batch : R;
   const int64_t nb = br ? (R + br - 1) / br : 1;
-  int64_t c = (br + 2047) / 2048;  // >= 2048 rows per chunk
+  int64_t c = (br + 511) / 512;  // >= 512 rows per chunk
   int64_t cmax = 2048 / (nb > 0 ? nb : 1);
   if (cmax < 1) cmax = 1;
   if (c > cmax) c = cmax;
@@ -417,7 +437,7 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
   if (rc) return rc;
   const int64_t n_out = (int64_t)K * Nf;
   const int64_t total = nb * n_out;
-  hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st,
                      (const float*)workspace, dW, n_out, chunks, total);
   return check_launch("gemm_dw_reduce");
 }
