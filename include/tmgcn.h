@@ -158,6 +158,45 @@ int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const int64_t* d
                             float* dZ, float* dU, int64_t R, int64_t E, int32_t F, int32_t C,
                             void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- adjacency pipeline on the device ----------------------------------
+ * Replaces the reference's offline preprocessing loops: read_data.py:88-111 (symmetrise),
+ * :116-125 (edge-life window), :130-169 (add I, D^-1/2 · D^-1/2), :204-223 (sparse M-product),
+ * MATLAB read_data.m:172-209, and the list-of-COO ingest ehf:560-574.
+ * A batched COO is (key, val) with ONE 64-bit key per entry:  key = (slice*N + row)*N + col.
+ * Each step either fans entries out ("expand": output arrays sized n * fan-out by the caller;
+ * unused slots carry the sentinel key ~0 and value 0) or is elementwise; tmgcn_coo_sort_reduce
+ * sorts by key and sums equal keys in sorted order (reproducible).  A sentinel run, if any, ends
+ * up as the LAST reduced entry (key ~0): the caller drops it.
+ */
+int tmgcn_adj_make_keys(const int64_t* slice, const int64_t* row, const int64_t* col, int64_t n,
+                        int64_t N, uint64_t* key, void* stream);
+int64_t tmgcn_coo_sort_reduce_workspace_bytes(int64_t n);
+int tmgcn_coo_sort_reduce(const uint64_t* keys_in, const float* vals_in, int64_t n, int32_t key_bits,
+                          uint64_t* keys_out, float* vals_out, int64_t* n_out_dev,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+/* out: 2n entries — (t,i,j,v/2) and (t,j,i,v/2) */
+int tmgcn_adj_symmetrise(const uint64_t* key, const float* val, int64_t n, int64_t N,
+                         uint64_t* okey, float* oval, void* stream);
+/* out: n*window entries — the entry of slice t repeated in slices t .. t+window-1 (< T) */
+int tmgcn_adj_edge_life(const uint64_t* key, const float* val, int64_t n, int64_t N, int32_t T,
+                        int32_t window, uint64_t* okey, float* oval, void* stream);
+/* out: TN entries (t,i,i,1) */
+int tmgcn_adj_identity(int64_t TN, int64_t N, uint64_t* okey, float* oval, void* stream);
+/* in place on a sorted, reduced COO: val *= d[row]*d[col], d = 1/sqrt(row sum); also returns
+ * rowptr[TN+1] and dinv[TN] */
+int tmgcn_adj_normalise(const uint64_t* key, float* val, int64_t n, int64_t N, int64_t TN,
+                        int64_t* rowptr, float* dinv, void* stream);
+/* out: n*(band_lo+band_hi+1) entries — (k,r,c, M[k][j]*v) for the rows k of column j inside the band */
+int tmgcn_adj_mproduct_expand(const uint64_t* key, const float* val, int64_t n, int64_t N, int32_t T,
+                              const float* M, int32_t ldm, int32_t band_lo, int32_t band_hi,
+                              uint64_t* okey, float* oval, void* stream);
+/* sorted keys -> rowptr[TN+1] (binary search of r*N) and col[n] (key mod N) */
+int tmgcn_adj_keys_to_csr(const uint64_t* key, int64_t n, int64_t N, int64_t TN, int64_t* rowptr,
+                          int32_t* col, void* stream);
+/* keys (slice, col, row) of every entry of a batched CSR: sort them to get the per-slice transpose */
+int tmgcn_adj_transpose_keys(const int64_t* rowptr, const int32_t* col, int64_t TN, int64_t N,
+                             uint64_t* okey, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

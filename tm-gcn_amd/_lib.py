@@ -38,6 +38,16 @@ SIGNATURES = {
     "tmgcn_edge_head_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_edge_head_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "tmgcn_edge_head_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i64, _p]),
+    "tmgcn_adj_make_keys": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
+    "tmgcn_coo_sort_reduce_workspace_bytes": (_i64, [_i64]),
+    "tmgcn_coo_sort_reduce": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),
+    "tmgcn_adj_symmetrise": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p]),
+    "tmgcn_adj_edge_life": (C.c_int, [_p, _p, _i64, _i64, _i32, _i32, _p, _p, _p]),
+    "tmgcn_adj_identity": (C.c_int, [_i64, _i64, _p, _p, _p]),
+    "tmgcn_adj_normalise": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
+    "tmgcn_adj_mproduct_expand": (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _i32, _i32, _i32, _p, _p, _p]),
+    "tmgcn_adj_keys_to_csr": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p]),
+    "tmgcn_adj_transpose_keys": (C.c_int, [_p, _p, _i64, _i64, _p, _p]),
     "tmgcn_act_fwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p]),
     "tmgcn_act_bwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _p]),
 }

@@ -9,9 +9,11 @@ CSR so that a single kernel launch covers the whole tensor:
     col     int32 [nnz]       column inside the slice, 0..N-1
     val     fp32  [nnz]
 
-Duplicates in the COO input are kept as separate entries (their products are summed by the
-SpMM exactly as ``sparse.mm`` sums uncoalesced entries).  Within a row, entries are ordered
-by column, ties in input order, so every row sum has a fixed order.
+Ingest on a ROCm device goes through the native sort/reduce of csrc/adjacency.hip (rocPRIM
+radix sort on 64-bit (slice,row,col) keys; duplicate entries are summed, which is what
+``sparse.mm`` does with uncoalesced COO).  On the CPU (oracle/tests only) the same layout is
+built with torch ops and duplicates are kept as separate entries.  Within a row, entries are
+ordered by column, so every row sum has a fixed order.
 """
 from __future__ import annotations
 
@@ -53,7 +55,11 @@ class BatchedCSR:
     @staticmethod
     def from_coo(slice_idx, row, col, val, T: int, N: int, device=None) -> "BatchedCSR":
         """Build from one batched COO (any order).  Index tensors are integer, val any float."""
+        val = torch.as_tensor(val)
         device = torch.device(device) if device is not None else val.device
+        if device.type == "cuda":
+            from .adjacency import DeviceCOO  # native path: no torch compute ops
+            return DeviceCOO.from_edges(slice_idx, row, col, val, T, N, device).sort_reduce().to_csr()
         slice_idx = torch.as_tensor(slice_idx).to(device=device, dtype=torch.int64)
         row = torch.as_tensor(row).to(device=device, dtype=torch.int64)
         col = torch.as_tensor(col).to(device=device, dtype=torch.int64)
@@ -136,6 +142,11 @@ class BatchedCSR:
         Built slice by slice (one stable sort of nnz_k keys each) so the peak scratch is a few
         times one slice, not the whole tensor; inside a transposed row the entries keep the
         order of the original rows, so the backward sums are reproducible too."""
+        if self._t is None and self.device.type == "cuda":
+            from .adjacency import csr_transpose  # native sort of the transposed keys
+            t = csr_transpose(self)
+            t._t = self
+            self._t = t
         if self._t is None:
             N, T, dev = self.N, self.T, self.device
             counts = torch.zeros(T * N, dtype=torch.int64, device=dev)

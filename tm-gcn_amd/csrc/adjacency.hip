@@ -1,0 +1,303 @@
+// Adjacency pipeline on the device: raw dynamic-graph edges -> normalised, M-transformed
+// batched CSR   (gfx950 / CDNA4)
+//
+// Replaces the offline preprocessing the reference does with per-slice / per-nnz Python loops
+// (minutes): read_data.py:88-111 func_make_symmetric, :116-125 func_edge_life, :130-169
+// func_laplacian_transformation, :204-223 func_MProduct (MATLAB: read_data.m:172-209), and the
+// COO ingest of ehf:560-574.
+//
+// Every step is the same primitive on a batched COO whose entries carry ONE 64-bit key
+//      key = (slice * N + row) * N + col
+//   expand   each entry fans out to a few entries (transpose copy / later slices of the edge-life
+//            window / the slices k with M[k, j] != 0), one thread per output entry
+//   sort     rocPRIM radix sort of (key, value) pairs
+//   reduce   entries with equal keys are summed in sorted order (fixed order: reproducible)
+// followed by elementwise normalisation with the row sums.  Keys double as CSR: rowptr is a
+// binary search of r*N in the sorted keys, col = key mod N.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce_by_key.hpp>
+#include <rocprim/functional.hpp>
+
+#include "common.h"
+
+namespace tmgcn {
+
+// ---- expand kernels ---------------------------------------------------------------------
+// symmetrise: out[2p] = (t,i,j, v/2), out[2p+1] = (t,j,i, v/2)         (read_data.py:97-99)
+__global__ void adj_symmetrise_kernel(const uint64_t* __restrict__ key, const float* __restrict__ val,
+                                      int64_t n, int64_t N, uint64_t* __restrict__ okey,
+                                      float* __restrict__ oval) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint64_t k = key[p];
+  const uint64_t col = k % N, tr = k / N;   // tr = slice*N + row
+  const uint64_t row = tr % N, t = tr / N;
+  const float v = 0.5f * val[p];
+  okey[2 * p] = k;
+  oval[2 * p] = v;
+  okey[2 * p + 1] = (t * N + col) * N + row;
+  oval[2 * p + 1] = v;
+}
+
+// edge life: entry of slice t also lives in slices t+1 .. t+L-1 (< T)   (read_data.py:116-125)
+// out has n*L slots; slots past the last slice get the sentinel key ~0 and value 0
+__global__ void adj_edge_life_kernel(const uint64_t* __restrict__ key, const float* __restrict__ val,
+                                     int64_t n, int64_t N, int32_t T, int32_t L,
+                                     uint64_t* __restrict__ okey, float* __restrict__ oval) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n * L) return;
+  const int64_t p = q / L;
+  const int s = (int)(q % L);
+  const uint64_t k = key[p];
+  const uint64_t nn = (uint64_t)N * N;
+  const uint64_t t = k / nn;
+  if (t + s < (uint64_t)T) {
+    okey[q] = k + (uint64_t)s * nn;
+    oval[q] = val[p];
+  } else {
+    okey[q] = ~0ull;
+    oval[q] = 0.f;
+  }
+}
+
+// identity entries (t, i, i, 1) for every slice and node, appended at okey[0 .. T*N)
+__global__ void adj_identity_kernel(int64_t TN, int64_t N, uint64_t* __restrict__ okey,
+                                    float* __restrict__ oval) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= TN) return;
+  okey[r] = (uint64_t)r * N + (uint64_t)(r % N);
+  oval[r] = 1.f;
+}
+
+// row sums of a sorted COO -> d[r] = 1/sqrt(sum)          (read_data.py:146-147)
+__global__ void adj_rowsum_kernel(const uint64_t* __restrict__ key, const float* __restrict__ val,
+                                  const int64_t* __restrict__ rowptr, int64_t TN,
+                                  float* __restrict__ dinv) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= TN) return;
+  double s = 0.0;
+  for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) s += (double)val[p];
+  dinv[r] = s > 0.0 ? (float)(1.0 / sqrt(s)) : 0.f;
+}
+
+// v *= d[slice*N+row] * d[slice*N+col]                     (read_data.py:157-159)
+__global__ void adj_scale_kernel(const uint64_t* __restrict__ key, float* __restrict__ val, int64_t n,
+                                 int64_t N, const float* __restrict__ dinv) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint64_t k = key[p];
+  const uint64_t tr = k / N, col = k % N;
+  const uint64_t t = tr / N;
+  val[p] = (float)((double)val[p] * (double)dinv[tr] * (double)dinv[t * N + col]);
+}
+
+// M-product: entry (j, r, c, v) fans out to (k, r, c, M[k][j]*v) for the W slices k = j + koff[s],
+// s = 0..W-1, where the band of M (lower lo, upper hi) bounds the non-zeros of column j
+// (read_data.py:204-223).  Slots with k outside [0,T) or M[k][j] == 0 get the sentinel.
+__global__ void adj_mproduct_kernel(const uint64_t* __restrict__ key, const float* __restrict__ val,
+                                    int64_t n, int64_t N, int32_t T, const float* __restrict__ M,
+                                    int32_t ldm, int32_t lo, int32_t hi,
+                                    uint64_t* __restrict__ okey, float* __restrict__ oval) {
+  const int W = lo + hi + 1;
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n * W) return;
+  const int64_t p = q / W;
+  const int s = (int)(q % W);
+  const uint64_t k0 = key[p];
+  const uint64_t nn = (uint64_t)N * N;
+  const int64_t j = (int64_t)(k0 / nn);
+  const int64_t k = j - hi + s;  // rows k of M with M[k][j] possibly non-zero: j-hi .. j+lo
+  float m = 0.f;
+  if (k >= 0 && k < T) m = M[k * ldm + j];
+  if (m != 0.f) {
+    okey[q] = k0 + (uint64_t)(k - j) * nn;
+    oval[q] = m * val[p];
+  } else {
+    okey[q] = ~0ull;
+    oval[q] = 0.f;
+  }
+}
+
+// ---- CSR views of sorted keys ----------------------------------------------------------------
+__global__ void adj_rowptr_kernel(const uint64_t* __restrict__ key, int64_t n, int64_t N, int64_t TN,
+                                  int64_t* __restrict__ rowptr) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > TN) return;
+  const uint64_t target = (uint64_t)r * N;  // first key of row r
+  int64_t a = 0, b = n;
+  while (a < b) {
+    const int64_t m = (a + b) >> 1;
+    if (key[m] < target) a = m + 1; else b = m;
+  }
+  rowptr[r] = a;
+}
+
+__global__ void adj_cols_kernel(const uint64_t* __restrict__ key, int64_t n, int64_t N,
+                                int32_t* __restrict__ col) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  col[p] = (int32_t)(key[p] % N);
+}
+
+__global__ void adj_make_keys_kernel(const int64_t* __restrict__ t, const int64_t* __restrict__ i,
+                                     const int64_t* __restrict__ j, int64_t n, int64_t N,
+                                     uint64_t* __restrict__ key) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  key[p] = ((uint64_t)t[p] * N + (uint64_t)i[p]) * N + (uint64_t)j[p];
+}
+
+// transposed key of a CSR entry: (slice, col, row)
+__global__ void adj_transpose_keys_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                          int64_t TN, int64_t N, uint64_t* __restrict__ okey) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= TN) return;
+  const uint64_t t = r / N, i = r % N;
+  for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) okey[p] = (t * N + (uint64_t)col[p]) * N + i;
+}
+
+static inline unsigned blocks(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace tmgcn
+
+using namespace tmgcn;
+
+// ---- sort + reduce (rocPRIM) ------------------------------------------------------------------
+// Sorts (key, val) pairs by key and sums runs of equal keys.  Entries with the sentinel key ~0
+// are dropped.  Outputs: keys_out/vals_out (capacity n), *n_out_dev (device int64).
+// Workspace layout: [keys_sorted n*8][vals_sorted n*4][count 8][rocprim temp].
+extern "C" int64_t tmgcn_coo_sort_reduce_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  size_t t1 = 0, t2 = 0;
+  uint64_t* k = nullptr;
+  float* v = nullptr;
+  int64_t* c = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, t1, k, k, v, v, (size_t)n, 0, 64, (hipStream_t)0);
+  (void)rocprim::reduce_by_key(nullptr, t2, k, v, (size_t)n, k, v, c, rocprim::plus<float>(),
+                               rocprim::equal_to<uint64_t>(), (hipStream_t)0);
+  const size_t tmp = t1 > t2 ? t1 : t2;
+  return (int64_t)(align256((size_t)n * 8) + align256((size_t)n * 4) + 256 + align256(tmp));
+}
+
+extern "C" int tmgcn_coo_sort_reduce(const uint64_t* keys_in, const float* vals_in, int64_t n,
+                                      int32_t key_bits, uint64_t* keys_out, float* vals_out,
+                                      int64_t* n_out_dev, void* workspace, int64_t workspace_bytes,
+                                      void* stream) {
+  TMGCN_REQUIRE(n >= 0, "coo_sort_reduce: negative n");
+  hipStream_t st = (hipStream_t)stream;
+  TMGCN_REQUIRE(n_out_dev, "coo_sort_reduce: null n_out");
+  if (n == 0) {
+    (void)hipMemsetAsync(n_out_dev, 0, sizeof(int64_t), st);
+    return check_launch("coo_sort_reduce memset");
+  }
+  TMGCN_REQUIRE(keys_in && vals_in && keys_out && vals_out && workspace, "coo_sort_reduce: null pointer");
+  const int64_t need = tmgcn_coo_sort_reduce_workspace_bytes(n);
+  if (workspace_bytes < need) {
+    set_error("coo_sort_reduce: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
+    return TMGCN_ERR_WORKSPACE;
+  }
+  char* w = (char*)workspace;
+  uint64_t* ks = (uint64_t*)w;
+  w += align256((size_t)n * 8);
+  float* vs = (float*)w;
+  w += align256((size_t)n * 4);
+  w += 256;
+  size_t tmp = (size_t)(workspace_bytes - (w - (char*)workspace));
+  // the sentinel ~0 has every bit set, so all 64 bits are sorted when sentinels may be present
+  const unsigned end_bit = (key_bits > 0 && key_bits < 64) ? (unsigned)key_bits : 64u;
+  hipError_t e = rocprim::radix_sort_pairs(w, tmp, keys_in, ks, vals_in, vs, (size_t)n, 0, end_bit, st);
+  if (e != hipSuccess) {
+    set_error("coo_sort_reduce: radix sort: %s", hipGetErrorString(e));
+    return TMGCN_ERR_LAUNCH;
+  }
+  tmp = (size_t)(workspace_bytes - (w - (char*)workspace));
+  e = rocprim::reduce_by_key(w, tmp, ks, vs, (size_t)n, keys_out, vals_out, n_out_dev,
+                             rocprim::plus<float>(), rocprim::equal_to<uint64_t>(), st);
+  if (e != hipSuccess) {
+    set_error("coo_sort_reduce: reduce_by_key: %s", hipGetErrorString(e));
+    return TMGCN_ERR_LAUNCH;
+  }
+  return TMGCN_OK;
+}
+
+// ---- the expand / elementwise steps --------------------------------------------------------------
+extern "C" int tmgcn_adj_make_keys(const int64_t* t, const int64_t* i, const int64_t* j, int64_t n,
+                                    int64_t N, uint64_t* key, void* stream) {
+  TMGCN_REQUIRE(n >= 0 && N > 0, "adj_make_keys: bad size");
+  if (n == 0) return TMGCN_OK;
+  hipLaunchKernelGGL(adj_make_keys_kernel, dim3(blocks(n)), dim3(256), 0, (hipStream_t)stream, t, i, j, n, N, key);
+  return check_launch("adj_make_keys");
+}
+
+extern "C" int tmgcn_adj_symmetrise(const uint64_t* key, const float* val, int64_t n, int64_t N,
+                                     uint64_t* okey, float* oval, void* stream) {
+  TMGCN_REQUIRE(n >= 0 && N > 0, "adj_symmetrise: bad size");
+  if (n == 0) return TMGCN_OK;
+  hipLaunchKernelGGL(adj_symmetrise_kernel, dim3(blocks(n)), dim3(256), 0, (hipStream_t)stream, key, val, n, N,
+                     okey, oval);
+  return check_launch("adj_symmetrise");
+}
+
+extern "C" int tmgcn_adj_edge_life(const uint64_t* key, const float* val, int64_t n, int64_t N, int32_t T,
+                                    int32_t window, uint64_t* okey, float* oval, void* stream) {
+  TMGCN_REQUIRE(n >= 0 && N > 0 && T > 0 && window >= 1, "adj_edge_life: bad size");
+  if (n == 0) return TMGCN_OK;
+  hipLaunchKernelGGL(adj_edge_life_kernel, dim3(blocks(n * window)), dim3(256), 0, (hipStream_t)stream, key, val,
+                     n, N, T, window, okey, oval);
+  return check_launch("adj_edge_life");
+}
+
+extern "C" int tmgcn_adj_identity(int64_t TN, int64_t N, uint64_t* okey, float* oval, void* stream) {
+  TMGCN_REQUIRE(TN >= 0 && N > 0, "adj_identity: bad size");
+  if (TN == 0) return TMGCN_OK;
+  hipLaunchKernelGGL(adj_identity_kernel, dim3(blocks(TN)), dim3(256), 0, (hipStream_t)stream, TN, N, okey, oval);
+  return check_launch("adj_identity");
+}
+
+// C = D^-1/2 (B) D^-1/2 in place on a sorted, reduced COO; rowptr (TN+1) and dinv (TN) are outputs too
+extern "C" int tmgcn_adj_normalise(const uint64_t* key, float* val, int64_t n, int64_t N, int64_t TN,
+                                    int64_t* rowptr, float* dinv, void* stream) {
+  TMGCN_REQUIRE(n >= 0 && N > 0 && TN >= 0, "adj_normalise: bad size");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adj_rowptr_kernel, dim3(blocks(TN + 1)), dim3(256), 0, st, key, n, N, TN, rowptr);
+  if (TN) hipLaunchKernelGGL(adj_rowsum_kernel, dim3(blocks(TN)), dim3(256), 0, st, key, val, rowptr, TN, dinv);
+  if (n) hipLaunchKernelGGL(adj_scale_kernel, dim3(blocks(n)), dim3(256), 0, st, key, val, n, N, dinv);
+  return check_launch("adj_normalise");
+}
+
+extern "C" int tmgcn_adj_mproduct_expand(const uint64_t* key, const float* val, int64_t n, int64_t N,
+                                          int32_t T, const float* M, int32_t ldm, int32_t band_lo,
+                                          int32_t band_hi, uint64_t* okey, float* oval, void* stream) {
+  TMGCN_REQUIRE(n >= 0 && N > 0 && T > 0 && band_lo >= 0 && band_hi >= 0, "adj_mproduct: bad size");
+  if (n == 0) return TMGCN_OK;
+  TMGCN_REQUIRE(M && ldm >= T, "adj_mproduct: bad M");
+  if (band_lo > T - 1) band_lo = T - 1;
+  if (band_hi > T - 1) band_hi = T - 1;
+  const int W = band_lo + band_hi + 1;
+  hipLaunchKernelGGL(adj_mproduct_kernel, dim3(blocks(n * W)), dim3(256), 0, (hipStream_t)stream, key, val, n, N,
+                     T, M, ldm, band_lo, band_hi, okey, oval);
+  return check_launch("adj_mproduct");
+}
+
+// sorted keys -> CSR arrays
+extern "C" int tmgcn_adj_keys_to_csr(const uint64_t* key, int64_t n, int64_t N, int64_t TN, int64_t* rowptr,
+                                      int32_t* col, void* stream) {
+  TMGCN_REQUIRE(n >= 0 && N > 0 && TN >= 0, "adj_keys_to_csr: bad size");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adj_rowptr_kernel, dim3(blocks(TN + 1)), dim3(256), 0, st, key, n, N, TN, rowptr);
+  if (n) hipLaunchKernelGGL(adj_cols_kernel, dim3(blocks(n)), dim3(256), 0, st, key, n, N, col);
+  return check_launch("adj_keys_to_csr");
+}
+
+// keys of the per-slice transpose of a batched CSR (then sort them with tmgcn_coo_sort_reduce)
+extern "C" int tmgcn_adj_transpose_keys(const int64_t* rowptr, const int32_t* col, int64_t TN, int64_t N,
+                                         uint64_t* okey, void* stream) {
+  TMGCN_REQUIRE(TN >= 0 && N > 0, "adj_transpose_keys: bad size");
+  if (TN == 0) return TMGCN_OK;
+  hipLaunchKernelGGL(adj_transpose_keys_kernel, dim3(blocks(TN)), dim3(256), 0, (hipStream_t)stream, rowptr, col,
+                     TN, N, okey);
+  return check_launch("adj_transpose_keys");
+}
