@@ -49,18 +49,19 @@ def parse():
     p.add_argument("--no-pipeline", action="store_true", help="exchange all slices before computing")
     p.add_argument("--force-collectives", action="store_true",
                    help="run the exchange (RCCL) code path even at --gpus 1 (diagnostic)")
-    p.add_argument("--cpu-nodes", type=int, default=500_000, help="N of the CPU-baseline sample")
+    p.add_argument("--cpu-nodes", type=int, default=250_000, help="N of the CPU-baseline sample")
     return p.parse_args()
 
 
 def cpu_baseline(args):
     """The oracle's layer fwd+bwd (list of COO fp64, one sparse.mm per slice, autograd) on the
-    host cores, on a bounded sample: 2 slices of the same degree/F at N = cpu-nodes."""
+    host cores, on a bounded sample: 2 slices of the same degree/F at N = cpu-nodes.  Timed at
+    two thread counts (all cores, and 32: torch's sparse kernels do not scale to hundreds of
+    threads) and the faster one is reported with the threads it used."""
     from oracle import tmgcn_oracle as orc
     from tmgcn_amd import synth
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     Tc, Nc, F = 2, min(args.nodes, args.cpu_nodes), args.feat
     A = synth.device_er_csr(Tc, Nc, args.deg, "cpu")
     At = A.to_coo_list(torch.float64)
@@ -69,21 +70,29 @@ def cpu_baseline(args):
     g = torch.Generator().manual_seed(1)
     W = torch.randn(F, F, generator=g) * 0.1
     dY = torch.randn(Tc, Nc, F, generator=g)
-    orc.layer_fwd_bwd(M, At, X, W, dY)  # warm-up (allocator, thread pool)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        orc.layer_fwd_bwd(M, At, X, W, dY)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 5:
-            break
+    best = None
+    for threads in sorted({ncpu, min(32, ncpu)}):
+        torch.set_num_threads(threads)
+        orc.layer_fwd_bwd(M, At, X, W, dY)  # warm-up (allocator, thread pool)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            orc.layer_fwd_bwd(M, At, X, W, dY)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > 6.0 or reps >= 3:
+                break
+        rate = A.nnz * reps / el
+        if best is None or rate > best[0]:
+            best = (rate, threads, reps, el)
+    rate, threads, reps, el = best
     try:
         model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    return {"value": A.nnz * reps / el, "unit": "edge-slices/s", "cores": cores, "kind": "port",
+    return {"value": rate, "unit": "edge-slices/s", "cores": threads, "kind": "port",
             "sample": f"{reps} x fwd+bwd of {Tc} slices, N={Nc}, deg={args.deg}+1, F={F}->{F} "
-                      f"(torch CPU, {cores} threads, {model}); {el / reps:.2f} s each"}
+                      f"(oracle = reference's way on torch CPU, best of {{{ncpu}, {min(32, ncpu)}}} threads, {model}); "
+                      f"{el / reps:.2f} s each"}
 
 
 def main():

@@ -17,6 +17,13 @@
 #include "common.h"
 #include "spmm_row.h"
 
+#ifndef TMGCN_SPMM_U
+#define TMGCN_SPMM_U 4      // gathers in flight per lane (F >= 64)
+#endif
+#ifndef TMGCN_SPMM_RPB
+#define TMGCN_SPMM_RPB 64   // rows per 256-thread block
+#endif
+
 namespace tmgcn {
 
 // ---------------------------------------------------------------------------------
@@ -197,7 +204,7 @@ extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int3
     const int F4 = F / 4;
     int lpr = 4;
     while (lpr < F4) lpr <<= 1;
-    const int rows_per_block = 64;
+    const int rows_per_block = TMGCN_SPMM_RPB;
     const unsigned grid = (unsigned)((n_rows + rows_per_block - 1) / rows_per_block);
     const float4* X4 = reinterpret_cast<const float4*>(X);
     float4* Y4 = reinterpret_cast<float4*>(Y);
@@ -209,9 +216,9 @@ extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int3
     switch (lpr) {
       TMGCN_VEC_CASE(4, 2)
       TMGCN_VEC_CASE(8, 2)
-      TMGCN_VEC_CASE(16, 4)
-      TMGCN_VEC_CASE(32, 4)
-      TMGCN_VEC_CASE(64, 4)
+      TMGCN_VEC_CASE(16, TMGCN_SPMM_U)
+      TMGCN_VEC_CASE(32, TMGCN_SPMM_U)
+      TMGCN_VEC_CASE(64, TMGCN_SPMM_U)
     }
 #undef TMGCN_VEC_CASE
     return check_launch("spmm_vec4");

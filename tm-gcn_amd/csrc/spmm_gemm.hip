@@ -21,6 +21,18 @@ namespace tmgcn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// tuning knobs (defaults = the measured best; tools/ab_variants.sh builds alternatives)
+#ifndef TMGCN_FUSED_OCC
+#define TMGCN_FUSED_OCC 4   // min waves per SIMD asked of the register allocator (A/B: 4 beats 3 by 4.5 %)
+#endif
+#ifndef TMGCN_FUSED_U
+#define TMGCN_FUSED_U 4     // gathers in flight per lane (F = 64 / 128 variants)
+#endif
+
+#ifndef TMGCN_FUSED_LDS_PAD
+#define TMGCN_FUSED_LDS_PAD 0
+#endif
+
 constexpr int FBM = 64;         // rows per tile
 constexpr int FKC = 128;        // max K (feature width of X)
 constexpr int FLDA = FKC + 4;   // LDS row stride in floats
@@ -47,8 +59,8 @@ struct FusedArgs {
 };
 
 template <int LPR, int U, int NJ>  // NJ = K / 8 (K is a multiple of 8 here)
-__global__ __launch_bounds__(256, 3) void spmm_gemm_kernel(FusedArgs a) {
-  __shared__ float As[FBM * FLDA];
+__global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedArgs a) {
+  __shared__ float As[FBM * FLDA + TMGCN_FUSED_LDS_PAD];  // (pad: occupancy experiments only)
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 31;
@@ -192,8 +204,8 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
   switch (K) {
     TMGCN_FUSED_CASE(16, 4, 2)
     TMGCN_FUSED_CASE(32, 8, 2)
-    TMGCN_FUSED_CASE(64, 16, 4)
-    TMGCN_FUSED_CASE(128, 32, 4)
+    TMGCN_FUSED_CASE(64, 16, TMGCN_FUSED_U)
+    TMGCN_FUSED_CASE(128, 32, TMGCN_FUSED_U)
   }
 #undef TMGCN_FUSED_CASE
   return check_launch("spmm_gemm");
