@@ -158,6 +158,20 @@ int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const int64_t* d
                             float* dZ, float* dU, int64_t R, int64_t E, int32_t F, int32_t C,
                             void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- class-weighted cross entropy, mean reduction (opt-in) -----------------------------
+ * Same value as  nn.CrossEntropyLoss(weight=w)(logits, target)  used by every experiment script
+ * (experiment_reddit_our_link_prediction.py:69, 79): loss = Σ w[t]·nll / Σ w[t].  One streaming
+ * pass each way with fp64 block sums in fixed order; C <= 8.  stats_out: 2 doubles {Σ w·nll, Σ w}
+ * kept by the caller for the backward.  Targets must lie in [0, C).
+ */
+int64_t tmgcn_wce_workspace_bytes(int64_t E);
+int tmgcn_wce_fwd_f32(const float* logits, const int64_t* target, const float* weight, int64_t E,
+                      int32_t C, float* loss_out, double* stats_out, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* weight,
+                      const double* stats, const float* grad_loss, int64_t E, int32_t C,
+                      float* dlogits, void* stream);
+
 /* ---- adjacency pipeline on the device ----------------------------------
  * Replaces the reference's offline preprocessing loops: read_data.py:88-111 (symmetrise),
  * :116-125 (edge-life window), :130-169 (add I, D^-1/2 · D^-1/2), :204-223 (sparse M-product),

@@ -307,3 +307,23 @@ def test_edge_head_wide_falls_back():
     assert tuple(ops.edge_head(Z, e, U).shape) == (2, 2)
     with pytest.raises(RuntimeError):
         ops.edge_head(Z, e, U, fuse=True)
+
+
+# ------------------------------------------------------------------------------------- weighted CE (opt-in)
+@pytest.mark.parametrize("E,C", [(1, 2), (1000, 2), (5000, 3), (300, 8), (3_000_001, 2)])
+def test_weighted_cross_entropy_matches_torch_fp64(E, C):
+    from tmgcn_amd.losses import WeightedCrossEntropy
+    g = torch.Generator().manual_seed(E + C)
+    z = torch.randn(E, C, generator=g) * 5
+    t = torch.randint(0, C, (E,), generator=g)
+    w = torch.rand(C, generator=g) + 0.1
+    zr = z.double().clone().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss(weight=w.double())(zr, t)
+    (ref * 1.7).backward()
+    zg = z.to(DEV).requires_grad_(True)
+    loss = WeightedCrossEntropy(w)(zg, t.to(DEV))
+    (loss * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-7 * max(1.0, abs(float(ref)))
+    assert_close(zg.grad, zr.grad, 2e-6, "wce dlogits")
+    with pytest.raises(RuntimeError):
+        WeightedCrossEntropy(torch.ones(9))(torch.randn(4, 9, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV))

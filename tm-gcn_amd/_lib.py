@@ -38,6 +38,9 @@ SIGNATURES = {
     "tmgcn_edge_head_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_edge_head_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "tmgcn_edge_head_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i64, _p]),
+    "tmgcn_wce_workspace_bytes": (_i64, [_i64]),
+    "tmgcn_wce_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
+    "tmgcn_wce_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
     "tmgcn_adj_make_keys": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "tmgcn_coo_sort_reduce_workspace_bytes": (_i64, [_i64]),
     "tmgcn_coo_sort_reduce": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),

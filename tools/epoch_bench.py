@@ -27,7 +27,7 @@ MODELS = {  # the scripts' model per config
 }
 
 
-def gpu_epochs(g, spec, epochs, graph):
+def gpu_epochs(g, spec, epochs, graph, fused_loss=False):
     At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
     edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels).cuda()
     torch.manual_seed(0)
@@ -37,7 +37,11 @@ def gpu_epochs(g, spec, epochs, graph):
     else:
         m = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=spec["hidden"], nonlin2=spec["nonlin"], **kw)
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
-    crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1], device="cuda"))
+    if fused_loss:
+        from tmgcn_amd.losses import WeightedCrossEntropy
+        crit = WeightedCrossEntropy(torch.tensor([0.9, 0.1])).cuda()
+    else:
+        crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1], device="cuda"))
 
     def epoch():
         opt.zero_grad(set_to_none=True)
@@ -121,11 +125,12 @@ if __name__ == "__main__":
     ap.add_argument("--epochs", type=int, default=50)
     ap.add_argument("--cpu-epochs", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--fused-loss", action="store_true", help="tmgcn_amd.WeightedCrossEntropy instead of nn.CrossEntropyLoss")
     args = ap.parse_args()
     for name in args.configs:
         g = synth.dynamic_graph(**synth.CONFIGS[name], seed=0)
         spec = MODELS[name]
-        l_gpu, t_eager, t_graph = gpu_epochs(g, spec, args.epochs, not args.no_graph)
+        l_gpu, t_eager, t_graph = gpu_epochs(g, spec, args.epochs, not args.no_graph, args.fused_loss)
         cpu = {}
         for th in (8, 32):  # all 256 threads is pathological on these small ops (measured: 1000x slower)
             l_cpu, cpu[th] = cpu_epochs(g, spec, args.cpu_epochs, th)
@@ -139,4 +144,4 @@ if __name__ == "__main__":
                           "cpu_epoch_ms": round(t_cpu * 1e3, 1), "cpu_threads": th_best,
                           "cpu_epoch_ms_by_threads": {str(k): round(v * 1e3, 1) for k, v in cpu.items()},
                           "speedup": round(t_cpu / best, 1),
-                          "first_loss_gpu": l_gpu, "first_loss_cpu": l_cpu}), flush=True)
+                          "fused_loss": args.fused_loss, "first_loss_gpu": l_gpu, "first_loss_cpu": l_cpu}), flush=True)
