@@ -36,7 +36,7 @@ inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0) {
   static int cached = 0;  // one instance per kernel type/instantiation site
   static const void* cached_for = nullptr;
   const void* key = reinterpret_cast<const void*>(kernel);
-  if (cached && cached_for == key) return cached;
+  if (cached && cached_for == key && dyn_smem == 0) return cached;  // dynamic LDS changes residency: re-query
   int dev = 0, cus = 256, per_cu = 1;
   if (hipGetDevice(&dev) == hipSuccess) {
     hipDeviceProp_t prop;

@@ -217,6 +217,90 @@ __global__ __launch_bounds__(256) void mtransform_dense_kernel(MtArgs a) {
   }
 }
 
+// Dense operator on the matrix cores (Minv = the reference's use_Minv path, ehf:224/332/341, or
+// any M wider than 20 diagonals).  Y[T_out x C] = Mop · X is a GEMM whose long dimension is C:
+//   A operand = Mop: wave w of a block owns output rows [32(4y+w), +32); its A fragments
+//               (T_in/2 values per lane) stay in registers for the whole launch
+//   B operand = a 64-column tile of X staged once per block through LDS (full-line loads),
+//               read back as ds_read_b32 (lane = column: conflict-free)
+//   v_mfma_f32_32x32x2_f32, exact fp32; k-steps outside the band of the wave's rows are skipped
+//   (a lower-triangular Minv costs half the MFMAs).  T_in <= 2*SMAX.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kDenseCols = 64;
+
+template <int SMAX>
+__global__ __launch_bounds__(256) void mtransform_dense_mfma_kernel(MtArgs a) {
+  extern __shared__ float Xs[];  // [T_in][64]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int k0 = (blockIdx.y * 4 + wave) * 32;
+  const bool wave_live = k0 < a.T_out;
+  const int d_lo = (a.row_off - a.col_off) - a.band_lo;
+  const int d_hi = (a.row_off - a.col_off) + a.band_hi;
+  const int nsteps = (a.T_in + 1) / 2;
+
+  // A fragments: lane (i, h) holds Mop[k0+i][2s+h]
+  float areg[SMAX];
+#pragma unroll
+  for (int s = 0; s < SMAX; ++s) {
+    const int k = k0 + li, j = 2 * s + lh;
+    float m = 0.f;
+    if (s < nsteps && k < a.T_out && j < a.T_in && j >= k + d_lo && j <= k + d_hi) m = mop(a, k, j);
+    areg[s] = m;
+  }
+  // k-steps this wave's 32 rows can touch
+  int j_lo = k0 + d_lo, j_hi = k0 + 31 + d_hi;
+  if (j_lo < 0) j_lo = 0;
+  if (j_hi > a.T_in - 1) j_hi = a.T_in - 1;
+  const int s_lo = j_lo / 2, s_hi = wave_live && j_hi >= j_lo ? j_hi / 2 + 1 : 0;
+
+  const int64_t n_tiles = (a.C + kDenseCols - 1) / kDenseCols;
+  const bool vec = (a.C % 4 == 0) && (reinterpret_cast<uintptr_t>(a.X) % 16 == 0);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t c0 = tile * kDenseCols;
+    __syncthreads();
+    if (vec) {
+      for (int t = threadIdx.x; t < a.T_in * (kDenseCols / 4); t += 256) {
+        const int j = t / (kDenseCols / 4), q = t % (kDenseCols / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + 4 * q < a.C)
+          v = *reinterpret_cast<const float4*>(a.X + row_pos(j, a.T_in, a.x_tl) * a.C + c0 + 4 * q);
+        *reinterpret_cast<float4*>(&Xs[j * kDenseCols + 4 * q]) = v;
+      }
+    } else {
+      for (int t = threadIdx.x; t < a.T_in * kDenseCols; t += 256) {
+        const int j = t / kDenseCols, q = t % kDenseCols;
+        Xs[t] = (c0 + q < a.C) ? a.X[row_pos(j, a.T_in, a.x_tl) * a.C + c0 + q] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (!wave_live) continue;
+#pragma unroll
+    for (int nb = 0; nb < kDenseCols / 32; ++nb) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) {
+        if (s >= s_lo && s < s_hi) {
+          const int j = 2 * s + lh;
+          const float b = j < a.T_in ? Xs[j * kDenseCols + nb * 32 + li] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], b, acc, 0, 0, 0);
+        }
+      }
+      const int64_t c = c0 + nb * 32 + li;
+      if (c < a.C) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = k0 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+          if (k < a.T_out) a.Y[row_pos(k, a.T_out, a.y_tl) * a.C + c] = acc[i];
+        }
+      }
+    }
+  }
+}
+
 template <int WIDTH, int VEC>
 static void launch_band(const MtArgs& a, dim3 grid, hipStream_t st) {
   constexpr int PF = 4;  // rows in flight per lane
@@ -254,6 +338,21 @@ static int dispatch(MtArgs a, hipStream_t st) {
     else if (width <= 16) launch_band<16, VEC>(a, grid, st);
     else launch_band<20, VEC>(a, grid, st);
     return check_launch("mtransform_band");
+  }
+  if (a.T_in <= 256) {  // matrix-core path
+    const size_t smem = (size_t)a.T_in * kDenseCols * sizeof(float);
+    const unsigned gy = (unsigned)((a.T_out + 127) / 128);
+    const int64_t n_tiles = (a.C + kDenseCols - 1) / kDenseCols;
+    if (a.T_in <= 128) {
+      int64_t gx = persistent_grid(mtransform_dense_mfma_kernel<64>, 256, smem);
+      if (gx > n_tiles) gx = n_tiles;
+      hipLaunchKernelGGL((mtransform_dense_mfma_kernel<64>), dim3((unsigned)gx, gy), dim3(256), smem, st, a);
+    } else {
+      int64_t gx = persistent_grid(mtransform_dense_mfma_kernel<128>, 256, smem);
+      if (gx > n_tiles) gx = n_tiles;
+      hipLaunchKernelGGL((mtransform_dense_mfma_kernel<128>), dim3((unsigned)gx, gy), dim3(256), smem, st, a);
+    }
+    return check_launch("mtransform_dense_mfma");
   }
   constexpr int RT = 16;
   dim3 grid((unsigned)((cvec + kWave - 1) / kWave), (unsigned)((a.T_out + 4 * RT - 1) / (4 * RT)));

@@ -63,6 +63,17 @@ def spmm(T=4, N=2_000_000, F=128, deg=32):
     print(f"spmm_gemm (+AX store): {ms:.2f} ms  {by / ms / 1e6:.0f} GB/s (P2 bytes only)")
 
 
+def mtransform_dense(T=128, N=250_000, F=128):
+    import numpy as np
+    X = torch.rand(T, N, F, device=dev)
+    op = ops.MOperator(synth.band_M(T, 20, "matlab"), dev).inverse()  # dense lower-triangular
+    for tr in (False, True):
+        ms = timeit(lambda: K.mtransform(op, X, transpose=tr))
+        fl = 2.0 * (T * (T + 1) / 2) * N * F
+        print(f"mtransform Minv (lower-triangular dense) T={T} N={N} F={F} transpose={tr}: {ms:.2f} ms  "
+              f"{2 * X.numel() * 4 / ms / 1e6:.0f} GB/s  {fl / ms / 1e9:.1f} TFLOP/s")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["mtransform", "gemm", "spmm"]
     for w in which:
@@ -74,3 +85,6 @@ if __name__ == "__main__":
             gemm()
         elif w == "spmm":
             spmm()
+        elif w == "dense":
+            mtransform_dense()
+            mtransform_dense(T=64, N=20000, F=6)
