@@ -139,7 +139,7 @@ int tmgcn_act_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, int
 /* ---- P4: edge head  (ehf:228-232, 351-355, 491-495) --------------------------------
  *   out[e][c] = sum_{f<F} Z[src[e]][f] * U[f][c] + sum_{f<F} Z[dst[e]][f] * U[F+f][c]
  * src/dst are the flat row indices t*N+node built at ehf:196-198.  Z is [R][F], U is [2F][C].
- * Supported when tmgcn_edge_head_supported(F, C) != 0 (F <= 32, C <= 8); wider heads use the
+ * Supported when tmgcn_edge_head_supported(F, C) != 0 (F <= 256, C <= 8); wider heads use the
  * caller's own gather + GEMM.
  * Backward (autograd of the same statements), no atomics, fixed summation order:
  *   dZ[r][f] (every row written, rows without edges get 0) and dU[2F][C].

@@ -261,7 +261,7 @@ def test_spmm_gemm_unsupported_width_raises():
 
 
 # ------------------------------------------------------------------------------------- P4 edge head
-@pytest.mark.parametrize("F,C", [(2, 2), (6, 2), (6, 3), (16, 8), (32, 2), (5, 1)])
+@pytest.mark.parametrize("F,C", [(2, 2), (6, 2), (6, 3), (16, 8), (32, 2), (5, 1), (128, 2), (100, 3), (256, 8)])
 @pytest.mark.parametrize("E", [0, 1, 1000, 70001])
 def test_edge_head_fwd_bwd(F, C, E):
     T, N = 3, 97
@@ -300,9 +300,9 @@ def test_edge_head_fwd_bwd(F, C, E):
 
 
 def test_edge_head_wide_falls_back():
-    assert not ops.kernels.edge_head_supported(128, 2)
-    Z = torch.randn(2, 10, 128, device=DEV)
-    U = torch.randn(256, 2, device=DEV)
+    assert not ops.kernels.edge_head_supported(300, 2)
+    Z = torch.randn(2, 10, 300, device=DEV)
+    U = torch.randn(600, 2, device=DEV)
     e = ops.EdgeIndex(torch.tensor([[0, 1], [1, 2], [3, 4]]), 10, DEV)
     assert tuple(ops.edge_head(Z, e, U).shape) == (2, 2)
     with pytest.raises(RuntimeError):

@@ -120,17 +120,21 @@ __global__ void adj_mproduct_kernel(const uint64_t* __restrict__ key, const floa
 }
 
 // ---- CSR views of sorted keys ----------------------------------------------------------------
+// rowptr from sorted keys in O(nnz): entry p owns the rows (row(p-1), row(p)] — every row that
+// starts at p — and the last entry also closes the tail; with n == 0 thread 0 fills everything.
 __global__ void adj_rowptr_kernel(const uint64_t* __restrict__ key, int64_t n, int64_t N, int64_t TN,
                                   int64_t* __restrict__ rowptr) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > TN) return;
-  const uint64_t target = (uint64_t)r * N;  // first key of row r
-  int64_t a = 0, b = n;
-  while (a < b) {
-    const int64_t m = (a + b) >> 1;
-    if (key[m] < target) a = m + 1; else b = m;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n == 0) {
+    for (int64_t r = p; r <= TN; r += (int64_t)gridDim.x * blockDim.x) rowptr[r] = 0;
+    return;
   }
-  rowptr[r] = a;
+  if (p >= n) return;
+  const int64_t row = (int64_t)(key[p] / (uint64_t)N);
+  const int64_t prev = p ? (int64_t)(key[p - 1] / (uint64_t)N) : -1;
+  for (int64_t r = prev + 1; r <= row; ++r) rowptr[r] = p;   // rows (prev, row] begin at p
+  if (p == n - 1)
+    for (int64_t r = row + 1; r <= TN; ++r) rowptr[r] = n;   // empty tail rows and the end marker
 }
 
 __global__ void adj_cols_kernel(const uint64_t* __restrict__ key, int64_t n, int64_t N,
@@ -262,7 +266,7 @@ extern "C" int tmgcn_adj_normalise(const uint64_t* key, float* val, int64_t n, i
                                     int64_t* rowptr, float* dinv, void* stream) {
   TMGCN_REQUIRE(n >= 0 && N > 0 && TN >= 0, "adj_normalise: bad size");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adj_rowptr_kernel, dim3(blocks(TN + 1)), dim3(256), 0, st, key, n, N, TN, rowptr);
+  hipLaunchKernelGGL(adj_rowptr_kernel, dim3(blocks(n ? n : TN + 1)), dim3(256), 0, st, key, n, N, TN, rowptr);
   if (TN) hipLaunchKernelGGL(adj_rowsum_kernel, dim3(blocks(TN)), dim3(256), 0, st, key, val, rowptr, TN, dinv);
   if (n) hipLaunchKernelGGL(adj_scale_kernel, dim3(blocks(n)), dim3(256), 0, st, key, val, n, N, dinv);
   return check_launch("adj_normalise");
@@ -287,7 +291,7 @@ extern "C" int tmgcn_adj_keys_to_csr(const uint64_t* key, int64_t n, int64_t N, 
                                       int32_t* col, void* stream) {
   TMGCN_REQUIRE(n >= 0 && N > 0 && TN >= 0, "adj_keys_to_csr: bad size");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adj_rowptr_kernel, dim3(blocks(TN + 1)), dim3(256), 0, st, key, n, N, TN, rowptr);
+  hipLaunchKernelGGL(adj_rowptr_kernel, dim3(blocks(n ? n : TN + 1)), dim3(256), 0, st, key, n, N, TN, rowptr);
   if (n) hipLaunchKernelGGL(adj_cols_kernel, dim3(blocks(n)), dim3(256), 0, st, key, n, N, col);
   return check_launch("adj_keys_to_csr");
 }

@@ -19,8 +19,8 @@
 
 namespace tmgcn {
 
-constexpr int kMaxC = 8;    // classes
-constexpr int kMaxF = 32;   // embedding width handled by the fused head
+constexpr int kMaxC = 8;     // classes
+constexpr int kMaxF = 256;   // embedding width handled by the fused head
 
 struct EdgeArgs {
   const float* Z;       // [R][F]
@@ -32,28 +32,41 @@ struct EdgeArgs {
   int32_t F, C;
 };
 
+// G lanes share one edge: lane gl takes features gl, gl+G, ... of both endpoint rows (coalesced
+// across the group), partial dot products are combined with a shuffle butterfly.  U sits in LDS.
+template <int G>
 __global__ __launch_bounds__(256) void edge_head_fwd_kernel(EdgeArgs a) {
-  __shared__ float Us[2 * kMaxF * kMaxC];
+  extern __shared__ float Us[];  // [2F][C]
   for (int t = threadIdx.x; t < 2 * a.F * a.C; t += 256) Us[t] = a.U[t];
   __syncthreads();
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= a.E) return;
-  const float* zs = a.Z + a.src[e] * a.F;
-  const float* zd = a.Z + a.dst[e] * a.F;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t e = gid / G;
+  const int gl = (int)(gid % G);
+  const bool live = e < a.E;
   float acc[kMaxC];
 #pragma unroll
   for (int c = 0; c < kMaxC; ++c) acc[c] = 0.f;
-  for (int f = 0; f < a.F; ++f) {
-    const float s = zs[f], d = zd[f];
-    const float* us = Us + f * a.C;
-    const float* ud = Us + (a.F + f) * a.C;
+  if (live) {
+    const float* zs = a.Z + a.src[e] * a.F;
+    const float* zd = a.Z + a.dst[e] * a.F;
+    for (int f = gl; f < a.F; f += G) {
+      const float s = zs[f], d = zd[f];
+      const float* us = Us + f * a.C;
+      const float* ud = Us + (a.F + f) * a.C;
 #pragma unroll
-    for (int c = 0; c < kMaxC; ++c)
-      if (c < a.C) acc[c] = fmaf(d, ud[c], fmaf(s, us[c], acc[c]));
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < a.C) acc[c] = fmaf(d, ud[c], fmaf(s, us[c], acc[c]));
+    }
   }
 #pragma unroll
-  for (int c = 0; c < kMaxC; ++c)
-    if (c < a.C) a.out[e * a.C + c] = acc[c];
+  for (int o = G >> 1; o > 0; o >>= 1)
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) acc[c] += __shfl_xor(acc[c], o);
+  if (live && gl == 0) {
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < a.C) a.out[e * a.C + c] = acc[c];
+  }
 }
 
 struct EdgeBwdArgs {
@@ -70,13 +83,19 @@ struct EdgeBwdArgs {
   int32_t F, C;
   int32_t chunks;
   int64_t edges_per_chunk;
+  int32_t du_edges;      // edges per LDS tile of the dU kernel
 };
 
+// G lanes per row: every lane of the group sums the row's incident dout rows (broadcast loads),
+// then lane gl writes features gl, gl+G, ...
+template <int G>
 __global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
-  __shared__ float Us[2 * kMaxF * kMaxC];
+  extern __shared__ float Us[];
   for (int t = threadIdx.x; t < 2 * a.F * a.C; t += 256) Us[t] = a.U[t];
   __syncthreads();
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = gid / G;
+  const int gl = (int)(gid % G);
   if (r >= a.R) return;
   double S[2][kMaxC];
 #pragma unroll
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
     s0[c] = (float)S[0][c];
     s1[c] = (float)S[1][c];
   }
-  for (int f = 0; f < a.F; ++f) {
+  for (int f = gl; f < a.F; f += G) {
     float v = 0.f;
 #pragma unroll
     for (int c = 0; c < kMaxC; ++c)
@@ -107,31 +126,28 @@ __global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
   }
 }
 
-// dU slabs: edges staged through LDS in tiles of DU_EDGES.  n_out = 2F*C outputs (k, c); with
+// dU slabs: edges staged through LDS in tiles of du_edges.  n_out = 2F*C outputs (k, c); with
 // n_out <= 128 the threads form 256/n_out edge groups so every lane works (the real head is
-// 12 x 2 = 24 outputs); fp64 running sums, groups combined through LDS in fixed order.
-constexpr int DU_EDGES = 64;
+// 12 x 2 = 24 outputs), otherwise each thread owns up to 16 outputs; fp64 running sums, groups
+// combined through LDS in fixed order.
+constexpr int DU_OMAX = 16;  // 2*256*8 / 256
 __global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
-  __shared__ float sz[DU_EDGES * 2 * kMaxF];
-  __shared__ float sd[DU_EDGES * kMaxC];
+  extern __shared__ float sm[];  // [du_edges][2F] gathered rows, then [du_edges][C] dout rows
   __shared__ double red[256];
   const int K = 2 * a.F;
-  const int n_out = K * a.C;  // <= 512
+  float* sz = sm;
+  float* sd = sm + a.du_edges * K;
+  const int n_out = K * a.C;
   const int groups = n_out <= 128 ? 256 / n_out : 1;
   const int grp = groups > 1 ? threadIdx.x / n_out : 0;
   const int64_t e0 = (int64_t)blockIdx.x * a.edges_per_chunk;
   int64_t e1 = e0 + a.edges_per_chunk;
   if (e1 > a.E) e1 = a.E;
-  double acc[2] = {0.0, 0.0};
-  int ok_[2], oc_[2];
+  double acc[DU_OMAX];
 #pragma unroll
-  for (int o = 0; o < 2; ++o) {
-    const int idx = groups > 1 ? (o == 0 && grp < groups ? (int)(threadIdx.x % n_out) : n_out) : threadIdx.x + o * 256;
-    ok_[o] = idx < n_out ? idx / a.C : -1;
-    oc_[o] = idx < n_out ? idx % a.C : 0;
-  }
-  for (int64_t e = e0; e < e1; e += DU_EDGES) {
-    const int ne = (int)((e1 - e) < DU_EDGES ? (e1 - e) : DU_EDGES);
+  for (int o = 0; o < DU_OMAX; ++o) acc[o] = 0.0;
+  for (int64_t e = e0; e < e1; e += a.du_edges) {
+    const int ne = (int)((e1 - e) < a.du_edges ? (e1 - e) : a.du_edges);
     __syncthreads();
     for (int t = threadIdx.x; t < ne * K; t += 256) {
       const int i = t / K, k = t % K;
@@ -140,18 +156,30 @@ __global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
     }
     for (int t = threadIdx.x; t < ne * a.C; t += 256) sd[t] = a.dout[e * a.C + t];
     __syncthreads();
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-      if (ok_[o] >= 0) {
-        double s = acc[o];
-        for (int i = grp; i < ne; i += groups) s += (double)sz[i * K + ok_[o]] * (double)sd[i * a.C + oc_[o]];
-        acc[o] = s;
+    if (groups > 1) {
+      if (grp < groups) {
+        const int idx = threadIdx.x % n_out, k = idx / a.C, c = idx % a.C;
+        double s = acc[0];
+        for (int i = grp; i < ne; i += groups) s += (double)sz[i * K + k] * (double)sd[i * a.C + c];
+        acc[0] = s;
       }
+    } else {
+#pragma unroll
+      for (int o = 0; o < DU_OMAX; ++o) {
+        const int idx = threadIdx.x + o * 256;
+        if (idx < n_out) {
+          const int k = idx / a.C, c = idx % a.C;
+          double s = acc[o];
+          for (int i = 0; i < ne; ++i) s += (double)sz[i * K + k] * (double)sd[i * a.C + c];
+          acc[o] = s;
+        }
+      }
+    }
   }
   float* P = a.part + (int64_t)blockIdx.x * n_out;
   if (groups > 1) {
     __syncthreads();
-    red[threadIdx.x] = acc[0];
+    red[threadIdx.x] = grp < groups ? acc[0] : 0.0;
     __syncthreads();
     if (threadIdx.x < n_out) {
       double s = 0.0;
@@ -160,8 +188,10 @@ __global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
     }
   } else {
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
-      if (ok_[o] >= 0) P[threadIdx.x + o * 256] = (float)acc[o];
+    for (int o = 0; o < DU_OMAX; ++o) {
+      const int idx = threadIdx.x + o * 256;
+      if (idx < n_out) P[idx] = (float)acc[o];
+    }
   }
 }
 
@@ -178,7 +208,22 @@ __global__ __launch_bounds__(256) void edge_head_du_reduce_kernel(const float* _
   if (lane == 0) dU[o] = (float)s;
 }
 
-static void du_plan(int64_t E, int* chunks, int64_t* per) {
+static int lanes_per_item(int F) {  // G: 1 for the real (tiny) heads, up to 64 lanes for wide ones
+  if (F <= 8) return 1;
+  int g = 2;
+  while (g < 64 && g * 4 < F) g <<= 1;
+  return g;
+}
+
+static int du_tile_edges(int F) {  // LDS tile <= 32 KB of gathered rows
+  int e = 8192 / (2 * F);
+  if (e > 64) e = 64;
+  if (e < 4) e = 4;
+  return e;
+}
+
+static void du_plan(int64_t E, int F, int* chunks, int64_t* per) {
+  const int DU_EDGES = du_tile_edges(F);
   int64_t c = (E + 255) / 256;  // >= 256 edges per chunk, <= 2048 slabs
   if (c > 2048) c = 2048;
   if (c < 1) c = 1;
@@ -207,7 +252,19 @@ extern "C" int tmgcn_edge_head_fwd_f32(const float* Z, const int64_t* src, const
   if (E == 0) return TMGCN_OK;
   TMGCN_REQUIRE(Z && src && dst && U && out, "edge_head: null pointer");
   EdgeArgs a{Z, src, dst, U, out, E, F, C};
-  hipLaunchKernelGGL(edge_head_fwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  const size_t smem = (size_t)2 * F * C * sizeof(float);
+  const int G = lanes_per_item(F);
+  const unsigned grid = (unsigned)((E * G + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (G) {
+    case 1: hipLaunchKernelGGL(edge_head_fwd_kernel<1>, dim3(grid), dim3(256), smem, st, a); break;
+    case 2: hipLaunchKernelGGL(edge_head_fwd_kernel<2>, dim3(grid), dim3(256), smem, st, a); break;
+    case 4: hipLaunchKernelGGL(edge_head_fwd_kernel<4>, dim3(grid), dim3(256), smem, st, a); break;
+    case 8: hipLaunchKernelGGL(edge_head_fwd_kernel<8>, dim3(grid), dim3(256), smem, st, a); break;
+    case 16: hipLaunchKernelGGL(edge_head_fwd_kernel<16>, dim3(grid), dim3(256), smem, st, a); break;
+    case 32: hipLaunchKernelGGL(edge_head_fwd_kernel<32>, dim3(grid), dim3(256), smem, st, a); break;
+    default: hipLaunchKernelGGL(edge_head_fwd_kernel<64>, dim3(grid), dim3(256), smem, st, a);
+  }
   return check_launch("edge_head_fwd");
 }
 
@@ -215,7 +272,7 @@ extern "C" int64_t tmgcn_edge_head_bwd_workspace_bytes(int64_t E, int32_t F, int
   if (E <= 0 || F <= 0 || C <= 0) return 0;
   int chunks;
   int64_t per;
-  du_plan(E, &chunks, &per);
+  du_plan(E, F, &chunks, &per);
   return (int64_t)chunks * 2 * F * C * (int64_t)sizeof(float);
 }
 
@@ -229,11 +286,22 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
   hipStream_t st = (hipStream_t)stream;
   int chunks;
   int64_t per;
-  du_plan(E, &chunks, &per);
-  EdgeBwdArgs a{Z, src, dst, U, dout, eptr, eidx, dZ, (float*)workspace, R, E, F, C, chunks, per};
+  du_plan(E, F, &chunks, &per);
+  EdgeBwdArgs a{Z, src, dst, U, dout, eptr, eidx, dZ, (float*)workspace, R, E, F, C, chunks, per, du_tile_edges(F)};
   if (dZ && R > 0) {
     TMGCN_REQUIRE(eptr && (E == 0 || (eidx && dout)) && U, "edge_head_bwd: null pointer (dZ)");
-    hipLaunchKernelGGL(edge_head_dz_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, a);
+    const size_t smem = (size_t)2 * F * C * sizeof(float);
+    const int G = lanes_per_item(F);
+    const unsigned grid = (unsigned)((R * G + 255) / 256);
+    switch (G) {
+      case 1: hipLaunchKernelGGL(edge_head_dz_kernel<1>, dim3(grid), dim3(256), smem, st, a); break;
+      case 2: hipLaunchKernelGGL(edge_head_dz_kernel<2>, dim3(grid), dim3(256), smem, st, a); break;
+      case 4: hipLaunchKernelGGL(edge_head_dz_kernel<4>, dim3(grid), dim3(256), smem, st, a); break;
+      case 8: hipLaunchKernelGGL(edge_head_dz_kernel<8>, dim3(grid), dim3(256), smem, st, a); break;
+      case 16: hipLaunchKernelGGL(edge_head_dz_kernel<16>, dim3(grid), dim3(256), smem, st, a); break;
+      case 32: hipLaunchKernelGGL(edge_head_dz_kernel<32>, dim3(grid), dim3(256), smem, st, a); break;
+      default: hipLaunchKernelGGL(edge_head_dz_kernel<64>, dim3(grid), dim3(256), smem, st, a);
+    }
     int rc = check_launch("edge_head_dz");
     if (rc) return rc;
   }
@@ -248,7 +316,8 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
       set_error("edge_head_bwd: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
       return TMGCN_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(edge_head_du_kernel, dim3((unsigned)chunks), dim3(256), 0, st, a);
+    const size_t smem = (size_t)a.du_edges * (2 * F + C) * sizeof(float);
+    hipLaunchKernelGGL(edge_head_du_kernel, dim3((unsigned)chunks), dim3(256), smem, st, a);
     int rc = check_launch("edge_head_du");
     if (rc) return rc;
     const int n_out = 2 * F * C;

@@ -445,7 +445,7 @@ def spmm_feature_gemm(A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, act=None,
 
 def edge_head(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, fuse: Optional[bool] = None) -> torch.Tensor:
     """P4: logits[e] = [Z[src[e]], Z[dst[e]]] · U  (ehf:228-232).  One fused gather-and-dot kernel
-    (atomic-free backward) when F <= 32 and C <= 8, else stock gather + matmul."""
+    (atomic-free backward) when F <= 256 and C <= 8, else stock gather + matmul."""
     F, Cn = Z.shape[-1], U.shape[-1]
     can = hasattr(kernels, "edge_head_supported") and kernels.edge_head_supported(F, Cn)
     if fuse is None:

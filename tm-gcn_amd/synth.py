@@ -171,6 +171,8 @@ CONFIGS = {
     "S1": dict(T=95, N=6000, edges_per_slice=250),                        # Bitcoin-OTC-shaped
     "S2": dict(T=65, N=3800, edges_per_slice=2500, neg_per_pos=19),       # Reddit-LP-shaped
     "S3": dict(T=150, N=1000, edges_per_slice=500),                       # AMLSim-shaped
+    # the two model-level probes of BASELINE.md §2 (uniform random graphs, wide features)
+    "P128": dict(T=32, N=20000, edges_per_slice=16000, window=1, F0=128), # F = 128 -> 128 -> 128
 }
 
 

@@ -24,6 +24,7 @@ MODELS = {  # the scripts' model per config
     "S1": dict(kind="gcn2", hidden=[6, 6, 2], nonlin="selu"),   # experiment_bitcoin_our.py:107 (2-layer)
     "S2": dict(kind="gcn", hidden=[6, 2]),                      # experiment_reddit_our_link_prediction.py:65
     "S3": dict(kind="gcn2", hidden=[6, 6, 2], nonlin="selu", param_dtype=torch.bfloat16),  # AMLSim, bf16 weights
+    "P128": dict(kind="gcn2", hidden=[128, 128, 2], nonlin="relu", scale=0.05),  # BASELINE.md §2 probe, wide features
 }
 
 
@@ -36,6 +37,10 @@ def gpu_epochs(g, spec, epochs, graph, fused_loss=False):
         m = ehf.EmbeddingGCN(At, X, edges, M, hidden_feat=spec["hidden"], **kw)
     else:
         m = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=spec["hidden"], nonlin2=spec["nonlin"], **kw)
+    if "scale" in spec:  # N(0,1) weights at width 128 overflow the activations; both sides scale the same way
+        with torch.no_grad():
+            for q in m.parameters():
+                q.mul_(spec["scale"])
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
     if fused_loss:
         from tmgcn_amd.losses import WeightedCrossEntropy
@@ -95,7 +100,7 @@ def cpu_epochs(g, spec, epochs, threads):
     edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels)
     torch.manual_seed(0)
     F = [X.shape[-1]] + spec["hidden"]
-    p = {k: torch.nn.Parameter(v) for k, v in orc.draw_params(spec["kind"], g.T, F).items()}
+    p = {k: torch.nn.Parameter(v * spec.get("scale", 1.0)) for k, v in orc.draw_params(spec["kind"], g.T, F).items()}
     AtXt = orc.compute_AtXt(M, At, X)  # cached at construction, as the reference does (ehf:195)
     src, dst = orc.flat_edge_index(edges, g.N)
     opt = torch.optim.SGD(list(p.values()), lr=0.01, momentum=0.9)
@@ -132,10 +137,11 @@ if __name__ == "__main__":
         spec = MODELS[name]
         l_gpu, t_eager, t_graph = gpu_epochs(g, spec, args.epochs, not args.no_graph, args.fused_loss)
         cpu = {}
-        for th in (8, 32):  # all 256 threads is pathological on these small ops (measured: 1000x slower)
+        for th in ((8, 32) if args.cpu_epochs > 0 else ()):  # all 256 threads is pathological on these small ops (measured: 1000x slower)
             l_cpu, cpu[th] = cpu_epochs(g, spec, args.cpu_epochs, th)
-        th_best = min(cpu, key=cpu.get)
-        t_cpu = cpu[th_best]
+        th_best = min(cpu, key=cpu.get) if cpu else 0
+        t_cpu = cpu[th_best] if cpu else float("nan")
+        l_cpu = l_cpu if cpu else float("nan")
         best = min(t for t in (t_eager, t_graph) if t)
         print(json.dumps({"config": name, "model": spec["kind"], "T": g.T, "N": g.N, "E": int(g.edges.shape[1]),
                           "nnz_At": int(sum(c.nnz for c in g.Ct)),
