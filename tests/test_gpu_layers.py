@@ -192,3 +192,36 @@ def test_wide_features_use_fused_kernel_and_match_oracle(branch):
     assert_close(out, ref.detach(), TOL, "logits")
     for n in p:
         assert_close(grads[n], p[n].grad, TOL, "d" + n)
+
+
+def test_graphed_train_step_matches_eager():
+    """The whole epoch (forward, weighted CE, backward, SGD) captured into one hipGraph gives the
+    same trajectory as eager execution (every C-ABI launcher is capture-safe)."""
+    from tmgcn_amd.graphs import GraphedTrainStep
+    from tmgcn_amd.losses import WeightedCrossEntropy
+    d = golden("g6_sgd_gcn2")
+    i = _inputs(d)
+    tgt = i["labels"].cuda()
+
+    def build():
+        torch.manual_seed(int(d["seed"]))
+        m = ehf.EmbeddingGCN2(i["At"], i["X"], i["edges"], i["M"], hidden_feat=[6, 6, 2], condensed_W=True,
+                              use_Minv=False, nonlin2="selu")
+        return m, torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9), WeightedCrossEntropy(torch.tensor([0.9, 0.1])).cuda()
+
+    m1, o1, c1 = build()
+    eager = []
+    for _ in range(3 + 10):  # GraphedTrainStep runs 3 warm-up steps before capturing
+        o1.zero_grad()
+        l = c1(m1(), tgt)
+        l.backward()
+        o1.step()
+        eager.append(float(l.detach()))
+    m2, o2, c2 = build()
+    step = GraphedTrainStep(m2, c2, o2, tgt, warmup=3)
+    graphed = [float(step()) for _ in range(10)]
+    assert_close(np.array(graphed), np.array(eager[3:]), 1e-5, "graphed vs eager losses")
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert_close(q.detach(), p.detach(), 1e-5, "graphed vs eager " + n)
+    # and the fixture's first 10 losses are what the first 10 eager steps gave (reference trajectory)
+    assert_close(np.array(eager[:10]), d["losses"], 1e-4, "reference trajectory")
