@@ -225,3 +225,34 @@ def test_graphed_train_step_matches_eager():
         assert_close(q.detach(), p.detach(), 1e-5, "graphed vs eager " + n)
     # and the fixture's first 10 losses are what the first 10 eager steps gave (reference trajectory)
     assert_close(np.array(eager[:10]), d["losses"], 1e-4, "reference trajectory")
+
+
+def test_tiny_and_degenerate_inputs():
+    """T = 1, a slice with no edges at all, isolated nodes, a single labelled edge."""
+    from oracle import tmgcn_oracle as orc
+    N = 5
+    a0 = torch.sparse_coo_tensor(torch.tensor([[0, 1, 4], [1, 0, 4]]), torch.tensor([0.5, 0.5, 1.0], dtype=torch.float64), (N, N))
+    empty = torch.sparse_coo_tensor(torch.zeros(2, 0, dtype=torch.long), torch.zeros(0, dtype=torch.float64), (N, N))
+    X = torch.arange(2 * N * 2, dtype=torch.float64).reshape(2, N, 2)
+    M = torch.tensor([[1.0, 0.0], [0.5, 1.0]], dtype=torch.float64)
+    edges = torch.tensor([[1], [2], [3]])
+    torch.manual_seed(0)
+    m = ehf.EmbeddingGCN([a0, empty], X, edges, M, hidden_feat=[3, 2], condensed_W=True, use_Minv=False)
+    assert_close(m.AtXt, orc.compute_AtXt(M, [a0, empty], X), TOL, "AtXt with an empty slice")
+    assert float(m.AtXt[1].abs().max()) == 0.0 and tuple(m().shape) == (1, 2)
+    m().sum().backward()
+    assert torch.isfinite(m.W.grad).all() and torch.isfinite(m.U.grad).all()
+    # T = 1
+    torch.manual_seed(0)
+    m1 = ehf.EmbeddingGCN2([a0], X[:1], torch.tensor([[0, 0], [0, 4], [1, 4]]), M[:1, :1], hidden_feat=[4, 3, 2],
+                           condensed_W=False, use_Minv=False, apply_M_twice=True, nonlin2="relu")
+    p = {n: q.detach().cpu() for n, q in m1.named_parameters()}
+    src, dst = orc.flat_edge_index(torch.tensor([[0, 0], [0, 4], [1, 4]]), N)
+    ref = orc.gcn2_forward(orc.compute_AtXt(M[:1, :1], [a0], X[:1]), [a0], M[:1, :1], p["W1"], p["W2"], p["U"], src, dst,
+                           nonlin="relu", apply_M_twice=True)
+    assert_close(m1(), ref, TOL, "T = 1 two-layer model")
+    # mismatched adjacency / features fail loudly, as RuntimeError (the reference's convention)
+    with pytest.raises(RuntimeError):
+        ehf.EmbeddingGCN([a0], X, edges, M, hidden_feat=[3, 2], condensed_W=True, use_Minv=False)
+    with pytest.raises(RuntimeError):
+        ehf.EmbeddingGCN([a0, empty], X[:, :3], edges, M, hidden_feat=[3, 2], condensed_W=True, use_Minv=False)
