@@ -47,7 +47,8 @@ def test_abi_version_and_error_string():
     rc = lib.tmgcn_spmm_csr_batched_f32(None, None, None, None, None, 10, 3, 4, None)
     assert rc == -1 and b"multiple" in lib.tmgcn_last_error() or b"null" in lib.tmgcn_last_error()
     assert lib.tmgcn_gemm_dw_workspace_bytes(1000, 6, 6, 0) > 0
-    assert lib.tmgcn_spmm_gemm_supported(128, 128) == 1 and lib.tmgcn_spmm_gemm_supported(6, 6) == 0
+    assert lib.tmgcn_spmm_gemm_supported(128, 128) == 1 and lib.tmgcn_spmm_gemm_supported(6, 6) == 1
+    assert lib.tmgcn_spmm_gemm_supported(20, 8) == 0 and lib.tmgcn_spmm_gemm_supported(6, 17) == 0
 
 
 def test_no_cpu_fallback():

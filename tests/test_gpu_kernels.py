@@ -250,6 +250,30 @@ def test_spmm_gemm_autograd_matches_unfused(act):
         assert_close(a, b, REL_TOL, f"fused vs unfused {what} act={act}")
 
 
+@pytest.mark.parametrize("K,Nf", [(1, 1), (2, 6), (6, 6), (6, 2), (3, 16), (8, 5), (4, 7)])
+@pytest.mark.parametrize("trans_w,per_slice", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("act", [None, "selu"])
+def test_spmm_gemm_fused_small_widths(K, Nf, trans_w, per_slice, act):
+    """The reference's real widths (2 -> 6 -> 6): one launch for P2+P3(+P5)."""
+    from oracle import tmgcn_oracle as orc
+    T, N = 3, 130
+    csr = rand_csr(T, N, 9.0, seed=K * 17 + Nf)
+    g = torch.Generator().manual_seed(K + Nf)
+    X = torch.randn(T, N, K, generator=g)
+    wshape = (Nf, K) if trans_w else (K, Nf)
+    W = torch.randn(*((T,) + wshape if per_slice else wshape), generator=g)
+    assert ops.kernels.spmm_gemm_supported(K, Nf)
+    Y, AX, pre = ops.kernels.spmm_gemm(csr.to(DEV), X.to(DEV), W.to(DEV), trans_w=trans_w, act=act, want_ax=True, want_pre=True)
+    ref_ax = ref_spmm(csr, X)
+    ref_pre = ref_gemm(ref_ax, W, trans_w, per_slice)
+    assert_close(AX, ref_ax, REL_TOL, "small fused: SpMM intermediate")
+    if act:
+        assert_close(pre, ref_pre, REL_TOL, "small fused: pre-activation")
+        assert_close(Y, orc.ACTS[act](pre.cpu()), 2e-6, "small fused: activation")
+    else:
+        assert_close(Y, ref_pre, REL_TOL, f"small fused K={K} Nf={Nf}")
+
+
 def test_spmm_gemm_unsupported_width_raises():
     csr = rand_csr(2, 20, 3.0, seed=1).to(DEV)
     assert not ops.kernels.spmm_gemm_supported(20, 8)

@@ -161,12 +161,76 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-F variant (the reference's real widths: F = 2 -> 6 -> 6): G lanes share a
+// row and stride over its non-zeros as in spmm_small; after the shuffle butterfly every lane of
+// the group holds the row sum, and lane gl produces output columns gl, gl+G, ...  The weight is
+// a few dozen floats, read through L1.  One launch instead of SpMM + GEMM, no [T,N,F] round trip.
+// ---------------------------------------------------------------------------------------------
+template <int F, int G>
+__global__ __launch_bounds__(256) void spmm_gemm_small_kernel(FusedArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = gid / G;
+  const int gl = (int)(gid % G);
+  const bool live = r < a.n_rows;
+  const float* X = reinterpret_cast<const float*>(a.X);
+  float acc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = 0.f;
+  if (live) {
+    const int64_t beg = a.rowptr[r], end = a.rowptr[r + 1];
+    const int64_t xoff = (r / a.N) * (int64_t)a.N;
+    for (int64_t p = beg + gl; p < end; p += G) {
+      const float* x = X + (xoff + a.col[p]) * F;
+      const float v = a.val[p];
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[f] = fmaf(v, x[f], acc[f]);
+    }
+  }
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1)
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] += __shfl_xor(acc[f], o);
+  if (!live) return;
+  if (a.AX && gl == 0) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) a.AX[r * F + f] = acc[f];
+  }
+  const float* Wb = a.W + (a.rows_per_batch ? (r / a.rows_per_batch) * a.w_batch_stride : 0);
+  for (int n = gl; n < a.Nf; n += G) {
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) s = fmaf(acc[f], a.trans_w ? Wb[(int64_t)n * F + f] : Wb[(int64_t)f * a.Nf + n], s);
+    if (a.pre) a.pre[r * a.Nf + n] = s;
+    a.Y[r * a.Nf + n] = act_apply(s, a.act);
+  }
+}
+
+template <int F>
+static int launch_fused_small(const FusedArgs& a, int G, hipStream_t st) {
+  const unsigned grid = (unsigned)((a.n_rows * G + 255) / 256);
+  switch (G) {
+    case 1: hipLaunchKernelGGL((spmm_gemm_small_kernel<F, 1>), dim3(grid), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((spmm_gemm_small_kernel<F, 2>), dim3(grid), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((spmm_gemm_small_kernel<F, 4>), dim3(grid), dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((spmm_gemm_small_kernel<F, 8>), dim3(grid), dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((spmm_gemm_small_kernel<F, 16>), dim3(grid), dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((spmm_gemm_small_kernel<F, 32>), dim3(grid), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((spmm_gemm_small_kernel<F, 64>), dim3(grid), dim3(256), 0, st, a);
+  }
+  return check_launch("spmm_gemm_small");
+}
+
+static bool fused_small_ok(int K, int Nf) {
+  return (K == 1 || K == 2 || K == 3 || K == 4 || K == 6 || K == 8) && Nf >= 1 && Nf <= 16;
+}
+
 }  // namespace tmgcn
 
 using namespace tmgcn;
 
 extern "C" int tmgcn_spmm_gemm_supported(int32_t K, int32_t Nf) {
-  return ((K == 16 || K == 32 || K == 64 || K == 128) && Nf >= 1 && Nf <= 128) ? 1 : 0;
+  return (((K == 16 || K == 32 || K == 64 || K == 128) && Nf >= 1 && Nf <= 128) || fused_small_ok(K, Nf)) ? 1 : 0;
 }
 
 extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* val,
@@ -176,13 +240,30 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
                                     float* Y, float* AX, float* pre_act, void* stream) {
   TMGCN_REQUIRE(n_rows >= 0 && N > 0, "spmm_gemm: bad shape n_rows=%lld N=%d", (long long)n_rows, N);
   TMGCN_REQUIRE(tmgcn_spmm_gemm_supported(K, Nf),
-                "spmm_gemm: unsupported widths K=%d Nf=%d (need K in {16,32,64,128}, Nf <= 128); "
+                "spmm_gemm: unsupported widths K=%d Nf=%d (need K in {16,32,64,128} with Nf <= 128, or K in {1,2,3,4,6,8} with Nf <= 16); "
                 "use tmgcn_spmm_csr_batched_f32 + tmgcn_gemm_f32", K, Nf);
   TMGCN_REQUIRE(act >= TMGCN_ACT_NONE && act <= TMGCN_ACT_SELU, "spmm_gemm: unknown activation %d", act);
   TMGCN_REQUIRE(rows_per_batch >= 0, "spmm_gemm: negative rows_per_batch");
   if (n_rows == 0) return TMGCN_OK;
   TMGCN_REQUIRE(rowptr && X && W && Y, "spmm_gemm: null pointer");
   TMGCN_REQUIRE(n_rows % N == 0, "spmm_gemm: n_rows=%lld is not a multiple of N=%d", (long long)n_rows, N);
+  if (fused_small_ok(K, Nf)) {
+    FusedArgs s{rowptr, col, val, reinterpret_cast<const float4*>(X), n_rows, N, K, W, Nf, trans_w,
+                rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0};
+    // lanes per row from the average row length (as tmgcn_spmm_csr_batched_f32_hint does)
+    int64_t nnz_host_unknown = -1;
+    (void)nnz_host_unknown;
+    int G = 8;
+    hipStream_t st2 = (hipStream_t)stream;
+    switch (K) {
+      case 1: return launch_fused_small<1>(s, G, st2);
+      case 2: return launch_fused_small<2>(s, G, st2);
+      case 3: return launch_fused_small<3>(s, G, st2);
+      case 4: return launch_fused_small<4>(s, G, st2);
+      case 6: return launch_fused_small<6>(s, G, st2);
+      default: return launch_fused_small<8>(s, G, st2);
+    }
+  }
   TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 && (!AX || reinterpret_cast<uintptr_t>(AX) % 16 == 0),
                 "spmm_gemm: X / AX must be 16-byte aligned");
   FusedArgs a{rowptr, col, val, reinterpret_cast<const float4*>(X), n_rows, N, K, W, Nf, trans_w,

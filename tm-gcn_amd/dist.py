@@ -293,7 +293,7 @@ class ShardedTMGCNLayer:
                 send = X.view(self.G, self.Tl, Nl, F).transpose(0, 1).contiguous()
             send = send.view(self.Tl, self.G, Nl, F)
             can_fuse = hasattr(ops.kernels, "spmm_gemm_supported") and \
-                ops.kernels.spmm_gemm_supported(F, W.shape[-1])
+                ops.kernels.spmm_gemm_supported(F, W.shape[-1]) and ops.kernels.spmm_gemm_supported(W.shape[-1], F)
             if self.pipeline and can_fuse and self.fuse is not False:
                 if shared_w:
                     W = _SharedWeight.apply(W, self.group)

@@ -377,7 +377,10 @@ class _SpmmGemm(torch.autograd.Function):
             dY = kernels.act_bwd(pre, dY, ctx.act)
         dX = dW = None
         if ctx.needs_input_grad[0]:
-            dX, _, _ = kernels.spmm_gemm(ctx.A.transpose(), dY, W, trans_w=True, tag="spmm_gemm_T")
+            if kernels.spmm_gemm_supported(dY.shape[-1], W.shape[-2]):
+                dX, _, _ = kernels.spmm_gemm(ctx.A.transpose(), dY, W, trans_w=True, tag="spmm_gemm_T")
+            else:  # the transposed widths have no fused kernel: dA = dY·Wᵀ, then Âᵀ·dA
+                dX = kernels.spmm(ctx.A.transpose(), kernels.gemm(dY, W, trans_w=True), tag="spmm_T")
         if ctx.needs_input_grad[1]:
             dW = kernels.gemm_dw(AX, dY, per_slice=W.dim() == 3)
         return dX, dW, None, None
@@ -431,7 +434,8 @@ def feature_gemm(A: torch.Tensor, W: torch.Tensor, act=None) -> torch.Tensor:
 
 def spmm_feature_gemm(A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, act=None, fuse: Optional[bool] = None):
     """P2 then P3 (+P5): act((Â ⋆ X) · W).  One fused launch when the kernel supports the
-    widths (K in {16,32,64,128}, Nf <= 128), else the two kernels back to back."""
+    widths (K in {16,32,64,128} with Nf <= 128, or K in {1,2,3,4,6,8} with Nf <= 16), else the two
+    kernels back to back."""
     K, Nf = X.shape[-1], W.shape[-1]
     can = hasattr(kernels, "spmm_gemm_supported") and kernels.spmm_gemm_supported(K, Nf)
     if fuse is None:
