@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
     const int64_t slice = r / N;
     const float4 acc = gather_row<LPR, U>(col, val, X + slice * (int64_t)N * F4, rowptr[r],
                                           rowptr[r + 1], F4, lane);
-    if (lane < LPR && lane < F4) Y[r * F4 + lane] = acc;
+    if (lane < LPR && lane < F4) store_f4(&Y[r * F4 + lane], acc);
   }
 }
 

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
       }
       if (lane < LPR && lane < F4) {
         *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
-        if (a.AX && r < row_end) reinterpret_cast<float4*>(a.AX)[r * F4 + lane] = acc;
+        if (a.AX && r < row_end) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
       }
     }
     __syncthreads();
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
             const int64_t r = row0 + mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
             if (r < row_end) {
               const float s = acc[mb][i];
-              if (a.pre) a.pre[r * a.Nf + n] = s;
-              a.Y[r * a.Nf + n] = act_apply(s, a.act);
+              if (a.pre) store_f1(&a.pre[r * a.Nf + n], s);
+              store_f1(&a.Y[r * a.Nf + n], act_apply(s, a.act));
             }
           }
         }

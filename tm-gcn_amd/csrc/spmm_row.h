@@ -2,7 +2,33 @@
 #pragma once
 #include "common.h"
 
+// tuning knobs for the A/B harness (tools/ab_variants.sh)
+#ifndef TMGCN_NT_COLVAL
+#define TMGCN_NT_COLVAL 0   // 1: stream (col,val) with non-temporal loads
+#endif
+#ifndef TMGCN_NT_STORE
+#define TMGCN_NT_STORE 1    // 1: non-temporal stores for the SpMM / fused outputs (A/B: -1.5 % on the fused kernel)
+#endif
+
 namespace tmgcn {
+
+__device__ __forceinline__ void store_f4(float4* p, const float4& v) {
+#if TMGCN_NT_STORE
+  __builtin_nontemporal_store(v.x, &p->x);
+  __builtin_nontemporal_store(v.y, &p->y);
+  __builtin_nontemporal_store(v.z, &p->z);
+  __builtin_nontemporal_store(v.w, &p->w);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void store_f1(float* p, float v) {
+#if TMGCN_NT_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 
 // One wave sums one CSR row:  acc = sum_p val[p] * Xs[col[p]]  over [beg, end).
 // LPR lanes cover the F4 float4s of a feature row (lane fl), S = 64/LPR streams split the
@@ -24,8 +50,13 @@ __device__ __forceinline__ float4 gather_row(const int32_t* __restrict__ col,
     int c = 0;
     float v = 0.f;
     if (lane < n) {
+#if TMGCN_NT_COLVAL
+      c = __builtin_nontemporal_load(col + base + lane);
+      v = __builtin_nontemporal_load(val + base + lane);
+#else
       c = col[base + lane];
       v = val[base + lane];
+#endif
     }
     for (int p = 0; p < n; p += S * U) {
       float4 x[U];
