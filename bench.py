@@ -169,6 +169,7 @@ def main():
     else:
         total_nnz = A.nnz
 
+    out = None
     if rank == 0:
         # roofline of the dominant kernel (forward SpMM): SURVEY §8d no-reuse gather model,
         # bytes per edge-slice = 8 (col+val) + F*4 (gathered row) + (4 + F*4)/d (rowptr + output row)
@@ -208,10 +209,20 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+    # RCCL prints its version banner through C stdio, which is flushed only at exit when stdout is
+    # a pipe/file: every rank flushes it BEFORE the last barrier so that rank 0's JSON line is the
+    # last line of the job's stdout.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

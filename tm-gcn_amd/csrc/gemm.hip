@@ -230,7 +230,10 @@ __global__ __launch_bounds__(256) void gemm_dw_mfma_kernel(DwArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 
-  constexpr int UR = 4;  // MFMA k-steps (row pairs) in flight
+#ifndef TMGCN_DW_UR
+#define TMGCN_DW_UR 4
+#endif
+  constexpr int UR = TMGCN_DW_UR;  // MFMA k-steps (row pairs) in flight
   for (int64_t r = r0; r < r1; r += 2 * UR) {
     float av[UR], bv[UR][4];
 #pragma unroll
@@ -350,7 +353,7 @@ static void dw_plan(int64_t R, int64_t rows_per_batch, int64_t* n_batch, int* ch
   if (c > cmax) c = cmax;
   if (c < 1) c = 1;
   int64_t rpc = (br + c - 1) / c;
-  rpc = (rpc + 7) & ~(int64_t)7;  // whole unrolled steps
+  rpc = (rpc + 31) & ~(int64_t)31;  // whole unrolled steps (2 * UR rows, UR <= 16)
   c = (br + rpc - 1) / (rpc ? rpc : 1);
   if (c < 1) c = 1;
   *n_batch = nb;
