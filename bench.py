@@ -207,7 +207,7 @@ def main():
                          "avg_launch_ms": sp["avg_ms"]},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args)
     # RCCL prints its version banner through C stdio, which is flushed only at exit when stdout is
     # a pipe/file: every rank flushes it BEFORE the last barrier so that rank 0's JSON line is the
