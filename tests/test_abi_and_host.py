@@ -119,10 +119,15 @@ def test_moperator_band_detection():
 
 
 def test_synth_configs_have_the_scripts_shapes():
-    g = synth.dynamic_graph(**synth.CONFIGS["S0"], seed=0)
+    g = synth.sbm_dynamic_graph()  # S0: the SBM plumbing config (T=10, N=500, F=16)
     assert g.X.shape == (10, 500, 16) and len(g.Ct) == 10 and g.M.shape == (10, 10)
-    # every Â slice has the full diagonal (the reference's size inference needs it)
-    assert all(c.diagonal().min() > 0 for c in g.Ct)
+    assert all((a != a.T).nnz == 0 and a.diagonal().sum() == 0 for a in g.A_raw)  # symmetric, no self loops
+    dens_in = g.A_raw[0][:250, :250].nnz / 250 ** 2
+    dens_out = g.A_raw[0][:250, 250:].nnz / 250 ** 2
+    assert 0.07 < dens_in < 0.13 and 0.005 < dens_out < 0.02  # p_in = .1, p_out = .01
+    s1 = synth.dynamic_graph(T=6, N=80, edges_per_slice=40, seed=3)
+    # every normalised Â slice has the full diagonal (the reference's size inference needs it)
+    assert all(c.diagonal().min() > 0 for c in s1.Ct)
     lp = synth.dynamic_graph(T=6, N=80, edges_per_slice=40, seed=1, neg_per_pos=3)
     assert set(np.unique(lp.labels)) == {0, 1} and lp.edges.shape[0] == 3
     a = synth.device_er_csr(2, 1000, 32, "cpu", first_slice=5)

@@ -134,3 +134,31 @@ def test_S4_shaped_properties_large():
     # 4. fused and unfused paths agree at this size
     un = ShardedTMGCNLayer(A, M, T, fuse=False)
     assert_close(un(X1, W), layer(X1, W), 1e-6, "fused vs unfused")
+
+
+def test_S0_sbm_config_on_gpu():
+    """The SBM plumbing config (raw, un-normalised adjacency, F0 = 16) through the device path."""
+    from oracle import tmgcn_oracle as orc
+    g = synth.sbm_dynamic_graph()
+    At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
+    edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels)
+    torch.manual_seed(0)
+    m = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False,
+                          apply_M_twice=True, nonlin2="selu")
+    with torch.no_grad():
+        for q in m.parameters():
+            q.mul_(0.1)
+    out = m()
+    params = {n: q.detach().cpu() for n, q in m.named_parameters()}
+    ref32, g32, dlogits = _oracle(orc, "gcn2", g, At, X, M, edges, labels, params, "selu", torch.float32)
+    # _oracle's gcn2 path is the default branch; S0 in the reference script uses apply_M_twice=False too
+    m2 = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False, nonlin2="selu")
+    with torch.no_grad():
+        for q, v in zip(m2.parameters(), params.values()):
+            q.copy_(v)
+    out2 = m2()
+    out2.backward(dlogits.cuda())
+    assert_close(out2, ref32, REL_TOL, "S0 logits")
+    for n, q in m2.named_parameters():
+        assert_close(q.grad, g32[n], REL_TOL, "S0 d" + n)
+    assert torch.isfinite(out).all()

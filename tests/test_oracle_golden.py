@@ -181,3 +181,23 @@ def test_g6_sgd_trajectory(kind):
     assert_close(np.array(losses), d["losses"], 1e-5, kind + " losses")
     for k, v in ps.items():
         assert_close(v.detach(), d[k + "_final"], 1e-5, kind + " final " + k)
+
+
+def test_S0_sbm_plumbing_config_on_cpu():
+    """BASELINE config 0 (SBM, T=10, N=500, F=16, CPU only): the oracle's 2-layer model on the SBM
+    stand-in agrees with the dense fp64 einsum form of the same math (no GPU involved)."""
+    g = synth.sbm_dynamic_graph()
+    At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
+    edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels)
+    torch.manual_seed(0)
+    p = {k: v * 0.1 for k, v in orc.draw_params("gcn2", g.T, [16, 6, 6, 2]).items()}
+    src, dst = orc.flat_edge_index(edges, g.N)
+    out = orc.gcn2_forward(orc.compute_AtXt(M, At, X), At, M, p["W1"], p["W2"], p["U"], src, dst, nonlin="selu",
+                           apply_M_twice=True)
+    A = torch.stack([a.to_dense() for a in At])
+    mt = lambda Z: torch.einsum("kj,jnf->knf", M, Z)
+    spm = lambda Z: torch.einsum("knm,kmf->knf", A, Z)
+    Y = torch.nn.functional.selu(spm(mt(X)) @ p["W1"].double())
+    Z = (spm(mt(Y)) @ p["W2"].double()).reshape(-1, 6)
+    ref = torch.cat((Z[src], Z[dst]), 1) @ p["U"].double()
+    assert_close(out, ref, 1e-5, "S0 SBM 2-layer logits")

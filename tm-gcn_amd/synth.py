@@ -164,10 +164,40 @@ def dynamic_graph(T: int, N: int, edges_per_slice: int, seed: int = 0, window: i
     return DynamicGraph(T, N, A, C, Ct, M, X, np.concatenate(es, axis=1), np.concatenate(ls))
 
 
+def sbm_dynamic_graph(T: int = 10, N: int = 500, p_in: float = 0.1, p_out: float = 0.01, migrate: int = 10,
+                      F0: int = 16, no_diag: int = 20, seed: int = 0) -> DynamicGraph:
+    """S0, the plumbing config of BASELINE.json: a 2-community stochastic block model in which
+    `migrate` nodes move from community 1 to community 0 at every step (SBM_our.py:98-109 uses
+    dynamicgem's get_community_diminish_series_v2 for this), RAW symmetric adjacency without
+    normalisation or self loops (SBM_our.py:111-131), M = 1/(d+1) on `no_diag` diagonals
+    (SBM_our.py:88-96), random-normal features, every edge labelled."""
+    import networkx as nx
+
+    rng = np.random.default_rng(seed)
+    member = np.zeros(N, dtype=int)
+    member[N // 2:] = 1
+    A = []
+    for t in range(T):
+        if t:
+            ones = np.nonzero(member == 1)[0]
+            member[rng.choice(ones, size=min(migrate, len(ones)), replace=False)] = 0
+        order = np.argsort(member, kind="stable")
+        sizes = [int((member == 0).sum()), int((member == 1).sum())]
+        g = nx.stochastic_block_model(sizes, [[p_in, p_out], [p_out, p_in]], seed=int(rng.integers(1 << 31)))
+        a = nx.to_scipy_sparse_array(g, format="coo")
+        A.append(sp.coo_matrix((np.ones(a.nnz), (order[a.row], order[a.col])), shape=(N, N)).tocsr())
+    M = band_M(T, no_diag, "matlab")
+    Ct = m_product(A, M)
+    X = rng.standard_normal((T, N, F0))
+    es = [np.stack([np.full(a.nnz, t), a.tocoo().row, a.tocoo().col]).astype(np.int64) for t, a in enumerate(A)]
+    edges = np.concatenate(es, axis=1)
+    labels = rng.integers(0, 2, edges.shape[1]).astype(np.int64)
+    return DynamicGraph(T, N, A, A, Ct, M, X, edges, labels)
+
+
 # Named stand-ins for the BASELINE configs (SURVEY §8d; N and edges/slice are assumptions,
-# T / feature / hidden sizes are the scripts').
+# T / feature / hidden sizes are the scripts').  S0 (SBM plumbing) is sbm_dynamic_graph().
 CONFIGS = {
-    "S0": dict(T=10, N=500, edges_per_slice=1500, F0=16),                 # SBM-sized plumbing
     "S1": dict(T=95, N=6000, edges_per_slice=250),                        # Bitcoin-OTC-shaped
     "S2": dict(T=65, N=3800, edges_per_slice=2500, neg_per_pos=19),       # Reddit-LP-shaped
     "S3": dict(T=150, N=1000, edges_per_slice=500),                       # AMLSim-shaped
