@@ -18,6 +18,16 @@ inline int check_launch(const char* what) {
   return TMGCN_OK;
 }
 
+// Work counters for dynamically scheduled persistent kernels (pointwise.hip owns the pool).
+// Persistent blocks draw their next tile from a device counter instead of a static
+// blockIdx-strided assignment: when some blocks are not resident from the start (another
+// kernel — e.g. RCCL's all-to-all on a side stream — holds CUs), the late blocks simply draw
+// fewer tiles instead of serialising a full share behind the others; skewed row lengths balance
+// the same way.  acquire_tile_counter() returns a zeroed counter (memset enqueued on `stream`),
+// rotating through a pool so that launches in flight on different streams do not share one.
+unsigned int* acquire_tile_counters(hipStream_t stream, int n);  // n consecutive zeroed counters
+inline unsigned int* acquire_tile_counter(hipStream_t stream) { return acquire_tile_counters(stream, 1); }
+
 #define TMGCN_REQUIRE(cond, ...)            \
   do {                                      \
     if (!(cond)) {                          \

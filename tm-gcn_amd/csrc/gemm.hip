@@ -38,6 +38,7 @@ struct GemmArgs {
   int32_t act;
   int64_t tiles_per_batch;
   int64_t n_tiles;
+  unsigned int* tile_counter;  // dynamic tile scheduling (common.h); one counter per blockIdx.y strip
 };
 
 __device__ __forceinline__ float wop(const GemmArgs& a, const float* Wb, int k, int n) {
@@ -57,8 +58,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
   float wreg[KC / 8][4];
   int64_t cur_batch = -1;
   const int n_kchunks = (a.K + KC - 1) / KC;
+  __shared__ unsigned int s_tile;
 
-  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter + blockIdx.y, 1u);
+    __syncthreads();
+    const int64_t tile = s_tile;
+    if (tile >= a.n_tiles) break;
     const int64_t batch = tile / a.tiles_per_batch;
     const int64_t row0 = batch * batch_rows + (tile % a.tiles_per_batch) * BM;
     int64_t row_end = (batch + 1) * batch_rows;
@@ -140,6 +146,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
         }
       }
     }
+    __syncthreads();  // everyone has read s_tile and the LDS tile before the next draw
   }
 }
 
@@ -374,7 +381,7 @@ extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* p
   if (R == 0) return TMGCN_OK;
   TMGCN_REQUIRE(A && W && Y, "gemm: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  GemmArgs a{A, W, Y, pre_act, R, K, Nf, trans_w, rows_per_batch, w_batch_stride, act, 0, 0};
+  GemmArgs a{A, W, Y, pre_act, R, K, Nf, trans_w, rows_per_batch, w_batch_stride, act, 0, 0, nullptr};
   if (use_small(K, Nf)) {
     const int Nfp = (Nf + 7) & ~7;
     const int64_t br = rows_per_batch ? rows_per_batch : R;
@@ -391,6 +398,10 @@ extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* p
   a.tiles_per_batch = (br + BM - 1) / BM;
   a.n_tiles = nb * a.tiles_per_batch;
   const unsigned gy = (unsigned)((Nf + 127) / 128);
+  TMGCN_REQUIRE(a.n_tiles < (int64_t)0x7fffffff && gy <= 64, "gemm: shape too large for the tile scheduler");
+  // gy consecutive counters of the pool (acquire zeroes one; take gy of them in a row)
+  a.tile_counter = acquire_tile_counters(st, (int)gy);
+  TMGCN_REQUIRE(a.tile_counter, "gemm: cannot set up the tile counters");
   int64_t gx = persistent_grid(gemm_mfma_kernel, 256);
   if (gx > a.n_tiles) gx = a.n_tiles;
   hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);

@@ -29,6 +29,7 @@ struct MtArgs {
   int64_t C;  // columns (floats)
   int32_t rows_per_chunk;
   int32_t x_tl, y_tl;  // group-interleaved row storage (0 = plain row order), see tmgcn.h
+  unsigned int* tile_counter;  // dense MFMA kernel: dynamic column-tile scheduling (common.h)
 };
 
 // storage position of logical row k of a tensor with T rows stored in groups of tl rows:
@@ -257,9 +258,14 @@ __global__ __launch_bounds__(256) void mtransform_dense_mfma_kernel(MtArgs a) {
 
   const int64_t n_tiles = (a.C + kDenseCols - 1) / kDenseCols;
   const bool vec = (a.C % 4 == 0) && (reinterpret_cast<uintptr_t>(a.X) % 16 == 0);
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t c0 = tile * kDenseCols;
+  __shared__ unsigned int s_tile;
+  for (;;) {
+    __syncthreads();  // previous tile's LDS reads and s_tile reads are done
+    if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter + blockIdx.y, 1u);
     __syncthreads();
+    const int64_t tile = s_tile;
+    if (tile >= n_tiles) break;
+    const int64_t c0 = tile * kDenseCols;
     if (vec) {
       for (int t = threadIdx.x; t < a.T_in * (kDenseCols / 4); t += 256) {
         const int j = t / (kDenseCols / 4), q = t % (kDenseCols / 4);
@@ -343,6 +349,15 @@ static int dispatch(MtArgs a, hipStream_t st) {
     const size_t smem = (size_t)a.T_in * kDenseCols * sizeof(float);
     const unsigned gy = (unsigned)((a.T_out + 127) / 128);
     const int64_t n_tiles = (a.C + kDenseCols - 1) / kDenseCols;
+    if (gy > 64 || n_tiles >= (int64_t)0x7fffffff) {
+      set_error("mtransform: shape too large for the dense tile scheduler");
+      return TMGCN_ERR_INVALID;
+    }
+    a.tile_counter = acquire_tile_counters(st, (int)gy);
+    if (!a.tile_counter) {
+      set_error("mtransform: cannot set up the tile counters");
+      return TMGCN_ERR_LAUNCH;
+    }
     if (a.T_in <= 128) {
       int64_t gx = persistent_grid(mtransform_dense_mfma_kernel<64>, 256, smem);
       if (gx > n_tiles) gx = n_tiles;
@@ -384,7 +399,7 @@ extern "C" int tmgcn_mtransform_f32(const float* M, int32_t Tm, int32_t ldm, int
                 "mtransform: y_group_rows=%d does not divide T_out=%d", y_group_rows, T_out);
   if (band_lo > Tm) band_lo = Tm;
   if (band_hi > Tm) band_hi = Tm;
-  MtArgs a{M, ldm, transpose, row_off, col_off, T_out, T_in, band_lo, band_hi, X, Y, C, T_out, x_group_rows, y_group_rows};
+  MtArgs a{M, ldm, transpose, row_off, col_off, T_out, T_in, band_lo, band_hi, X, Y, C, T_out, x_group_rows, y_group_rows, nullptr};
   const bool vec_ok = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
   return vec_ok ? dispatch<4>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);

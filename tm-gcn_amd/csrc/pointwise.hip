@@ -1,11 +1,34 @@
 // P5 — pointwise non-linearity between layers (embedding_help_functions.py:284-289, 332-334,
 // 486) and the library's error plumbing.  Pure HBM streams: 16 B per lane.
 #include <stdarg.h>
+#include <atomic>
 #include "common.h"
 
 namespace tmgcn {
 
 static thread_local char g_err[512] = "";
+
+constexpr int kCounterPool = 4096;  // 64 groups of 64: launches in flight on different streams never share a group
+constexpr int kMaxDevices = 16;
+__device__ unsigned int g_tile_counters[kCounterPool];
+
+unsigned int* acquire_tile_counters(hipStream_t stream, int n) {
+  if (n < 1 || n > 64) return nullptr;
+  static unsigned int* base[kMaxDevices] = {nullptr};
+  static std::atomic<unsigned> next{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= kMaxDevices) dev = 0;
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tile_counters)) != hipSuccess) return nullptr;
+    base[dev] = static_cast<unsigned int*>(p);
+  }
+  // slots are handed out in aligned groups of 64 so that n consecutive counters never wrap
+  unsigned int* c = base[dev] + (next.fetch_add(1) % (kCounterPool / 64)) * 64;
+  if (hipMemsetAsync(c, 0, sizeof(unsigned int) * n, stream) != hipSuccess) return nullptr;
+  return c;
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;

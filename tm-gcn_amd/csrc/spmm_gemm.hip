@@ -56,6 +56,7 @@ struct FusedArgs {
   int32_t act;
   int64_t tiles_per_batch;
   int64_t n_tiles;
+  unsigned int* tile_counter;  // dynamic tile scheduling (common.h)
 };
 
 template <int LPR, int U, int NJ>  // NJ = K / 8 (K is a multiple of 8 here)
@@ -72,8 +73,14 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
 
   float wreg[NJ][4];
   int64_t cur_batch = -1;
+  __shared__ unsigned int s_tile;
 
-  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  for (;;) {
+    // next tile from the device counter (ascending, so resident blocks stay inside one slice)
+    if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter, 1u);
+    __syncthreads();
+    const int64_t tile = s_tile;
+    if (tile >= a.n_tiles) break;
     const int64_t batch = tile / a.tiles_per_batch;
     const int64_t row0 = batch * batch_rows + (tile % a.tiles_per_batch) * FBM;
     int64_t row_end = (batch + 1) * batch_rows;
@@ -249,7 +256,7 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
   TMGCN_REQUIRE(n_rows % N == 0, "spmm_gemm: n_rows=%lld is not a multiple of N=%d", (long long)n_rows, N);
   if (fused_small_ok(K, Nf)) {
     FusedArgs s{rowptr, col, val, reinterpret_cast<const float4*>(X), n_rows, N, K, W, Nf, trans_w,
-                rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0};
+                rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0, nullptr};
     // lanes per row from the average row length (as tmgcn_spmm_csr_batched_f32_hint does)
     int64_t nnz_host_unknown = -1;
     (void)nnz_host_unknown;
@@ -267,11 +274,14 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
   TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 && (!AX || reinterpret_cast<uintptr_t>(AX) % 16 == 0),
                 "spmm_gemm: X / AX must be 16-byte aligned");
   FusedArgs a{rowptr, col, val, reinterpret_cast<const float4*>(X), n_rows, N, K, W, Nf, trans_w,
-              rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0};
+              rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0, nullptr};
   const int64_t br = rows_per_batch ? rows_per_batch : n_rows;
   const int64_t nb = (n_rows + br - 1) / br;
   a.tiles_per_batch = (br + FBM - 1) / FBM;
   a.n_tiles = nb * a.tiles_per_batch;
+  TMGCN_REQUIRE(a.n_tiles < (int64_t)0x7fffffff, "spmm_gemm: too many row tiles");
+  a.tile_counter = acquire_tile_counter((hipStream_t)stream);
+  TMGCN_REQUIRE(a.tile_counter, "spmm_gemm: cannot set up the tile counter");
   // persistent blocks: up to 4 per CU (LDS 33.8 KB each); tiles are dealt round-robin so the
   // blocks resident at any moment work on neighbouring rows of the same slice
   hipStream_t st = (hipStream_t)stream;
