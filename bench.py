@@ -206,6 +206,7 @@ def main():
                          "traffic": traffic, "bytes_per_edge_slice": bytes_per_unit,
                          "avg_launch_ms": sp["avg_ms"]},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
+            "peak_hbm_gb_rank0": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
         }
         if "gemm_dW" in kt:
             # the one GEMM that still runs as its own kernel (dW = AXᵀ·dY, exact-f32 MFMA); the

@@ -37,17 +37,28 @@ template <int LPR, int U>
 __global__ __launch_bounds__(256) void spmm_vec4_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float4* __restrict__ X, float4* __restrict__ Y,
-    int64_t n_rows, int32_t N, int32_t F4, int32_t rows_per_block) {
+    int64_t n_rows, int32_t N, int32_t F4, int32_t rows_per_block, unsigned int* tile_counter) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
-  int64_t r_end = r_begin + rows_per_block;
-  if (r_end > n_rows) r_end = n_rows;
-  for (int64_t r = r_begin + wave; r < r_end; r += 4) {
-    const int64_t slice = r / N;
-    const float4 acc = gather_row<LPR, U>(col, val, X + slice * (int64_t)N * F4, rowptr[r],
-                                          rowptr[r + 1], F4, lane);
-    if (lane < LPR && lane < F4) store_f4(&Y[r * F4 + lane], acc);
+  __shared__ unsigned int s_tile;
+  const int64_t n_tiles = (n_rows + rows_per_block - 1) / rows_per_block;
+  for (;;) {
+    // persistent blocks draw 64-row tiles from a device counter (ascending: resident blocks stay
+    // inside one slice of X); see common.h
+    __syncthreads();
+    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
+    __syncthreads();
+    const int64_t tile = s_tile;
+    if (tile >= n_tiles) break;
+    const int64_t r_begin = tile * rows_per_block;
+    int64_t r_end = r_begin + rows_per_block;
+    if (r_end > n_rows) r_end = n_rows;
+    for (int64_t r = r_begin + wave; r < r_end; r += 4) {
+      const int64_t slice = r / N;
+      const float4 acc = gather_row<LPR, U>(col, val, X + slice * (int64_t)N * F4, rowptr[r],
+                                            rowptr[r + 1], F4, lane);
+      if (lane < LPR && lane < F4) store_f4(&Y[r * F4 + lane], acc);
+    }
   }
 }
 
@@ -205,14 +216,20 @@ extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int3
     int lpr = 4;
     while (lpr < F4) lpr <<= 1;
     const int rows_per_block = TMGCN_SPMM_RPB;
-    const unsigned grid = (unsigned)((n_rows + rows_per_block - 1) / rows_per_block);
+    const int64_t n_tiles = (n_rows + rows_per_block - 1) / rows_per_block;
+    TMGCN_REQUIRE(n_tiles < (int64_t)0x7fffffff, "spmm: too many row tiles");
+    unsigned int* counter = acquire_tile_counter(st);
+    TMGCN_REQUIRE(counter, "spmm: cannot set up the tile counter");
     const float4* X4 = reinterpret_cast<const float4*>(X);
     float4* Y4 = reinterpret_cast<float4*>(Y);
 #define TMGCN_VEC_CASE(L, UU)                                                                \
-  case L:                                                                                    \
-    hipLaunchKernelGGL((spmm_vec4_kernel<L, UU>), dim3(grid), dim3(256), 0, st, rowptr, col, \
-                       val, X4, Y4, n_rows, N, F4, rows_per_block);                          \
-    break;
+  case L: {                                                                                  \
+    int64_t gx = 2 * (int64_t)persistent_grid(spmm_vec4_kernel<L, UU>, 256);                 \
+    if (gx > n_tiles) gx = n_tiles;                                                          \
+    hipLaunchKernelGGL((spmm_vec4_kernel<L, UU>), dim3((unsigned)gx), dim3(256), 0, st,      \
+                       rowptr, col, val, X4, Y4, n_rows, N, F4, rows_per_block, counter);    \
+    break;                                                                                   \
+  }
     switch (lpr) {
       TMGCN_VEC_CASE(4, 2)
       TMGCN_VEC_CASE(8, 2)
