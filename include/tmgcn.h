@@ -96,7 +96,7 @@ int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int32_t* col, c
  * Âᵀ(dY·Wᵀ) = (Âᵀ·dY)·Wᵀ.  X is [n_rows][K]; W, trans_w, rows_per_batch, w_batch_stride, act,
  * pre_act as in tmgcn_gemm_f32.  AX (optional, may be NULL) receives the SpMM result
  * [n_rows][K] itself (needed for dW).  Supported when tmgcn_spmm_gemm_supported(K, Nf) != 0
- * (K in {16, 32, 64, 128} with Nf <= 128 — MFMA epilogue — or K in {1,2,3,4,6,8} with Nf <= 16 —
+ * (K a multiple of 8 in [16, 128] with Nf <= 128 — MFMA epilogue — or K in {1,2,3,4,6,8} with Nf <= 16 —
  * the reference's real widths, FMA epilogue); otherwise call the two kernels separately.
  */
 int tmgcn_spmm_gemm_supported(int32_t K, int32_t Nf);

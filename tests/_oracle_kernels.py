@@ -49,7 +49,7 @@ class OracleKernels:
         return orc.slice_spmm(_view_coo(A), X.double())
 
     def spmm_gemm_supported(self, K, Nf):
-        return (K in (16, 32, 64, 128) and Nf <= 128) or (K in (1, 2, 3, 4, 6, 8) and Nf <= 16)  # the device rule
+        return (K % 8 == 0 and 16 <= K <= 128 and Nf <= 128) or (K in (1, 2, 3, 4, 6, 8) and Nf <= 16)  # the device rule
 
     def spmm_gemm(self, A, X, W, trans_w=False, act=None, want_ax=False, want_pre=False, tag=None, out=None):
         lists = _view_coo(A)

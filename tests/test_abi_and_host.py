@@ -133,3 +133,49 @@ def test_synth_configs_have_the_scripts_shapes():
     a = synth.device_er_csr(2, 1000, 32, "cpu", first_slice=5)
     b = synth.device_er_csr(1, 1000, 32, "cpu", first_slice=6)
     assert a.nnz == 2 * 1000 * 33 and torch.equal(a.slices(1, 2).col, b.col)  # seeded by global slice index
+
+
+# ------------------------------------------------------------------ property-based (hypothesis)
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 4), st.integers(1, 9), st.lists(st.tuples(st.integers(0, 3), st.integers(0, 8), st.integers(0, 8),
+                                                                  st.floats(-4, 4, allow_nan=False, width=32)), max_size=60))
+def test_batched_csr_properties(T, N, entries):
+    """For any batched COO (duplicates, empty rows/slices, any order): the CSR reproduces the dense
+    scatter-add, rowptr is monotone with rowptr[-1] = nnz, columns are sorted inside rows, the
+    transpose is the dense transpose, slices() and to_coo_list() round-trip."""
+    entries = [(k % T, i % N, j % N, v) for k, i, j, v in entries]
+    k = torch.tensor([e[0] for e in entries], dtype=torch.long)
+    i = torch.tensor([e[1] for e in entries], dtype=torch.long)
+    j = torch.tensor([e[2] for e in entries], dtype=torch.long)
+    v = torch.tensor([e[3] for e in entries], dtype=torch.float32)
+    csr = BatchedCSR.from_coo(k, i, j, v, T, N)
+    dense = torch.zeros(T, N, N)
+    dense.index_put_((k, i, j), v, accumulate=True)
+    assert torch.allclose(csr.to_dense(), dense, atol=1e-5)
+    assert int(csr.rowptr[0]) == 0 and int(csr.rowptr[-1]) == csr.nnz == len(entries)
+    assert bool((csr.rowptr[1:] >= csr.rowptr[:-1]).all())
+    rid = csr.row_ids()
+    same = rid[1:] == rid[:-1]
+    assert bool((csr.col[1:][same] >= csr.col[:-1][same]).all())
+    assert torch.allclose(csr.transpose().to_dense(), dense.transpose(1, 2), atol=1e-5)
+    for a in range(T):
+        assert torch.allclose(csr.slices(a, a + 1).to_dense()[0], dense[a], atol=1e-5)
+    back = csr.to_coo_list(torch.float32)
+    assert all(torch.allclose(b.to_dense(), dense[t], atol=1e-5) for t, b in enumerate(back))
+    views = csr.slice_views()
+    assert sum(vw.nnz for vw in views) == csr.nnz and all(vw.T == 1 for vw in views)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 40), st.integers(0, 45), st.integers(0, 45))
+def test_moperator_band_is_tight(T, lo, hi):
+    """band_lo / band_hi are exactly the extent of the non-zeros, for any banded operator."""
+    M = torch.zeros(T, T, dtype=torch.float64)
+    for a in range(T):
+        for b in range(max(0, a - lo), min(T, a + hi + 1)):
+            M[a, b] = 1.0 + a + b
+    op = ops.MOperator(M, "cpu")
+    assert op.band_lo == min(lo, T - 1) and op.band_hi == min(hi, T - 1)

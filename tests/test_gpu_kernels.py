@@ -211,7 +211,7 @@ def test_errors_are_runtime_errors():
 
 
 # ------------------------------------------------------------------------------------- P2+P3 fused
-@pytest.mark.parametrize("K", [16, 32, 64, 128])
+@pytest.mark.parametrize("K", [16, 24, 32, 48, 64, 96, 120, 128])
 @pytest.mark.parametrize("Nf", [1, 6, 32, 100, 128])
 @pytest.mark.parametrize("trans_w,per_slice", [(False, False), (True, False), (False, True)])
 def test_spmm_gemm_fused(K, Nf, trans_w, per_slice):

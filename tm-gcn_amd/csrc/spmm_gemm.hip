@@ -237,7 +237,7 @@ static bool fused_small_ok(int K, int Nf) {
 using namespace tmgcn;
 
 extern "C" int tmgcn_spmm_gemm_supported(int32_t K, int32_t Nf) {
-  return (((K == 16 || K == 32 || K == 64 || K == 128) && Nf >= 1 && Nf <= 128) || fused_small_ok(K, Nf)) ? 1 : 0;
+  return ((K % 8 == 0 && K >= 16 && K <= FKC && Nf >= 1 && Nf <= 128) || fused_small_ok(K, Nf)) ? 1 : 0;
 }
 
 extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* val,
@@ -247,7 +247,7 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
                                     float* Y, float* AX, float* pre_act, void* stream) {
   TMGCN_REQUIRE(n_rows >= 0 && N > 0, "spmm_gemm: bad shape n_rows=%lld N=%d", (long long)n_rows, N);
   TMGCN_REQUIRE(tmgcn_spmm_gemm_supported(K, Nf),
-                "spmm_gemm: unsupported widths K=%d Nf=%d (need K in {16,32,64,128} with Nf <= 128, or K in {1,2,3,4,6,8} with Nf <= 16); "
+                "spmm_gemm: unsupported widths K=%d Nf=%d (need K a multiple of 8 in [16,128] with Nf <= 128, or K in {1,2,3,4,6,8} with Nf <= 16); "
                 "use tmgcn_spmm_csr_batched_f32 + tmgcn_gemm_f32", K, Nf);
   TMGCN_REQUIRE(act >= TMGCN_ACT_NONE && act <= TMGCN_ACT_SELU, "spmm_gemm: unknown activation %d", act);
   TMGCN_REQUIRE(rows_per_batch >= 0, "spmm_gemm: negative rows_per_batch");
@@ -291,10 +291,21 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
     hipLaunchKernelGGL((spmm_gemm_kernel<L, UU, KK / 8>), dim3((unsigned)gx), dim3(256), 0, st, a); \
     break;                                                                                       \
   }
-  switch (K) {
+  switch (K) {  // every multiple of 8 in [16, 128]; lanes per feature row = next power of two >= K/4
     TMGCN_FUSED_CASE(16, 4, 2)
+    TMGCN_FUSED_CASE(24, 8, 2)
     TMGCN_FUSED_CASE(32, 8, 2)
+    TMGCN_FUSED_CASE(40, 16, TMGCN_FUSED_U)
+    TMGCN_FUSED_CASE(48, 16, TMGCN_FUSED_U)
+    TMGCN_FUSED_CASE(56, 16, TMGCN_FUSED_U)
     TMGCN_FUSED_CASE(64, 16, TMGCN_FUSED_U)
+    TMGCN_FUSED_CASE(72, 32, TMGCN_FUSED_U)
+    TMGCN_FUSED_CASE(80, 32, TMGCN_FUSED_U)
+    TMGCN_FUSED_CASE(88, 32, TMGCN_FUSED_U)
+    TMGCN_FUSED_CASE(96, 32, TMGCN_FUSED_U)
+    TMGCN_FUSED_CASE(104, 32, TMGCN_FUSED_U)
+    TMGCN_FUSED_CASE(112, 32, TMGCN_FUSED_U)
+    TMGCN_FUSED_CASE(120, 32, TMGCN_FUSED_U)
     TMGCN_FUSED_CASE(128, 32, TMGCN_FUSED_U)
   }
 #undef TMGCN_FUSED_CASE

@@ -434,7 +434,7 @@ def feature_gemm(A: torch.Tensor, W: torch.Tensor, act=None) -> torch.Tensor:
 
 def spmm_feature_gemm(A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, act=None, fuse: Optional[bool] = None):
     """P2 then P3 (+P5): act((Â ⋆ X) · W).  One fused launch when the kernel supports the
-    widths (K in {16,32,64,128} with Nf <= 128, or K in {1,2,3,4,6,8} with Nf <= 16), else the two
+    widths (K a multiple of 8 in [16,128] with Nf <= 128, or K in {1,2,3,4,6,8} with Nf <= 16), else the two
     kernels back to back."""
     K, Nf = X.shape[-1], W.shape[-1]
     can = hasattr(kernels, "spmm_gemm_supported") and kernels.spmm_gemm_supported(K, Nf)
