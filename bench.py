@@ -212,7 +212,7 @@ def main():
             # the one GEMM that still runs as its own kernel (dW = AXᵀ·dY, exact-f32 MFMA); the
             # forward / dA GEMMs run inside the fused SpMM kernels, hidden under the gather
             tf = 2.0 * A.n_rows * F * F / (kt["gemm_dW"]["avg_ms"] * 1e-3) / 1e12
-            out["mfma"] = {"kernel": "gemm_dw_mfma_kernel (dW)", "bound": "mfma", "achieved": tf, "peak": 157.3,
+            out["mfma"] = {"kernel": "gemm_dw_lds_kernel (dW)", "bound": "mfma", "achieved": tf, "peak": 157.3,
                            "unit": "TFLOP/s", "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args)

@@ -11,10 +11,11 @@
 //                  ds_read_b128 feeds four MFMAs.
 //   gemm_small     thread-per-row FMA kernel for the reference's real sizes (2x6, 6x6, 12x2):
 //                  MFMA tiles would be >90 % padding there; the op is a pure HBM stream.
-//   gemm_dw_mfma   dW = AᵀdY.  The reduction index is the row r, so the MFMA A/B operands
-//                  are read straight from global memory with the feature index on the lane
-//                  (128-B coalesced segments, no LDS); row-chunk partial slabs are reduced
-//                  in a fixed order by a second kernel (no float atomics: reproducible).
+//   gemm_dw_lds    dW = AᵀdY.  The reduction index is the row r, so the MFMA operands have the
+//                  feature index on the lane; 32-row windows of A and dY are staged once per
+//                  block through LDS (full-line loads) and read back with conflict-free
+//                  ds_read_b32; row-chunk partial slabs are reduced in a fixed order by a
+//                  second kernel (no float atomics: reproducible).
 #include "common.h"
 
 namespace tmgcn {
@@ -206,7 +207,15 @@ struct DwArgs {
 };
 
 // grid: x = batch*chunks + chunk, y = 128x128 output tile (ky * n_tiles_n + ny)
-__global__ __launch_bounds__(256) void gemm_dw_mfma_kernel(DwArgs a) {
+// LDS-staged dW: the block stages DWT rows of A and dY (the 128-column windows of its output
+// tile) once with full-line loads; all four waves then read their MFMA operands from LDS with
+// conflict-free ds_read_b32 (lane = feature).  Without the staging every wave re-reads the same
+// dY rows through L1 (4x redundancy) and the kernel sits at 0.55 of the f32 MFMA rate, sensitive
+// to how many loads are in flight (deeper unrolling made it slower: L1 thrash).
+constexpr int DWT = 32;  // rows per LDS tile: 32 x (128 + 128) x 4 B = 32 KB
+__global__ __launch_bounds__(256) void gemm_dw_lds_kernel(DwArgs a) {
+  __shared__ float sA[DWT * 128];
+  __shared__ float sB[DWT * 128];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 31;
@@ -221,50 +230,65 @@ __global__ __launch_bounds__(256) void gemm_dw_mfma_kernel(DwArgs a) {
   const int64_t r0 = b0 + (int64_t)chunk * a.rows_per_chunk;
   int64_t r1 = r0 + a.rows_per_chunk;
   if (r1 > b1) r1 = b1;
+  const int kbase = kt * 128, nbase = nt * 128;
+  const bool vecA = a.K % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) % 16 == 0);
+  const bool vecB = a.Nf % 4 == 0 && (reinterpret_cast<uintptr_t>(a.dY) % 16 == 0);
 
-  const int k = kt * 128 + wave * 32 + li;  // A-operand feature on the lane
-  const bool k_ok = k < a.K;
-  int ncol[4];
-  bool n_ok[4];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
-    ncol[nb] = nt * 128 + nb * 32 + li;
-    n_ok[nb] = ncol[nb] < a.Nf;
-  }
   f32x16 acc[4];
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 
-#ifndef TMGCN_DW_UR
-#define TMGCN_DW_UR 4
-#endif
-  constexpr int UR = TMGCN_DW_UR;  // MFMA k-steps (row pairs) in flight
-  for (int64_t r = r0; r < r1; r += 2 * UR) {
-    float av[UR], bv[UR][4];
-#pragma unroll
-    for (int u = 0; u < UR; ++u) {
-      const int64_t rr = r + 2 * u + lh;
-      const bool ok = rr < r1;
-      av[u] = (ok && k_ok) ? a.A[rr * a.K + k] : 0.f;
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) bv[u][nb] = (ok && n_ok[nb]) ? a.dY[rr * a.Nf + ncol[nb]] : 0.f;
+  // (a register-prefetched variant of this loop measured the same 92.5 TF at 3 instead of 4 blocks
+  // per CU: with four blocks resident the staging of one overlaps the MFMAs of the others)
+  for (int64_t r = r0; r < r1; r += DWT) {
+    const int nr = (int)((r1 - r) < DWT ? (r1 - r) : DWT);
+    __syncthreads();  // previous tile consumed
+    // stage [nr][128] windows of A and dY (zero padded in rows and columns)
+    for (int t = threadIdx.x; t < DWT * 32; t += 256) {
+      const int i = t >> 5, q = (t & 31) * 4;
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+      if (i < nr) {
+        const float* ga = a.A + (r + i) * a.K + kbase + q;
+        const float* gb = a.dY + (r + i) * a.Nf + nbase + q;
+        if (vecA && kbase + q + 3 < a.K) va = *reinterpret_cast<const float4*>(ga);
+        else {
+          if (kbase + q < a.K) va.x = ga[0];
+          if (kbase + q + 1 < a.K) va.y = ga[1];
+          if (kbase + q + 2 < a.K) va.z = ga[2];
+          if (kbase + q + 3 < a.K) va.w = ga[3];
+        }
+        if (vecB && nbase + q + 3 < a.Nf) vb = *reinterpret_cast<const float4*>(gb);
+        else {
+          if (nbase + q < a.Nf) vb.x = gb[0];
+          if (nbase + q + 1 < a.Nf) vb.y = gb[1];
+          if (nbase + q + 2 < a.Nf) vb.z = gb[2];
+          if (nbase + q + 3 < a.Nf) vb.w = gb[3];
+        }
+      }
+      *reinterpret_cast<float4*>(&sA[i * 128 + q]) = va;
+      *reinterpret_cast<float4*>(&sB[i * 128 + q]) = vb;
     }
+    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < UR; ++u)
+    for (int s = 0; s < DWT / 2; ++s) {
+      const int row = 2 * s + lh;  // MFMA k index = row of the pair
+      const float av = sA[row * 128 + wave * 32 + li];
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][nb], acc[nb], 0, 0, 0);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sB[row * 128 + nb * 32 + li], acc[nb], 0, 0, 0);
+    }
   }
   float* P = a.part + ((int64_t)blockIdx.x) * a.K * a.Nf;
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
-    if (n_ok[nb]) {
+    const int n = nbase + nb * 32 + li;
+    if (n < a.Nf) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int kk = kt * 128 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-        if (kk < a.K) P[(int64_t)kk * a.Nf + ncol[nb]] = acc[nb][i];
+        const int kk = kbase + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        if (kk < a.K) P[(int64_t)kk * a.Nf + n] = acc[nb][i];
       }
     }
   }
@@ -445,7 +469,7 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
     hipLaunchKernelGGL(gemm_dw_small_kernel, dim3(gx), dim3(256), smem, st, a);
   } else {
     const unsigned gy = (unsigned)(((K + 127) / 128) * ((Nf + 127) / 128));
-    hipLaunchKernelGGL(gemm_dw_mfma_kernel, dim3(gx, gy), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(gemm_dw_lds_kernel, dim3(gx, gy), dim3(256), 0, st, a);
   }
   int rc = check_launch("gemm_dw");
   if (rc) return rc;
