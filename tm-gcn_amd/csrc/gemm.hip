@@ -212,7 +212,10 @@ struct DwArgs {
 // conflict-free ds_read_b32 (lane = feature).  Without the staging every wave re-reads the same
 // dY rows through L1 (4x redundancy) and the kernel sits at 0.55 of the f32 MFMA rate, sensitive
 // to how many loads are in flight (deeper unrolling made it slower: L1 thrash).
-constexpr int DWT = 32;  // rows per LDS tile: 32 x (128 + 128) x 4 B = 32 KB
+#ifndef TMGCN_DWT
+#define TMGCN_DWT 32
+#endif
+constexpr int DWT = TMGCN_DWT;  // rows per LDS tile: 32 x (128 + 128) x 4 B = 32 KB
 __global__ __launch_bounds__(256) void gemm_dw_lds_kernel(DwArgs a) {
   __shared__ float sA[DWT * 128];
   __shared__ float sB[DWT * 128];
