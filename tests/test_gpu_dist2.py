@@ -1,0 +1,83 @@
+"""GPU, world size 2 on ONE device (two processes share cuda:0, gloo transport for the CUDA tensors —
+RCCL refuses two ranks on one GPU): the slice-sharded layer with the REAL HIP kernels, the side
+stream and the per-slice pipelining, against the unsharded layer computed by the same kernels.
+Together with test_dist_gloo.py (CPU, oracle kernels) and test_gpu_dist1.py (RCCL, world 1) this is
+as close to a multi-GPU run as a single-GPU box allows."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, exchange, F0, F1, condensed, act, pipeline, ret):
+    try:
+        for p in (ROOT, HERE):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tmgcn_amd import synth
+        from tmgcn_amd.csr import BatchedCSR
+        from tmgcn_amd.dist import ShardedTMGCNLayer, even_bounds
+        T, N, b = 8, 96, 5
+        g = synth.dynamic_graph(T, N, edges_per_slice=4 * N, seed=7, no_diag=b, F0=F0)
+        gen = torch.Generator().manual_seed(3)
+        W0 = torch.randn(*(() if condensed else (T,)), F0, F1, generator=gen) * 0.3
+        dY0 = torch.randn(T, N, F1, generator=gen)
+        X0 = torch.from_numpy(g.X).float()
+        A = BatchedCSR.from_scipy_list(g.Ct, device="cuda")
+        # unsharded answer with the same kernels (no collectives)
+        ref_layer = ShardedTMGCNLayer(A, g.M, T, local_only=True)
+        assert not ref_layer.collective
+        Xr = X0.cuda().requires_grad_(True)
+        Wr = W0.cuda().requires_grad_(True)
+        Yr = ref_layer(Xr, Wr, act=act)
+        Yr.backward(dY0.cuda())
+        # sharded
+        k0, k1 = even_bounds(T, world)[rank]
+        n0, n1 = even_bounds(N, world)[rank]
+        layer = ShardedTMGCNLayer(A.slices(k0, k1), g.M, T, exchange=exchange, pipeline=pipeline)
+        assert layer.G == world and layer.collective
+        Xin = (X0[:, n0:n1] if exchange == "a2a" else X0[k0:k1]).contiguous().cuda().requires_grad_(True)
+        Wl = (W0 if condensed else W0[k0:k1]).contiguous().cuda().requires_grad_(True)
+        Y = layer(Xin, Wl, act=act)
+        Y.backward(dY0[k0:k1].contiguous().cuda())
+        torch.cuda.synchronize()
+
+        def close(a, b, what, tol=2e-5):
+            err = float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+            assert err <= tol, f"{what}: {err:.2e}"
+        close(Y.detach(), Yr.detach()[k0:k1], "Y")
+        close(Xin.grad, Xr.grad[:, n0:n1] if exchange == "a2a" else Xr.grad[k0:k1], "dX")
+        close(Wl.grad, Wr.grad if condensed else Wr.grad[k0:k1], "dW")
+        dist.barrier()
+        ret[rank] = "ok"
+    except Exception as e:
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange,F0,F1,pipeline", [("a2a", 16, 32, True),   # fused MFMA kernel, pipelined per-slice exchange
+                                                      ("a2a", 16, 32, False),  # same, exchange first
+                                                      ("a2a", 6, 6, True),     # fused small-F kernel, pipelined
+                                                      ("a2a", 5, 7, True),     # unfused widths
+                                                      ("allgather", 16, 32, True)])
+@pytest.mark.parametrize("condensed,act", [(True, None), (False, "selu")])
+def test_two_ranks_one_gpu(exchange, F0, F1, pipeline, condensed, act):
+    world = 2
+    port = 29700 + abs(hash((exchange, F0, pipeline, condensed))) % 250
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, exchange, F0, F1, condensed, act, pipeline, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", f"rank {r}:\n{ret.get(r)}"

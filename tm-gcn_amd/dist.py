@@ -229,8 +229,10 @@ class ShardedTMGCNLayer:
 
     def __init__(self, A_local: BatchedCSR, M, T: int, group=None, exchange: str = "a2a",
                  apply_m: bool = True, fuse: Optional[bool] = None, pipeline: bool = True,
-                 force_collectives: bool = False):
-        self.rank, self.G = _world(group)
+                 force_collectives: bool = False, local_only: bool = False):
+        # local_only: ignore any initialised process group (an unsharded layer inside a
+        # distributed job, e.g. to cross-check a sharded result)
+        self.rank, self.G = (0, 1) if local_only else _world(group)
         # force_collectives: run the exchange code at world size 1 too (exercises the RCCL path on
         # a single GPU; needs an initialised process group)
         self.collective = self.G > 1 or (force_collectives and dist.is_initialized())
