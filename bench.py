@@ -47,6 +47,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-fuse", action="store_true", help="run P2 and P3 as separate kernels")
     p.add_argument("--no-pipeline", action="store_true", help="exchange all slices before computing")
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                   "the single-device diagnostic below)")
+    p.add_argument("--single-device", action="store_true",
+                   help="diagnostic: all ranks share cuda:0 (needs --backend gloo; RCCL refuses it)")
     p.add_argument("--force-collectives", action="store_true",
                    help="run the exchange (RCCL) code path even at --gpus 1 (diagnostic)")
     p.add_argument("--cpu-nodes", type=int, default=250_000, help="N of the CPU-baseline sample")
@@ -103,6 +107,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -110,7 +116,10 @@ def main():
     if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from tmgcn_amd import _lib, ops, synth
     from tmgcn_amd.dist import ShardedTMGCNLayer
@@ -179,7 +188,9 @@ def main():
         # (then it also writes Y; only P2's own bytes are counted, conservatively)
         dom = "spmm_gemm" if "spmm_gemm" in kt else "spmm"
         sp = kt[dom]
-        achieved = bytes_per_unit * A.nnz / (sp["avg_ms"] * 1e-3) / 1e9
+        # one launch per step at N = 1; the pipelined multi-GPU path launches slice by slice
+        units_per_launch = A.nnz * args.steps / sp["launches"]
+        achieved = bytes_per_unit * units_per_launch / (sp["avg_ms"] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -203,7 +214,8 @@ def main():
                        "edge_slices_per_step": total_nnz},
             "roofline": {"kernel": "spmm_gemm_kernel (forward P2 + fused P3)" if dom == "spmm_gemm" else "spmm_vec4_kernel (forward P2)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "bytes_per_edge_slice": bytes_per_unit,
+                         "traffic": traffic if sp["launches"] == args.steps else None,
+                         "bytes_per_edge_slice": bytes_per_unit, "edge_slices_per_launch": units_per_launch,
                          "avg_launch_ms": sp["avg_ms"]},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
             "peak_hbm_gb_rank0": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
