@@ -256,3 +256,36 @@ def test_tiny_and_degenerate_inputs():
         ehf.EmbeddingGCN([a0], X, edges, M, hidden_feat=[3, 2], condensed_W=True, use_Minv=False)
     with pytest.raises(RuntimeError):
         ehf.EmbeddingGCN([a0, empty], X[:, :3], edges, M, hidden_feat=[3, 2], condensed_W=True, use_Minv=False)
+
+
+def test_graphed_train_step_wide_features():
+    """Graph capture also covers the persistent MFMA kernels (their tile counters are zeroed by a
+    memset node that is captured with the launch)."""
+    from tmgcn_amd import synth
+    from tmgcn_amd.graphs import GraphedTrainStep
+    from tmgcn_amd.losses import WeightedCrossEntropy
+    g = synth.dynamic_graph(T=6, N=300, edges_per_slice=600, seed=9, no_diag=4, F0=32)
+    At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
+    edges, tgt = torch.from_numpy(g.edges), torch.from_numpy(g.labels).cuda()
+
+    def build():
+        torch.manual_seed(2)
+        m = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=[64, 32, 2], condensed_W=True, use_Minv=False,
+                              apply_M_twice=True, nonlin2="relu")
+        with torch.no_grad():
+            for q in m.parameters():
+                q.mul_(0.1)
+        return m, torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9), WeightedCrossEntropy(torch.tensor([0.9, 0.1])).cuda()
+
+    m1, o1, c1 = build()
+    eager = []
+    for _ in range(3 + 5):
+        o1.zero_grad()
+        l = c1(m1(), tgt)
+        l.backward()
+        o1.step()
+        eager.append(float(l.detach()))
+    m2, o2, c2 = build()
+    step = GraphedTrainStep(m2, c2, o2, tgt, warmup=3)
+    graphed = [float(step().detach()) for _ in range(5)]
+    assert_close(np.array(graphed), np.array(eager[3:]), 1e-5, "graphed vs eager losses (wide)")
