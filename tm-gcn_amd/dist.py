@@ -207,10 +207,11 @@ class _PipelinedCore(torch.autograd.Function):
                         dist.all_to_all_single(dsend[kk], dXt[kk].view(G, Nl, F), group=layer.group)
                 else:
                     dist.all_to_all_single(dsend[kk], dXt[kk].view(G, Nl, F), group=layer.group)
-            if use_streams:
-                main.wait_stream(comm)
         if ctx.needs_input_grad[1]:
+            # dW does not depend on the exchange: it runs while the last slices are still leaving
             dW = K.gemm_dw(AX, dY, per_slice=per_slice_w)
+        if ctx.needs_input_grad[0] and dY.is_cuda:
+            torch.cuda.current_stream(dY.device).wait_stream(layer.comm_stream())
         return dsend, dW, None, None
 
 
