@@ -51,6 +51,8 @@ def parse():
                    "the single-device diagnostic below)")
     p.add_argument("--single-device", action="store_true",
                    help="diagnostic: all ranks share cuda:0 (needs --backend gloo; RCCL refuses it)")
+    p.add_argument("--grid-reserve", type=int, default=None,
+                   help="block slots the fused kernel leaves free for RCCL's kernels (default: the layer's choice)")
     p.add_argument("--force-collectives", action="store_true",
                    help="run the exchange (RCCL) code path even at --gpus 1 (diagnostic)")
     p.add_argument("--cpu-nodes", type=int, default=250_000, help="N of the CPU-baseline sample")
@@ -132,7 +134,8 @@ def main():
     A.transpose()  # backward operand, built once (plan time, not timed)
     M = synth.band_M(T, args.band, "matlab")
     layer = ShardedTMGCNLayer(A, M, T, group=None, exchange=args.exchange, fuse=False if args.no_fuse else None,
-                              pipeline=not args.no_pipeline, force_collectives=args.force_collectives)
+                              pipeline=not args.no_pipeline, force_collectives=args.force_collectives,
+                              grid_reserve=args.grid_reserve)
     shape = layer.input_shape(F)
     if layer.collective and args.exchange == "a2a":
         # node shard of the synthetic features: slice k seeded by k, columns of this rank's nodes
@@ -210,7 +213,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S4 TM-GCN layer fwd+bwd: {Tl} slices/GPU (T={T}), N={N}, "
                                    f"deg={args.deg}+self, F={F}->{F}, band-M b={args.band}, fp32",
-                       "exchange": args.exchange if layer.collective else "none",
+                       "exchange": args.exchange if layer.collective else "none", "grid_reserve": layer.grid_reserve,
                        "edge_slices_per_step": total_nnz},
             "roofline": {"kernel": "spmm_gemm_kernel (forward P2 + fused P3)" if dom == "spmm_gemm" else "spmm_vec4_kernel (forward P2)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

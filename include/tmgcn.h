@@ -46,6 +46,11 @@ enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SE
 
 int tmgcn_abi_version(void);
 const char* tmgcn_last_error(void);
+/* Process-wide tuning knobs (performance only, never results).
+ *   "persistent_grid_reserve"  block slots the persistent fused kernel leaves free (default 0);
+ *                              the sharded layer sets it so that RCCL's kernels on the side
+ *                              stream can become resident next to the compute kernel. */
+int tmgcn_config_set(const char* key, int64_t value);
 
 /* ---- P1: tube-fibre M-transform ------------------------------------------------
  * Replaces  t.matmul(self.M, X.reshape(self.T,-1)).reshape(X.size())

@@ -26,6 +26,7 @@ _i64 = C.c_int64
 SIGNATURES = {
     "tmgcn_abi_version": (C.c_int, []),
     "tmgcn_last_error": (C.c_char_p, []),
+    "tmgcn_config_set": (C.c_int, [C.c_char_p, _i64]),
     "tmgcn_mtransform_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_spmm_csr_batched_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_spmm_csr_batched_f32_hint": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, C.c_float, _p]),

@@ -1,6 +1,7 @@
 // P5 — pointwise non-linearity between layers (embedding_help_functions.py:284-289, 332-334,
 // 486) and the library's error plumbing.  Pure HBM streams: 16 B per lane.
 #include <stdarg.h>
+#include <string.h>
 #include <atomic>
 #include "common.h"
 
@@ -11,6 +12,9 @@ static thread_local char g_err[512] = "";
 constexpr int kCounterPool = 4096;  // 64 groups of 64: launches in flight on different streams never share a group
 constexpr int kMaxDevices = 16;
 __device__ unsigned int g_tile_counters[kCounterPool];
+
+static std::atomic<int> g_grid_reserve{0};
+int persistent_grid_reserve() { return g_grid_reserve.load(); }
 
 unsigned int* acquire_tile_counters(hipStream_t stream, int n) {
   if (n < 1 || n > 64) return nullptr;
@@ -93,6 +97,17 @@ static unsigned stream_grid(int64_t n) {
 using namespace tmgcn;
 
 extern "C" int tmgcn_abi_version(void) { return 1; }
+
+extern "C" int tmgcn_config_set(const char* key, int64_t value) {
+  TMGCN_REQUIRE(key, "config_set: null key");
+  if (strcmp(key, "persistent_grid_reserve") == 0) {
+    TMGCN_REQUIRE(value >= 0 && value <= 4096, "config_set: persistent_grid_reserve out of range");
+    g_grid_reserve.store((int)value);
+    return TMGCN_OK;
+  }
+  set_error("config_set: unknown key '%s'", key);
+  return TMGCN_ERR_INVALID;
+}
 extern "C" const char* tmgcn_last_error(void) { return g_err; }
 
 extern "C" int tmgcn_act_fwd_f32(const float* x, float* y, int64_t n, int32_t act, void* stream) {

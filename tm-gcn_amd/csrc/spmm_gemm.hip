@@ -286,7 +286,7 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
   hipStream_t st = (hipStream_t)stream;
 #define TMGCN_FUSED_CASE(KK, L, UU)                                                              \
   case KK: {                                                                                     \
-    int64_t gx = persistent_grid(spmm_gemm_kernel<L, UU, KK / 8>, 256);                          \
+    int64_t gx = persistent_grid_reserved(spmm_gemm_kernel<L, UU, KK / 8>, 256);                 \
     if (gx > a.n_tiles) gx = a.n_tiles;                                                          \
     hipLaunchKernelGGL((spmm_gemm_kernel<L, UU, KK / 8>), dim3((unsigned)gx), dim3(256), 0, st, a); \
     break;                                                                                       \

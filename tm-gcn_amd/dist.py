@@ -230,7 +230,7 @@ class ShardedTMGCNLayer:
 
     def __init__(self, A_local: BatchedCSR, M, T: int, group=None, exchange: str = "a2a",
                  apply_m: bool = True, fuse: Optional[bool] = None, pipeline: bool = True,
-                 force_collectives: bool = False, local_only: bool = False):
+                 force_collectives: bool = False, local_only: bool = False, grid_reserve: Optional[int] = None):
         # local_only: ignore any initialised process group (an unsharded layer inside a
         # distributed job, e.g. to cross-check a sharded result)
         self.rank, self.G = (0, 1) if local_only else _world(group)
@@ -238,6 +238,16 @@ class ShardedTMGCNLayer:
         # a single GPU; needs an initialised process group)
         self.collective = self.G > 1 or (force_collectives and dist.is_initialized())
         self.pipeline = pipeline
+        # RCCL's exchange kernels run on the side stream while the persistent fused kernel works;
+        # they can only become resident if that kernel does not hold every block slot.  One slot
+        # per CU (256 blocks; costs ~4 % of the gather with dynamic tile scheduling, measured at
+        # world size 1) is left free whenever a real exchange runs beside it.
+        if grid_reserve is None:
+            grid_reserve = 256 if (self.G > 1 and pipeline and exchange == "a2a") else 0
+        self.grid_reserve = grid_reserve
+        if grid_reserve and A_local.device.type == "cuda":
+            from . import _lib
+            _lib.check(_lib.load().tmgcn_config_set(b"persistent_grid_reserve", int(grid_reserve)), "tmgcn_config_set")
         self._comm_stream = None
         self._views = None
         self.group = group
