@@ -179,3 +179,23 @@ def test_moperator_band_is_tight(T, lo, hi):
             M[a, b] = 1.0 + a + b
     op = ops.MOperator(M, "cpu")
     assert op.band_lo == min(lo, T - 1) and op.band_hi == min(hi, T - 1)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/tmgcn.h compiles as C99 and a C program links against the
+    library and calls it (argument validation only — no device work without a GPU)."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "tmgcn.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '  if (tmgcn_abi_version() != 1) return 1;\n'
+                   '  if (tmgcn_spmm_gemm_supported(128, 128) != 1) return 2;\n'
+                   '  if (tmgcn_gemm_f32(0, 0, 0, 0, 10, 0, 4, 0, 0, 0, 0, 0) != TMGCN_ERR_INVALID) return 3;\n'
+                   '  printf("%s\\n", tmgcn_last_error());\n  return 0;\n}\n')
+    exe = tmp_path / "abi"
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", lib_dir, "-ltmgcn_hip", f"-Wl,-rpath,{lib_dir}"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gemm" in out.stdout
