@@ -19,7 +19,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tmgcn_amd.layers as ehf  # drop-in for `import embedding_help_functions as ehf`
-from tmgcn_amd import WeightedCrossEntropy, synth
+from tmgcn_amd import WeightedCrossEntropy, metrics, synth
 from tmgcn_amd.adjacency import build_adjacency
 from tmgcn_amd.graphs import GraphedTrainStep
 
@@ -30,13 +30,8 @@ alpha, lr, momentum = 0.9, 0.01, 0.9
 
 
 def f1_minority(logits, target):
-    """precision / recall / F1 with class 0 as the positive class (the scripts' convention)."""
-    guess = logits.argmax(dim=1)
-    tp = ((guess == 0) & (target == 0)).sum().double()
-    fp = ((guess == 0) & (target != 0)).sum().double()
-    fn = ((guess != 0) & (target == 0)).sum().double()
-    precision, recall = tp / (tp + fp), tp / (tp + fn)
-    return float(precision), float(recall), float(2 * precision * recall / (precision + recall))
+    """precision / recall / F1 with class 0 as the positive class (ehf.compute_f1, on the device)."""
+    return tuple(float(x) for x in metrics.compute_f1(logits.argmax(dim=1), target))
 
 
 def main():
