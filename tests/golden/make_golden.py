@@ -241,5 +241,28 @@ def g6():
         save(f"g6_sgd_{name}", seed=51, losses=np.array(losses), **final, **base)
 
 
+# ------------------------------------------------------------------------------ G8
+def g8():
+    """EmbeddingGCN_reg (ehf:359-423): regression head, MSE loss as in test_graph_SEIR.py."""
+    g = synth.dynamic_graph(9, 40, 60, seed=8, no_diag=3)
+    base = graph_inputs(g)
+    y = torch.randn(9, 40, generator=torch.Generator().manual_seed(80))
+    for condensed in (True, False):
+        torch.manual_seed(61)
+        m = ehf.EmbeddingGCN_reg(ref_list(g.Ct), torch.tensor(g.X), torch.tensor(g.M), hidden_feat=[6],
+                                 condensed_W=condensed, use_Minv=False)
+        p0 = {n.replace(".", "_") + "0": p.detach().numpy().copy() for n, p in m.named_parameters()}
+        out = m()
+        loss = torch.nn.MSELoss()(out, y)
+        m.zero_grad()
+        loss.backward()
+        grads = {"d" + n.replace(".", "_"): p.grad.detach().numpy().copy() for n, p in m.named_parameters()}
+        save(f"g8_gcn_reg_condensed{int(condensed)}", seed=61, out=out.detach().numpy(), y=y.numpy(), loss=float(loss),
+             **p0, **grads, **base)
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g4(); g5(); g6()
+    which = sys.argv[1:]
+    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g8", g8)):
+        if not which or name in which:
+            fn()

@@ -289,3 +289,24 @@ def test_graphed_train_step_wide_features():
     step = GraphedTrainStep(m2, c2, o2, tgt, warmup=3)
     graphed = [float(step().detach()) for _ in range(5)]
     assert_close(np.array(graphed), np.array(eager[3:]), 1e-5, "graphed vs eager losses (wide)")
+
+
+@pytest.mark.parametrize("name", golden_names("g8_"))
+def test_g8_gcn_reg(name):
+    """EmbeddingGCN_reg (ehf:359-423): output [T,N], parameters incl. the nn.Linear head drawn as in
+    the reference, gradients of an MSE loss."""
+    d = golden(name)
+    i = _inputs(d)
+    torch.manual_seed(int(d["seed"]))
+    m = ehf.EmbeddingGCN_reg(i["At"], i["X"], i["M"], hidden_feat=[6], condensed_W=d["W0"].ndim == 2, use_Minv=False)
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), d[n.replace(".", "_") + "0"]), n
+    out = m()
+    assert tuple(out.shape) == d["out"].shape
+    loss = torch.nn.MSELoss()(out, torch.from_numpy(d["y"]).cuda())
+    loss.backward()
+    assert_close(out, d["out"], TOL, name + " output")
+    assert abs(float(loss) - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    for n, p in m.named_parameters():
+        assert_close(p.grad, d["d" + n.replace(".", "_")], TOL, name + " d" + n)
+    assert torch.equal(m(i["At"], i["X"]), m())  # forward ignores its arguments (ehf:410-412)

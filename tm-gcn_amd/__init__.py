@@ -10,7 +10,7 @@ Python host side that keeps the reference's class contract:
 """
 from .csr import BatchedCSR  # noqa: F401
 from . import _lib, ops, layers  # noqa: F401
-from .layers import EmbeddingGCN, EmbeddingGCN2, EmbeddingKWGCN  # noqa: F401
+from .layers import EmbeddingGCN, EmbeddingGCN2, EmbeddingGCN_reg, EmbeddingKWGCN  # noqa: F401
 from .losses import WeightedCrossEntropy  # noqa: F401
 
-__all__ = ["BatchedCSR", "EmbeddingGCN", "EmbeddingGCN2", "EmbeddingKWGCN", "WeightedCrossEntropy", "ops", "layers"]
+__all__ = ["BatchedCSR", "EmbeddingGCN", "EmbeddingGCN2", "EmbeddingGCN_reg", "EmbeddingKWGCN", "WeightedCrossEntropy", "ops", "layers"]

@@ -5,6 +5,7 @@ draw order and ``__call__`` contract as the reference's ``embedding_help_functio
     EmbeddingGCN    ehf:156-234   1-layer TM-GCN
     EmbeddingGCN2   ehf:236-357   2-layer TM-GCN (three layer-2 variants)
     EmbeddingKWGCN  ehf:425-497   baseline GCN without the M-product, 1 or 2 layers
+    EmbeddingGCN_reg ehf:359-423  1-layer TM-GCN + per-node linear regression head (SEIR scripts)
 
 Contract kept from the reference
   * ``At`` is a Python list of T sparse COO matrices (or an already built ``BatchedCSR``),
@@ -118,6 +119,36 @@ class EmbeddingGCN(nn.Module):
         if self.use_Minv:
             Y = ops.m_transform(Y, self.Minv)                                # ehf:224
         return _edge_head(Y, eidx, _w(self.U))
+
+
+class EmbeddingGCN_reg(nn.Module):
+    """1-layer TM-GCN with a linear regression head per node (ehf:359-423; the SEIR experiments).
+    As in the reference, ``forward`` ignores its arguments and always uses the tensors cached at
+    construction (ehf:410-412), and returns [T, N]."""
+
+    def __init__(self, At: AdjLike, X: torch.Tensor, M: torch.Tensor, hidden_feat=[2, 2], condensed_W=False,
+                 use_Minv=True, device=None):
+        super().__init__()
+        dev = torch.device(device) if device is not None else _default_device()
+        self.use_Minv = use_Minv
+        self.T, self.N = int(X.shape[0]), int(X.shape[1])
+        self.F = [int(X.shape[-1])] + list(hidden_feat)
+        self.Mop = ops.MOperator(M, dev)
+        if self.Mop.T != self.T:
+            raise RuntimeError(f"M is {self.Mop.T}x{self.Mop.T} but X has T={self.T}")
+        if use_Minv:
+            self.Minv = self.Mop.inverse()
+        w_shape = (self.F[0], self.F[1]) if condensed_W else (self.T, self.F[0], self.F[1])
+        self.W = _param(torch.randn(*w_shape), dev, torch.float32)          # ehf:392/394
+        self.lin1 = nn.Linear(self.F[1], 1).to(dev)                         # ehf:395 (initialised on the CPU generator)
+        self.AtXt = ops.spmm(_adj(At, self.N, dev), ops.m_transform(_feat(X, dev), self.Mop))  # ehf:398
+        self.dev = dev
+
+    def forward(self, At=None, X=None):
+        Y = ops.feature_gemm(self.AtXt, self.W)                               # ehf:415
+        if self.use_Minv:
+            Y = ops.m_transform(Y, self.Minv)                                # ehf:417
+        return self.lin1(Y).squeeze(2)                                       # ehf:421-423
 
 
 class EmbeddingGCN2(nn.Module):
