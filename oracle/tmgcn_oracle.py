@@ -99,6 +99,14 @@ def gcn_forward(AtXt, W, U, src, dst, Minv: Optional[torch.Tensor] = None):
     return edge_head(Y, src, dst, U)
 
 
+def gcn_reg_forward(AtXt, W, lin_weight, lin_bias, Minv: Optional[torch.Tensor] = None):
+    """EmbeddingGCN_reg.forward, ehf:410-423: per-node linear head on the 1-layer embedding -> [T, N]."""
+    Y = torch.matmul(AtXt, W)
+    if Minv is not None:
+        Y = m_transform(Minv, Y)
+    return torch.nn.functional.linear(Y, lin_weight, lin_bias).squeeze(2)
+
+
 def gcn2_forward(AtXt, At_train, M, W1, W2, U, src, dst, nonlin="relu", use_Minv=False,
                  apply_M_twice=False, apply_M_three_times=False, Minv=None):
     """EmbeddingGCN2.forward, ehf:325-357.  `At_train` is self.At: layer 2 always uses the

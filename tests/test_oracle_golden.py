@@ -201,3 +201,19 @@ def test_S0_sbm_plumbing_config_on_cpu():
     Z = (spm(mt(Y)) @ p["W2"].double()).reshape(-1, 6)
     ref = torch.cat((Z[src], Z[dst]), 1) @ p["U"].double()
     assert_close(out, ref, 1e-5, "S0 SBM 2-layer logits")
+
+
+@pytest.mark.parametrize("name", golden_names("g8_"))
+def test_g8_gcn_reg(name):
+    d = golden(name)
+    i = _inputs(d)
+    W = torch.from_numpy(d["W0"]).requires_grad_(True)
+    lw = torch.from_numpy(d["lin1_weight0"]).requires_grad_(True)
+    lb = torch.from_numpy(d["lin1_bias0"]).requires_grad_(True)
+    out = orc.gcn_reg_forward(orc.compute_AtXt(i["M"], i["At"], i["X"]), W, lw, lb)
+    loss = torch.nn.MSELoss()(out, torch.from_numpy(d["y"]))
+    loss.backward()
+    assert_close(out.detach(), d["out"], 1e-6, name)
+    assert_close(W.grad, d["dW"], 2e-6, name + " dW")
+    assert_close(lw.grad, d["dlin1_weight"], 2e-6, name + " dlin1.weight")
+    assert_close(lb.grad, d["dlin1_bias"], 2e-6, name + " dlin1.bias")
