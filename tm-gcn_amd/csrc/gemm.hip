@@ -274,13 +274,38 @@ __global__ __launch_bounds__(256) void gemm_dw_lds_kernel(DwArgs a) {
       *reinterpret_cast<float4*>(&sB[i * 128 + q]) = vb;
     }
     __syncthreads();
+    // operands of 4 row pairs are read from LDS one group ahead of the 16 MFMAs that use them
+    // (left to itself hipcc emits ds_read -> s_waitcnt lgkmcnt(0) -> 2 MFMAs with one register
+    // pair, exposing the LDS latency 32 times per tile)
+    constexpr int GS = 2;                 // row pairs per group (4 costs a wave of occupancy: 136 VGPRs)
+    constexpr int NG = DWT / 2 / GS;      // groups per tile
+    float av[2][GS], bv[2][GS][4];
+    const float* pA = sA + lh * 128 + wave * 32 + li;
+    const float* pB = sB + lh * 128 + li;
 #pragma unroll
-    for (int s = 0; s < DWT / 2; ++s) {
-      const int row = 2 * s + lh;  // MFMA k index = row of the pair
-      const float av = sA[row * 128 + wave * 32 + li];
+    for (int u = 0; u < GS; ++u) {
+      av[0][u] = pA[(2 * u) * 128];
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, sB[row * 128 + nb * 32 + li], acc[nb], 0, 0, 0);
+      for (int nb = 0; nb < 4; ++nb) bv[0][u][nb] = pB[(2 * u) * 128 + nb * 32];
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+          av[nxt][u] = pA[(2 * ((g + 1) * GS + u)) * 128];
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) bv[nxt][u][nb] = pB[(2 * ((g + 1) * GS + u)) * 128 + nb * 32];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the next group's reads ahead of this group's MFMAs
+#pragma unroll
+      for (int u = 0; u < GS; ++u)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][u], bv[cur][u][nb], acc[nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   float* P = a.part + ((int64_t)blockIdx.x) * a.K * a.Nf;
