@@ -1,0 +1,104 @@
+"""A whole link-prediction experiment in the shape of the reference's
+experiment_*_our_link_prediction.py, run with ``import tmgcn_amd.ehf as ehf`` as the only change and
+everything else (host-side targets, class weights, criterion, optimiser, metric calls, [-K_val:]
+slicing) as the scripts have it, against fixture G9: what the real reference produced for the
+committed ``g9_saved_content.mat`` (tests/golden/make_golden_data.py)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import tmgcn_amd.ehf as ehf
+from _util import GOLDEN, assert_close, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("no_layers", [1, 2])
+def test_link_prediction_script_flow(no_layers):
+    g9 = golden("g9_data")
+    S_train, S_val, S_test = (int(s) for s in g9["S"])
+    beta1, beta2, cutoff = 3, 2, 6
+    lr, momentum, alpha = 0.01, 0.9, 0.9
+
+    A, A_labels, Ct_train_2, Ct_val_2, Ct_test_2, N, M = ehf.load_data(GOLDEN + "/", "g9_saved_content.mat",
+                                                                      S_train, S_val, S_test, transformed=True)
+    X_train, X_val, X_test = ehf.create_node_features(A, S_train, S_val, S_test, same_block_size=True)
+    edges = A_labels._indices()
+    random.seed(7)
+    edges_aug, labels = ehf.augment_edges(edges, N, beta1, beta2, cutoff)
+    assert np.array_equal(edges_aug.numpy(), g9["edges_aug"])
+    (edges_train, target_train, e_train, edges_val, target_val, e_val, K_val,
+     edges_test, target_test, e_test, K_test) = ehf.split_data(edges_aug, labels, S_train, S_val, S_test, same_block_size=True)
+
+    class_weights = torch.tensor([alpha, 1.0 - alpha])
+    torch.manual_seed(100 + no_layers)
+    if no_layers == 2:
+        gcn = ehf.EmbeddingGCN2(Ct_train_2[:-1], X_train[:-1], e_train, M[:-1, :-1], hidden_feat=[6, 6, 2],
+                                condensed_W=True, use_Minv=False, nonlin2="selu")
+    else:
+        gcn = ehf.EmbeddingGCN(Ct_train_2[:-1], X_train[:-1], e_train, M[:-1, :-1], hidden_feat=[6, 2],
+                               condensed_W=True, use_Minv=False)
+    assert all(p.is_cuda for p in gcn.parameters())          # the model lives on the MI355X ...
+    optimizer = torch.optim.SGD(gcn.parameters(), lr=lr, momentum=momentum)
+    criterion = nn.CrossEntropyLoss(weight=class_weights)     # ... the criterion on the host, as in the scripts
+
+    losses = []
+    for ep in range(6):
+        optimizer.zero_grad()
+        output_train = gcn()
+        assert output_train.device.type == "cpu"
+        loss_train = criterion(output_train, target_train[edges_train[0] != 0])
+        loss_train.backward()
+        optimizer.step()
+        losses.append(float(loss_train.detach()))
+    pre = f"exp{no_layers}_"
+    assert_close(np.array(losses), g9[pre + "loss"], 1e-4, "loss trajectory")
+
+    with torch.no_grad():
+        output_train = gcn()
+        output_val = gcn(Ct_val_2[:-1], X_val[:-1], e_val)
+        output_test = gcn(Ct_test_2[:-1], X_test[:-1], e_test)
+        assert_close(output_train, g9[pre + "out_train"], 1e-4, "train logits")
+        assert_close(output_val, g9[pre + "out_val"], 1e-4, "val logits")
+        assert_close(output_test, g9[pre + "out_test"], 1e-4, "test logits")
+        loss_val = criterion(output_val[-K_val:], target_val[-K_val:])
+        loss_test = criterion(output_test[-K_test:], target_test[-K_test:])
+        assert abs(float(loss_val) - float(g9[pre + "loss_val"])) <= 1e-4 * abs(float(g9[pre + "loss_val"]))
+        assert abs(float(loss_test) - float(g9[pre + "loss_test"])) <= 1e-4 * abs(float(g9[pre + "loss_test"]))
+
+        guess_val = torch.argmax(output_val, dim=1)
+        f1_val = ehf.compute_f1(guess_val[-K_val:], target_val[-K_val:])
+        ref_guess = torch.from_numpy(g9[pre + "out_val"]).argmax(1)
+        if torch.equal(guess_val, ref_guess):                  # no logit pair closer than the tolerance
+            np.testing.assert_allclose([float(v) for v in f1_val], g9[pre + "f1_val"], rtol=1e-12)
+        for name, (out, tgt, e) in {
+            "train": (output_train, target_train[edges_train[0] != 0], edges_train[:, edges_train[0] != 0]),
+            "val": (output_val[-K_val:], target_val[-K_val:], edges_val[:, -K_val:]),
+            "test": (output_test[-K_test:], target_test[-K_test:], edges_test[:, -K_test:]),
+        }.items():
+            MAP, MRR = ehf.compute_MAP_MRR(out, tgt, e)
+            ref = g9[pre + "mapmrr_" + name]
+            # rank metrics move by 1/E-sized steps when two nearly equal scores swap
+            assert abs(float(MAP) - ref[0]) <= 2e-3 and abs(float(MRR) - ref[1]) <= 2e-3, (name, float(MAP), float(MRR), ref)
+
+
+def test_layers_module_keeps_logits_on_the_device():
+    import tmgcn_amd.layers as layers
+    g9 = golden("g9_data")
+    S = [int(s) for s in g9["S"]]
+    A, A_labels, Ct_train, _, _, N, M = ehf.load_data(GOLDEN + "/", "g9_saved_content.mat", *S, transformed=True)
+    X_train, _, _ = ehf.create_node_features(A, *S, same_block_size=True)
+    e = A_labels._indices()
+    e = e[:, e[0] < S[0]]
+    torch.manual_seed(0)
+    dev = layers.EmbeddingGCN(Ct_train, X_train, e, M, hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
+    torch.manual_seed(0)
+    host = ehf.EmbeddingGCN(Ct_train, X_train, e, M, hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
+    a, b = dev(), host()
+    assert a.is_cuda and not b.is_cuda and torch.equal(a.cpu(), b)
+    b.sum().backward()
+    a.sum().backward()
+    assert host.W.grad.is_cuda and torch.equal(host.W.grad, dev.W.grad)

@@ -18,7 +18,9 @@ Contract kept from the reference
     (W, U / W1, W2, U / (W2), W1, U) so a seeded script starts from the same weights.
   * ``EmbeddingGCN2`` layer 2 always uses the *training* adjacency ``self.At`` (ehf:339, 343,
     348), also in validation/test calls.
-  * Returns fp32 logits [E, C].
+  * Returns fp32 logits [E, C] — on the device; a class whose ``output_device`` attribute is set
+    (``tmgcn_amd.ehf`` sets "cpu") delivers them there through an autograd-aware copy, which is
+    what a script that keeps its targets and criterion on the host needs.
 The reference computes P1/P2 in fp64 and rounds to fp32 (ehf:205); here everything is fp32,
 within the stated tolerance 1e-5·max|ref|.
 """
@@ -70,6 +72,14 @@ def _edge_head(Z: torch.Tensor, idx, U: torch.Tensor) -> torch.Tensor:
 _NONLIN = ("relu", "leaky", "selu")
 
 
+class _Deliver:
+    """Mixin: where ``forward`` hands its result.  None = leave it on the compute device."""
+    output_device = None
+
+    def _deliver(self, out: torch.Tensor) -> torch.Tensor:
+        return out if self.output_device is None else out.to(self.output_device)
+
+
 def _param(t: torch.Tensor, dev, dtype) -> nn.Parameter:
     """A parameter drawn on the CPU generator (reference order/values), stored on the device in
     `dtype` (fp32, or bf16 for the "bf16 weights" config)."""
@@ -82,7 +92,7 @@ def _w(p: torch.Tensor) -> torch.Tensor:
     return p if p.dtype == torch.float32 else p.float()
 
 
-class EmbeddingGCN(nn.Module):
+class EmbeddingGCN(_Deliver, nn.Module):
     """1-layer TM-GCN (ehf:156-234)."""
 
     def __init__(self, At: AdjLike, X: torch.Tensor, edges: torch.Tensor, M: torch.Tensor,
@@ -118,10 +128,10 @@ class EmbeddingGCN(nn.Module):
         Y = ops.feature_gemm(AtXt, _w(self.W))                               # ehf:222
         if self.use_Minv:
             Y = ops.m_transform(Y, self.Minv)                                # ehf:224
-        return _edge_head(Y, eidx, _w(self.U))
+        return self._deliver(_edge_head(Y, eidx, _w(self.U)))
 
 
-class EmbeddingGCN_reg(nn.Module):
+class EmbeddingGCN_reg(_Deliver, nn.Module):
     """1-layer TM-GCN with a linear regression head per node (ehf:359-423; the SEIR experiments).
     As in the reference, ``forward`` ignores its arguments and always uses the tensors cached at
     construction (ehf:410-412), and returns [T, N]."""
@@ -148,10 +158,10 @@ class EmbeddingGCN_reg(nn.Module):
         Y = ops.feature_gemm(self.AtXt, self.W)                               # ehf:415
         if self.use_Minv:
             Y = ops.m_transform(Y, self.Minv)                                # ehf:417
-        return self.lin1(Y).squeeze(2)                                       # ehf:421-423
+        return self._deliver(self.lin1(Y).squeeze(2))                        # ehf:421-423
 
 
-class EmbeddingGCN2(nn.Module):
+class EmbeddingGCN2(_Deliver, nn.Module):
     """2-layer TM-GCN (ehf:236-357)."""
 
     def __init__(self, At: AdjLike, X: torch.Tensor, edges: torch.Tensor, M: torch.Tensor,
@@ -210,10 +220,10 @@ class EmbeddingGCN2(nn.Module):
                 Z = ops.m_transform(Z, self.Mop)                                   # ehf:346
         else:
             Z = ops.spmm_feature_gemm(self.At, Y, W2)                              # ehf:348-349
-        return _edge_head(Z, eidx, U)
+        return self._deliver(_edge_head(Z, eidx, U))
 
 
-class EmbeddingKWGCN(nn.Module):
+class EmbeddingKWGCN(_Deliver, nn.Module):
     """Baseline GCN without the M-product, 1 or 2 layers (ehf:425-497)."""
 
     def __init__(self, A: AdjLike, X: torch.Tensor, edges: torch.Tensor, hidden_feat=[2, 2],
@@ -252,4 +262,4 @@ class EmbeddingKWGCN(nn.Module):
             Z = ops.spmm_feature_gemm(self.A, Y, _w(self.W2))                      # ehf:487
         else:
             Z = ops.feature_gemm(AX, _w(self.W1))                                  # ehf:489
-        return _edge_head(Z, eidx, _w(self.U))
+        return self._deliver(_edge_head(Z, eidx, _w(self.U)))

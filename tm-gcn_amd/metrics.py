@@ -80,6 +80,30 @@ def _mrr_slice(value: torch.Tensor, true: torch.Tensor, row: torch.Tensor, col: 
     return row_mrr[has_one].mean()                                          # rows that contain a class-1 cell (ehf:697)
 
 
+def get_MAP(predictions: torch.Tensor, true_classes: torch.Tensor, do_softmax: bool = True) -> torch.Tensor:
+    """ehf:704-711.  Average precision of class 0 over one edge set; ``predictions`` are [E,2]
+    logits (do_softmax) or ready class-0 scores [E]."""
+    score = torch.softmax(predictions, dim=1)[:, 0] if do_softmax else predictions
+    return _average_precision_pos0(score, true_classes.to(score.device))
+
+
+def get_MRR(predictions: torch.Tensor, true_classes: torch.Tensor, adj: torch.Tensor, do_softmax: bool = True) -> torch.Tensor:
+    """ehf:684-702.  Mean over the rows of one slice of the mean reciprocal rank of its "existing"
+    cells; ``adj`` = [2,E] (src, dst) of the scored edges."""
+    score = torch.softmax(predictions, dim=1)[:, 0] if do_softmax else predictions[:, 0]
+    adj = adj.to(score.device)
+    return _mrr_slice(score, true_classes.to(score.device), adj[0], adj[1])
+
+
+def get_row_MRR(probs, true_classes) -> torch.Tensor:
+    """ehf:669-681.  One dense row: mean of 1/rank over the entries with class 0, ranks by
+    descending score."""
+    probs, true_classes = torch.as_tensor(probs), torch.as_tensor(true_classes)
+    order = torch.argsort(probs, descending=True)
+    ranks = torch.arange(1, probs.numel() + 1, dtype=torch.float64, device=probs.device)[(true_classes == 0)[order]]
+    return (1.0 / ranks).sum() / ranks.numel()
+
+
 def compute_MAP_MRR(output: torch.Tensor, target: torch.Tensor, edges: torch.Tensor, do_softmax: bool = True):
     """ehf:714-729.  output [E,2] logits, target [E], edges [3,E] (slice, src, dst).  Returns (MAP, MRR)."""
     edges = edges.to(output.device)
@@ -91,6 +115,6 @@ def compute_MAP_MRR(output: torch.Tensor, target: torch.Tensor, edges: torch.Ten
         m = edges[0] == k
         w = m.sum().double() / total
         pred, tru = output[m], target[m]
-        MAP = MAP + _average_precision_pos0(torch.softmax(pred, dim=1)[:, 0], tru) * w   # get_MAP(..., True)
-        MRR = MRR + _mrr_slice(pred[:, 0], tru, edges[1][m], edges[2][m]) * w            # get_MRR(..., False)
+        MAP = MAP + get_MAP(pred, tru, True) * w
+        MRR = MRR + get_MRR(pred, tru, edges[1:3, m], False) * w
     return MAP, MRR
