@@ -168,7 +168,8 @@ int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const int64_t* d
  * Same value as  nn.CrossEntropyLoss(weight=w)(logits, target)  used by every experiment script
  * (experiment_reddit_our_link_prediction.py:69, 79): loss = Σ w[t]·nll / Σ w[t].  One streaming
  * pass each way with fp64 block sums in fixed order; C <= 8.  stats_out: 2 doubles {Σ w·nll, Σ w}
- * kept by the caller for the backward.  Targets must lie in [0, C).
+ * kept by the caller for the backward.  A target outside [0, C) carries no weight and gets a
+ * zero gradient (the criterion's ignore_index = -100 is such a target).
  */
 int64_t tmgcn_wce_workspace_bytes(int64_t E);
 int tmgcn_wce_fwd_f32(const float* logits, const int64_t* target, const float* weight, int64_t E,

@@ -43,13 +43,13 @@ def test_link_prediction_script_flow(no_layers):
                                condensed_W=True, use_Minv=False)
     assert all(p.is_cuda for p in gcn.parameters())          # the model lives on the MI355X ...
     optimizer = torch.optim.SGD(gcn.parameters(), lr=lr, momentum=momentum)
-    criterion = nn.CrossEntropyLoss(weight=class_weights)     # ... the criterion on the host, as in the scripts
+    criterion = nn.CrossEntropyLoss(weight=class_weights)     # ... the criterion is the script's own, built on the host
 
     losses = []
     for ep in range(6):
         optimizer.zero_grad()
         output_train = gcn()
-        assert output_train.device.type == "cpu"
+        assert output_train.is_cuda                           # ... and so does the output (hosted.DeviceResult)
         loss_train = criterion(output_train, target_train[edges_train[0] != 0])
         loss_train.backward()
         optimizer.step()
@@ -85,8 +85,7 @@ def test_link_prediction_script_flow(no_layers):
             assert abs(float(MAP) - ref[0]) <= 2e-3 and abs(float(MRR) - ref[1]) <= 2e-3, (name, float(MAP), float(MRR), ref)
 
 
-def test_layers_module_keeps_logits_on_the_device():
-    import tmgcn_amd.layers as layers
+def _small_model(cls_module, **attrs):
     g9 = golden("g9_data")
     S = [int(s) for s in g9["S"]]
     A, A_labels, Ct_train, _, _, N, M = ehf.load_data(GOLDEN + "/", "g9_saved_content.mat", *S, transformed=True)
@@ -94,11 +93,74 @@ def test_layers_module_keeps_logits_on_the_device():
     e = A_labels._indices()
     e = e[:, e[0] < S[0]]
     torch.manual_seed(0)
-    dev = layers.EmbeddingGCN(Ct_train, X_train, e, M, hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
-    torch.manual_seed(0)
-    host = ehf.EmbeddingGCN(Ct_train, X_train, e, M, hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
-    a, b = dev(), host()
-    assert a.is_cuda and not b.is_cuda and torch.equal(a.cpu(), b)
-    b.sum().backward()
-    a.sum().backward()
-    assert host.W.grad.is_cuda and torch.equal(host.W.grad, dev.W.grad)
+    m = cls_module.EmbeddingGCN(Ct_train, X_train, e, M, hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    return m, e
+
+
+def test_three_ways_to_hand_over_the_logits_agree():
+    import tmgcn_amd.layers as layers
+    from tmgcn_amd.hosted import DeviceResult
+    dev, _ = _small_model(layers)                                           # plain device tensor
+    hosted, _ = _small_model(ehf)                                           # DeviceResult on the device
+    host, _ = _small_model(ehf, output_device="cpu", host_operands=False)  # plain host tensor
+    a, b, c = dev(), hosted(), host()
+    assert a.is_cuda and type(a) is torch.Tensor
+    assert b.is_cuda and isinstance(b, DeviceResult)
+    assert not c.is_cuda and type(c) is torch.Tensor
+    assert torch.equal(a, b.as_subclass(torch.Tensor)) and torch.equal(a.cpu(), c)
+    for out in (a, b, c):
+        out.sum().backward()
+    assert hosted.W.grad.is_cuda and torch.equal(hosted.W.grad, dev.W.grad) and torch.equal(host.W.grad, dev.W.grad)
+    assert type(hosted.W.grad) is torch.Tensor
+
+
+def test_device_result_takes_host_operands_the_way_the_scripts_use_them():
+    from tmgcn_amd.hosted import DeviceResult
+    m, e = _small_model(ehf)
+    E = e.shape[1]
+    g = torch.Generator().manual_seed(5)
+    target = torch.randint(0, 2, (E,), generator=g)                         # host tensors, as in the scripts
+    class_weights = torch.tensor([0.8, 0.2])
+    out = m()
+    ref = out.detach().as_subclass(torch.Tensor).cpu().double().requires_grad_(True)
+
+    # criterion: the fused kernel's value == torch's on the host in fp64; gradients too
+    loss = nn.CrossEntropyLoss(weight=class_weights)(out, target)
+    assert isinstance(loss, DeviceResult) and loss.is_cuda
+    loss_ref = nn.CrossEntropyLoss(weight=class_weights.double())(ref, target)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-6 * abs(float(loss_ref))
+    m.zero_grad()
+    (g_out,) = torch.autograd.grad(loss, out, retain_graph=True)
+    (g_ref,) = torch.autograd.grad(loss_ref, ref)
+    assert_close(g_out, g_ref, 1e-6, "dloss/dlogits")
+    # unweighted, ignore_index targets, and forms the kernel does not cover (torch runs them on the device)
+    tgt_ign = target.clone()
+    tgt_ign[::7] = -100
+    for crit, crit_ref in ((nn.CrossEntropyLoss(), nn.CrossEntropyLoss()),
+                           (nn.CrossEntropyLoss(weight=class_weights, reduction="sum"), nn.CrossEntropyLoss(weight=class_weights.double(), reduction="sum")),
+                           (nn.CrossEntropyLoss(label_smoothing=0.1), nn.CrossEntropyLoss(label_smoothing=0.1))):
+        for tg in (target, tgt_ign):
+            got, want = crit(out, tg), crit_ref(ref, tg)
+            assert got.is_cuda and abs(float(got) - float(want)) <= 2e-5 * abs(float(want)), (crit, float(got), float(want))
+
+    # metrics and bookkeeping idioms of the scripts
+    guess = torch.argmax(out, dim=1)
+    p, r, f1 = ehf.compute_f1(guess, target)
+    p2, r2, f2 = ehf.compute_f1(guess.cpu().as_subclass(torch.Tensor), target)
+    assert float(p) == float(p2) and float(r) == float(r2) and float(f1) == float(f2)
+    K = torch.tensor(10)
+    assert out[-K:].shape == (10, 2) and (target[-K:] == guess[-K:]).shape == (10,)
+    row = np.zeros((2, 4))
+    row[0] = [p, r, f1, loss]                                                # ep_acc_loss[ep] = [...]
+    assert row[0, 3] == float(loss) and row[0, 0] == float(p)
+    print("alpha/Tr/Ep %.2f/%d/%d. Train precision/recall/f1 %.16f/%.16f/%.16f. Train loss %.16f." % (0.9, 0, 0, p, r, f1, loss))
+    buf = torch.empty(E, 2)
+    buf.copy_(out.detach())                                                  # a host destination stays a host tensor
+    assert not buf.is_cuda and torch.equal(buf, out.detach().as_subclass(torch.Tensor).cpu())
+    both = torch.cat((torch.zeros(1, 2), out.detach()))
+    assert both.is_cuda and both.shape == (E + 1, 2)
+    MAP, MRR = ehf.compute_MAP_MRR(out, target, e)
+    MAP2, MRR2 = ehf.compute_MAP_MRR(ref.detach().float(), target, e)
+    assert abs(float(MAP) - float(MAP2)) <= 1e-12 and abs(float(MRR) - float(MRR2)) <= 1e-12

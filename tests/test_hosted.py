@@ -1,0 +1,43 @@
+"""hosted.DeviceResult mechanics that do not need a device (the cross-device behaviour is covered
+on the MI355X in test_gpu_experiment.py)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from tmgcn_amd.hosted import DeviceResult, _fused_cross_entropy
+
+
+def test_subclass_carries_through_the_scripts_operations_and_autograd():
+    x = torch.randn(7, 2, requires_grad=True)
+    out = (x * 2).as_subclass(DeviceResult)
+    target = torch.tensor([0, 1, 0, 1, 1, 0, 0])
+    w = torch.tensor([0.9, 0.1])
+    loss = nn.CrossEntropyLoss(weight=w)(out, target)
+    assert isinstance(loss, DeviceResult)
+    want = nn.CrossEntropyLoss(weight=w)(x * 2, target)
+    assert torch.equal(loss.as_subclass(torch.Tensor), want)              # host tensors: torch's own path, untouched
+    loss.backward()
+    assert type(x.grad) is torch.Tensor and x.grad.shape == x.shape
+    guess = torch.argmax(out, dim=1)
+    assert isinstance(guess, DeviceResult) and isinstance((guess == 0) & (target == 0), DeviceResult)
+    K = torch.tensor(3)
+    assert out[-K:].shape == (3, 2)
+
+
+def test_numpy_and_python_scalar_conversions():
+    out = (torch.arange(6.0).reshape(3, 2).requires_grad_(True) * 1).as_subclass(DeviceResult)
+    s = out.sum()
+    row = np.zeros(3)
+    row[:] = [s, out[0, 1], 2.5]                                          # ep_acc_loss[ep] = [...] in the scripts
+    assert row.tolist() == [15.0, 1.0, 2.5]
+    assert np.asarray(out).shape == (3, 2) and np.asarray(out, dtype=np.float64).dtype == np.float64
+    assert "%.3f" % s == "15.000" and float(s) == 15.0 and out.tolist()[2] == [4.0, 5.0]
+
+
+def test_fused_cross_entropy_declines_what_the_kernel_does_not_cover():
+    z, t = torch.randn(4, 2), torch.tensor([0, 1, 1, 0])
+    assert _fused_cross_entropy(z, t) is None                               # host tensor: not ours
+    # (shape / dtype / option screening happens before any device work)
+    for kw in (dict(reduction="sum"), dict(label_smoothing=0.1), dict(ignore_index=1), dict(size_average=True)):
+        assert _fused_cross_entropy(z, t, **kw) is None
+    assert _fused_cross_entropy(z, t.float()) is None and _fused_cross_entropy(torch.randn(4, 9), t) is None

@@ -45,12 +45,15 @@ __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)
       if (c < C) s += expf(v[c] - mx);
-    const int t = (int)tgt[e];
+    // a target outside [0, C) carries no weight (nn.CrossEntropyLoss's ignore_index = -100 lands here)
+    const int64_t t64 = tgt[e];
+    const bool valid = t64 >= 0 && t64 < C;
+    const int t = valid ? (int)t64 : 0;
     float zt = 0.f;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)
       if (c == t) zt = v[c];
-    const double wt = (double)w[t];
+    const double wt = valid ? (double)w[t] : 0.0;
     num += wt * ((double)mx + (double)logf(s) - (double)zt);
     den += wt;
   }
@@ -100,8 +103,10 @@ __global__ __launch_bounds__(256) void wce_bwd_kernel(const float* __restrict__ 
         v[c] = expf(v[c] - mx);
         s += v[c];
       }
-    const int t = (int)tgt[e];
-    const float scale = (float)((double)g * (double)w[t] / den);
+    const int64_t t64 = tgt[e];
+    const bool valid = t64 >= 0 && t64 < C;
+    const int t = valid ? (int)t64 : 0;
+    const float scale = valid ? (float)((double)g * (double)w[t] / den) : 0.f;
     const float inv = 1.f / s;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)

@@ -12,11 +12,13 @@ values — the four model classes (layers.py; the layer runs in the HIP kernels)
     compute_f1  compute_MAP_MRR  get_MAP  get_MRR  get_row_MRR  print_f1
 
 The scripts keep targets, class weights and the criterion on the host (``criterion(gcn(),
-target_train)``, …_link_prediction.py:69,79), so the classes exported here deliver their logits
-to the host: ``output_device = "cpu"``, an autograd-aware copy of the [E, C] result; the backward
-copy of its gradient is the only other host↔device traffic of an epoch.  A script that moves
-its targets and criterion to the device should use ``tmgcn_amd.layers`` (same classes, logits stay
-on the device) or set ``ehf.EmbeddingGCN.output_device = None``.
+target_train)``, …_link_prediction.py:69,79).  The classes exported here therefore return their
+logits as ``hosted.DeviceResult``: a tensor that stays on the MI355X and pulls the host tensors it
+is combined with over to the device, so the loss, its backward and the metrics run there too and
+the script does not change.  Two alternatives, per class or per instance:
+``output_device = "cpu"`` (plain host logits through an autograd-aware copy; the criterion then
+runs on the CPU) and ``host_operands = False`` (plain device logits — ``tmgcn_amd.layers``'
+behaviour, for scripts that move their targets themselves).
 """
 from . import layers as _layers
 from .data import augment_edges, compute_At, create_node_features, load_data, print_f1, split_data  # noqa: F401
@@ -24,19 +26,19 @@ from .metrics import compute_f1, compute_MAP_MRR, get_MAP, get_MRR, get_row_MRR 
 
 
 class EmbeddingGCN(_layers.EmbeddingGCN):
-    output_device = "cpu"
+    host_operands = True
 
 
 class EmbeddingGCN2(_layers.EmbeddingGCN2):
-    output_device = "cpu"
+    host_operands = True
 
 
 class EmbeddingKWGCN(_layers.EmbeddingKWGCN):
-    output_device = "cpu"
+    host_operands = True
 
 
 class EmbeddingGCN_reg(_layers.EmbeddingGCN_reg):
-    output_device = "cpu"
+    host_operands = True
 
 
 for _c in (EmbeddingGCN, EmbeddingGCN2, EmbeddingKWGCN, EmbeddingGCN_reg):

@@ -18,9 +18,9 @@ Contract kept from the reference
     (W, U / W1, W2, U / (W2), W1, U) so a seeded script starts from the same weights.
   * ``EmbeddingGCN2`` layer 2 always uses the *training* adjacency ``self.At`` (ehf:339, 343,
     348), also in validation/test calls.
-  * Returns fp32 logits [E, C] — on the device; a class whose ``output_device`` attribute is set
-    (``tmgcn_amd.ehf`` sets "cpu") delivers them there through an autograd-aware copy, which is
-    what a script that keeps its targets and criterion on the host needs.
+  * Returns fp32 logits [E, C] on the device.  The classes exported by ``tmgcn_amd.ehf`` set
+    ``host_operands`` so that a script which keeps its targets and criterion on the host runs
+    unchanged (hosted.DeviceResult); ``output_device = "cpu"`` copies the result to the host instead.
 The reference computes P1/P2 in fp64 and rounds to fp32 (ehf:205); here everything is fp32,
 within the stated tolerance 1e-5·max|ref|.
 """
@@ -73,11 +73,20 @@ _NONLIN = ("relu", "leaky", "selu")
 
 
 class _Deliver:
-    """Mixin: where ``forward`` hands its result.  None = leave it on the compute device."""
+    """Mixin: how ``forward`` hands its result over.
+    output_device   None = leave it on the compute device; "cpu" = autograd-aware copy to the host.
+    host_operands   wrap the (device) result as hosted.DeviceResult, so that the host tensors a
+                    reference script combines it with (targets, class weights) follow it to the device."""
     output_device = None
+    host_operands = False
 
     def _deliver(self, out: torch.Tensor) -> torch.Tensor:
-        return out if self.output_device is None else out.to(self.output_device)
+        if self.output_device is not None:
+            out = out.to(self.output_device)
+        if self.host_operands:
+            from .hosted import DeviceResult
+            out = out.as_subclass(DeviceResult)
+        return out
 
 
 def _param(t: torch.Tensor, dev, dtype) -> nn.Parameter:

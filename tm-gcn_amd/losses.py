@@ -12,6 +12,9 @@ from . import _lib
 from .ops import _ptr, _stream, _want
 
 
+MAX_CLASSES = 8   # kLossMaxC in csrc/loss.hip
+
+
 class _WCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, weight):

@@ -28,9 +28,13 @@ MODELS = {  # the scripts' model per config
 }
 
 
-def gpu_epochs(g, spec, epochs, graph, fused_loss=False):
+def gpu_epochs(g, spec, epochs, graph, fused_loss=False, script_mode=False):
+    global ehf
     At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
     edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels).cuda()
+    if script_mode:  # an untouched reference script: tmgcn_amd.ehf, targets / class weights / criterion as the script has them
+        import tmgcn_amd.ehf as ehf
+        labels, graph = labels.cpu(), False
     torch.manual_seed(0)
     kw = dict(condensed_W=True, use_Minv=False, param_dtype=spec.get("param_dtype", torch.float32))
     if spec["kind"] == "gcn":
@@ -45,6 +49,8 @@ def gpu_epochs(g, spec, epochs, graph, fused_loss=False):
     if fused_loss:
         from tmgcn_amd.losses import WeightedCrossEntropy
         crit = WeightedCrossEntropy(torch.tensor([0.9, 0.1])).cuda()
+    elif script_mode:
+        crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1]))
     else:
         crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1], device="cuda"))
 
@@ -131,11 +137,13 @@ if __name__ == "__main__":
     ap.add_argument("--cpu-epochs", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--fused-loss", action="store_true", help="tmgcn_amd.WeightedCrossEntropy instead of nn.CrossEntropyLoss")
+    ap.add_argument("--script-mode", action="store_true",
+                    help="what an untouched reference script does: import tmgcn_amd.ehf, host-side targets and criterion")
     args = ap.parse_args()
     for name in args.configs:
         g = synth.dynamic_graph(**synth.CONFIGS[name], seed=0)
         spec = MODELS[name]
-        l_gpu, t_eager, t_graph = gpu_epochs(g, spec, args.epochs, not args.no_graph, args.fused_loss)
+        l_gpu, t_eager, t_graph = gpu_epochs(g, spec, args.epochs, not args.no_graph, args.fused_loss, args.script_mode)
         cpu = {}
         for th in ((8, 32) if args.cpu_epochs > 0 else ()):  # all 256 threads is pathological on these small ops (measured: 1000x slower)
             l_cpu, cpu[th] = cpu_epochs(g, spec, args.cpu_epochs, th)
@@ -150,4 +158,4 @@ if __name__ == "__main__":
                           "cpu_epoch_ms": round(t_cpu * 1e3, 1), "cpu_threads": th_best,
                           "cpu_epoch_ms_by_threads": {str(k): round(v * 1e3, 1) for k, v in cpu.items()},
                           "speedup": round(t_cpu / best, 1),
-                          "fused_loss": args.fused_loss, "first_loss_gpu": l_gpu, "first_loss_cpu": l_cpu}), flush=True)
+                          "fused_loss": args.fused_loss, "script_mode": args.script_mode, "first_loss_gpu": l_gpu, "first_loss_cpu": l_cpu}), flush=True)
