@@ -65,18 +65,25 @@ __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ 
   }
 }
 
-// out[0] = loss (float); stats = {num, den} (double) kept for the backward
-__global__ void wce_finish_kernel(const double* __restrict__ partial, int n, float* __restrict__ out,
-                                  double* __restrict__ stats) {
-  if (threadIdx.x || blockIdx.x) return;
+// out[0] = loss (float); stats = {num, den} (double) kept for the backward.  One wave: lane l adds
+// the partials l, l+64, ... in order, then a butterfly — a fixed summation order, so reproducible.
+__global__ __launch_bounds__(64) void wce_finish_kernel(const double* __restrict__ partial, int n,
+                                                        float* __restrict__ out, double* __restrict__ stats) {
   double num = 0.0, den = 0.0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = threadIdx.x; i < n; i += 64) {
     num += partial[2 * i];
     den += partial[2 * i + 1];
   }
-  stats[0] = num;
-  stats[1] = den;
-  out[0] = (float)(num / den);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    num += __shfl_xor(num, off);
+    den += __shfl_xor(den, off);
+  }
+  if (threadIdx.x == 0) {
+    stats[0] = num;
+    stats[1] = den;
+    out[0] = (float)(num / den);
+  }
 }
 
 // dz[e][c] = g · w[t_e]/den · (softmax(z_e)[c] − [c == t_e])
