@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the slice-sharded layer (tmgcn_amd.dist) reproduces the unsharded
+"""CPU, world_size 2 and 4, gloo: the slice-sharded layer (tmgcn_amd.dist) reproduces the unsharded
 layer — forward, dX, dW — in both exchange modes.  The device kernels are substituted by the
 oracle here (no GPU in this environment); the collectives and the sharding arithmetic are the
 product's."""
@@ -40,7 +40,7 @@ def _worker(rank, world, port, exchange, condensed, act, F0, ret):
         _setup(rank, world, port)
         from tmgcn_amd.csr import BatchedCSR
         from tmgcn_amd.dist import ShardedTMGCNLayer, even_bounds
-        T, N, F1, b = 8, 30, 6, 5
+        T, N, F1, b = 8, (30 if world == 2 else 8 * world), 6, 5
         g, X, W, dY = _problem(T, N, F0, F1, b, condensed)
         k0, k1 = even_bounds(T, world)[rank]
         n0, n1 = even_bounds(N, world)[rank]
@@ -97,6 +97,20 @@ def _reference_local(g, X, W, dY, act):
 def test_sharded_layer_matches_unsharded(exchange, condensed, act, F0):
     world = 2
     port = 29600 + (abs(hash((exchange, condensed, F0))) % 300)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, exchange, condensed, act, F0, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", f"rank {r}:\n{ret.get(r)}"
+
+
+@pytest.mark.parametrize("exchange,condensed,act,F0", [("a2a", True, "relu", 16), ("a2a", False, None, 4),
+                                                       ("allgather", True, None, 16)])
+def test_sharded_layer_world_size_4(exchange, condensed, act, F0):
+    """Four ranks: two slices and eight nodes per rank — the group-interleaved send / receive layouts
+    with more than one peer on either side."""
+    world = 4
+    port = 29900 + (abs(hash((exchange, condensed, F0))) % 90)
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, exchange, condensed, act, F0, ret), nprocs=world, join=True)

@@ -1,4 +1,4 @@
-"""GPU, world size 2 on ONE device (two processes share cuda:0, gloo transport for the CUDA tensors —
+"""GPU, world size 2 (and 4) on ONE device (the processes share cuda:0, gloo transport for the CUDA tensors —
 RCCL refuses two ranks on one GPU): the slice-sharded layer with the REAL HIP kernels, the side
 stream and the per-slice pipelining, against the unsharded layer computed by the same kernels.
 Together with test_dist_gloo.py (CPU, oracle kernels) and test_gpu_dist1.py (RCCL, world 1) this is
@@ -79,5 +79,18 @@ def test_two_ranks_one_gpu(exchange, F0, F1, pipeline, condensed, act):
     port = 29700 + abs(hash((exchange, F0, pipeline, condensed))) % 250
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, exchange, F0, F1, condensed, act, pipeline, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", f"rank {r}:\n{ret.get(r)}"
+
+
+@pytest.mark.parametrize("exchange,F0,F1,condensed,act", [("a2a", 16, 32, True, "relu"), ("a2a", 6, 6, False, None),
+                                                           ("allgather", 16, 32, False, "selu")])
+def test_four_ranks_one_gpu(exchange, F0, F1, condensed, act):
+    """Two slices and 24 nodes per rank: the band kernel's group-interleaved send / receive layouts
+    with four groups, and the per-slice pipeline with three peers."""
+    world = 4
+    port = 29960 + abs(hash((exchange, F0, condensed))) % 30
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, exchange, F0, F1, condensed, act, True, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", f"rank {r}:\n{ret.get(r)}"
