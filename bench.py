@@ -224,11 +224,16 @@ def main():
             "peak_hbm_gb_rank0": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
         }
         if "gemm_dW" in kt:
-            # the one GEMM that still runs as its own kernel (dW = AXᵀ·dY, exact-f32 MFMA); the
-            # forward / dA GEMMs run inside the fused SpMM kernels, hidden under the gather
-            tf = 2.0 * A.n_rows * F * F / (kt["gemm_dW"]["avg_ms"] * 1e-3) / 1e12
-            out["mfma"] = {"kernel": "gemm_dw_lds_kernel (dW)", "bound": "mfma", "achieved": tf, "peak": 157.3,
-                           "unit": "TFLOP/s", "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+            # the one GEMM that still runs as its own kernel (dW = AXᵀ·dY); the forward / dA GEMMs run
+            # inside the fused SpMM kernels, hidden under the gather.  It multiplies on the bf16 matrix
+            # cores after an exact 3-way split of the fp32 operands: 6 bf16 MFMA products per fp32 term.
+            t_dw = kt["gemm_dW"]["avg_ms"] * 1e-3
+            fp32_tf = 2.0 * A.n_rows * F * F / t_dw / 1e12
+            out["mfma"] = {"kernel": "gemm_dw_bf16x3_kernel (dW)", "bound": "mfma", "achieved": 6.0 * fp32_tf,
+                           "peak": 2500.0, "unit": "TFLOP/s", "frac": 6.0 * fp32_tf / 2500.0,
+                           "dtype": "bf16 planes of an exact 3-way fp32 split (v_mfma_f32_32x32x16_bf16), fp32 accumulate",
+                           "fp32_equivalent_tflops": fp32_tf, "f32_mfma_peak_tflops": 157.3,
+                           "hbm_gbs": A.n_rows * 2 * F * 4 / t_dw / 1e9}
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args)
     # RCCL prints its version banner through C stdio, which is flushed only at exit when stdout is

@@ -49,7 +49,10 @@ const char* tmgcn_last_error(void);
 /* Process-wide tuning knobs (performance only, never results).
  *   "persistent_grid_reserve"  block slots the persistent fused kernel leaves free (default 0);
  *                              the sharded layer sets it so that RCCL's kernels on the side
- *                              stream can become resident next to the compute kernel. */
+ *                              stream can become resident next to the compute kernel.
+ *   "dw_bf16x3"                1 (default): tmgcn_gemm_dw_f32 multiplies on the bf16 matrix cores after an
+ *                              exact 3-way split of the fp32 operands (fp32-accurate, reproducible);
+ *                              0: the exact-f32 MFMA kernel. */
 int tmgcn_config_set(const char* key, int64_t value);
 
 /* ---- P1: tube-fibre M-transform ------------------------------------------------
@@ -129,6 +132,9 @@ int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* pre_act,
  *   dW_b[k][n] = sum_{r in batch b} A[r][k] * dY[r][n]
  * workspace: tmgcn_gemm_dw_workspace_bytes() bytes of scratch on the device
  * (partial slabs, reduced in a fixed order: bitwise reproducible).
+ * For K, Nf >= 16 (multiples of 4, 16-byte aligned operands) the products run as v_mfma_f32_32x32x16_bf16
+ * on three bf16 planes per operand, x = hi + mid + lo exactly, keeping the six plane products above
+ * 2^-24 |a·b|: the accuracy of an fp32 FMA chain at 2.7x the f32 MFMA rate.
  */
 int64_t tmgcn_gemm_dw_workspace_bytes(int64_t R, int32_t K, int32_t Nf, int64_t rows_per_batch);
 int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW,

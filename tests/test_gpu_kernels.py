@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import REL_TOL, assert_close, cptr, load_c_oracle
+from _util import max_rel_err, REL_TOL, assert_close, cptr, load_c_oracle
 from tmgcn_amd import ops, synth
 from tmgcn_amd.csr import BatchedCSR
 
@@ -187,6 +187,30 @@ def test_gemm_dw(K, Nf, per_slice):
     got = ops.kernels.gemm_dw(A.to(DEV), dY.to(DEV), per_slice)
     assert_close(got, ref, REL_TOL, f"dW {K}x{Nf}")
     assert torch.equal(got, ops.kernels.gemm_dw(A.to(DEV), dY.to(DEV), per_slice)), "dW not reproducible"
+
+
+@pytest.mark.parametrize("K,Nf,R", [(128, 128, 70001), (132, 260, 5000), (16, 16, 33), (64, 36, 4099), (20, 100, 777)])
+def test_gemm_dw_bf16_split_is_fp32_accurate(K, Nf, R):
+    """dW runs on the bf16 matrix cores through an exact 3-way split of the fp32 operands (hi + mid +
+    lo planes, six plane products per term).  Against an fp64 product, on operands whose rows span
+    six orders of magnitude, it must be as accurate as the exact-f32 MFMA kernel it replaces — both
+    are selectable through tmgcn_config_set("dw_bf16x3", 0 | 1) — and bit-reproducible."""
+    from tmgcn_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(R)
+    A = (torch.randn(1, R, K, generator=g) * torch.exp(torch.randn(1, R, 1, generator=g) * 3)).to(DEV)
+    dY = torch.randn(1, R, Nf, generator=g).to(DEV)
+    ref = A[0].double().T @ dY[0].double()
+    err = {}
+    try:
+        for mode in (0, 1):
+            _lib.check(lib.tmgcn_config_set(b"dw_bf16x3", mode), "config_set")
+            got = ops.kernels.gemm_dw(A, dY, False)
+            err[mode] = max_rel_err(got, ref)
+            assert torch.equal(got, ops.kernels.gemm_dw(A, dY, False)), "dW not reproducible"
+    finally:
+        lib.tmgcn_config_set(b"dw_bf16x3", 1)
+    assert err[1] <= 2e-6 and err[1] <= 2 * err[0] + 1e-7, err
 
 
 def test_gemm_many_rows_persistent_loop():

@@ -45,6 +45,8 @@ constexpr int kWave = 64;  // gfx950 wavefront
 // in the multi-GPU path RCCL's kernels run on a side stream and can only become resident if the
 // persistent compute kernels do not hold every block slot of every CU.
 int persistent_grid_reserve();
+// dW through the 3-way bf16 split on the bf16 matrix cores (tmgcn_config_set("dw_bf16x3")), default on
+bool dw_bf16x3_enabled();
 
 template <typename K>
 inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0) {

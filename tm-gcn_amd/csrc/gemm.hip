@@ -11,7 +11,9 @@
 //                  ds_read_b128 feeds four MFMAs.
 //   gemm_small     thread-per-row FMA kernel for the reference's real sizes (2x6, 6x6, 12x2):
 //                  MFMA tiles would be >90 % padding there; the op is a pure HBM stream.
-//   gemm_dw_lds    dW = AᵀdY.  The reduction index is the row r, so the MFMA operands have the
+//   gemm_dw_bf16x3 dW = AᵀdY on the bf16 matrix cores after an exact 3-way split of the fp32 operands
+//                  (fp32-accurate, reproducible; the default for K, Nf >= 16) — see the kernel.
+//   gemm_dw_lds    the exact-f32 MFMA form of the same product.  The reduction index is the row r, so the MFMA operands have the
 //                  feature index on the lane; 32-row windows of A and dY are staged once per
 //                  block through LDS (full-line loads) and read back with conflict-free
 //                  ds_read_b32; row-chunk partial slabs are reduced in a fixed order by a
@@ -322,6 +324,210 @@ __global__ __launch_bounds__(256) void gemm_dw_lds_kernel(DwArgs a) {
   }
 }
 
+// dW on the bf16 matrix cores at fp32 accuracy: every fp32 operand is split exactly into three
+// bf16 planes  x = hi + mid + lo  (8 + 8 + 8 mantissa bits; each residual is exact in fp32), and
+// a product is the six plane products that matter,
+//     a·b ≈ hi·hi + (hi·mid + mid·hi) + (hi·lo + lo·hi + mid·mid)          (dropped: ≤ 2^-24 |a·b|)
+// each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs do the work of
+// eight f32 ones at 16x the rate, which turns dW from MFMA-bound (0.62 of the f32 peak) into a
+// stream over its two operands.
+//   step = 32 rows.  Thread (kg, fq) loads rows 4kg..4kg+3 x features 4fq..4fq+3 of both operand
+//   windows (coalesced float4s), splits them, and writes for each feature the four k-slots it owns
+//   as one 8-byte store into the LDS image  [operand][plane][feature quad: 272 B][feature: 64 B][slot: 2 B];
+//   the 16-byte pad per quad makes the ds_read_b128 fragment reads conflict-free (2-way on the
+//   stores, which their issue cost hides).  k-slot = row inside the step for BOTH operands, so the
+//   MFMA's k order is consistent.  Staging registers are refilled for the next step before the MFMA
+//   phase; three blocks per CU overlap one block's split/store phase with another's MFMAs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // bf16(a) | bf16(b) << 16, RNE
+  f32x2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+
+// (a, b) -> the three packed planes
+__device__ __forceinline__ void split3(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  h = pack_bf16(a, b);
+  a -= bf16_lo(h);
+  b -= bf16_hi(h);
+  m = pack_bf16(a, b);
+  a -= bf16_lo(m);
+  b -= bf16_hi(m);
+  l = pack_bf16(a, b);
+}
+
+// Measured (33.5 M rows, 128x128): depth 1 at 3 blocks/CU 7.57 ms, depth 2 / 3 / 4 at 2 blocks/CU 7.68 /
+// 7.69 / 7.73 ms — hipcc drains every outstanding load at the ring loop's header (s_waitcnt vmcnt(0)),
+// so a deeper ring buys nothing today; the f32-MFMA kernel it replaces takes 10.9 ms.
+#ifndef X3_DEPTH
+#define X3_DEPTH 1
+#endif
+#ifndef X3_OCC
+#define X3_OCC 3
+#endif
+constexpr int X3_ROWS = 32;
+constexpr int X3_PITCH = 272;             // bytes per feature quad (4 x 64 + 16)
+constexpr int X3_PLANE = 32 * X3_PITCH;   // 128 features
+constexpr int X3_OPERAND = 3 * X3_PLANE;
+
+__device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+__global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2 * X3_OPERAND];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int tiles_n = (a.Nf + 127) / 128;
+  const int kt = blockIdx.y / tiles_n, nt = blockIdx.y % tiles_n;
+  const int64_t batch = blockIdx.x / a.chunks;
+  const int chunk = blockIdx.x % a.chunks;
+  const int64_t b0 = batch * a.batch_rows;
+  int64_t b1 = b0 + a.batch_rows;
+  if (b1 > a.R) b1 = a.R;
+  const int64_t r0 = b0 + (int64_t)chunk * a.rows_per_chunk;
+  int64_t r1 = r0 + a.rows_per_chunk;
+  if (r1 > b1) r1 = b1;
+  const int kbase = kt * 128, nbase = nt * 128;
+
+  // staging role of this thread
+  const int kg = 2 * wave + lh;  // rows 4kg .. 4kg+3 of the step
+  const int fq = li;             // features 4fq .. 4fq+3 of the 128-wide windows
+  // K and Nf are multiples of 4, so a feature quad is inside or outside as a whole; a thread whose
+  // quad is outside reads column 0 instead (a valid address) and zeroes the values: the steady state
+  // has no conditional load (those force s_waitcnt vmcnt(0) and exec-mask branches)
+  const bool okA = kbase + 4 * fq < a.K, okB = nbase + 4 * fq < a.Nf;
+  const float* pa = a.A + (r0 + 4 * kg) * a.K + (okA ? kbase + 4 * fq : 0);
+  const float* pb = a.dY + (r0 + 4 * kg) * a.Nf + (okB ? nbase + 4 * fq : 0);
+  const float za = okA ? 1.f : 0.f, zb = okB ? 1.f : 0.f;
+  // X3_DEPTH staging sets form a ring: the rows of step n+DEPTH are requested as soon as step n has
+  // been split, so a request has DEPTH whole steps to arrive.  The ring loop contains no conditional
+  // load (the compiler then counts outstanding loads exactly: s_waitcnt vmcnt(8*(DEPTH-1)) instead of
+  // draining every request before each split); chunk heads/tails go through the plain loop below.
+  float4 sa[X3_DEPTH][4], sb[X3_DEPTH][4];
+  auto fetch_full = [&](float4 (&xa)[4], float4 (&xb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xa[i] = *reinterpret_cast<const float4*>(pa + (int64_t)i * a.K);
+      xb[i] = *reinterpret_cast<const float4*>(pb + (int64_t)i * a.Nf);
+    }
+    pa += (int64_t)X3_ROWS * a.K;
+    pb += (int64_t)X3_ROWS * a.Nf;
+  };
+  auto fetch_any = [&](float4 (&xa)[4], float4 (&xb)[4], int64_t r) {  // r < r1; rows past r1 read row r1-1 and are zeroed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = r + 4 * kg + i;
+      const int64_t back = row < r1 ? 0 : row - (r1 - 1);
+      const float z = row < r1 ? 1.f : 0.f;
+      const float4 va = *reinterpret_cast<const float4*>(pa + ((int64_t)i - back) * a.K);
+      const float4 vb = *reinterpret_cast<const float4*>(pb + ((int64_t)i - back) * a.Nf);
+      xa[i] = make_float4(va.x * z, va.y * z, va.z * z, va.w * z);
+      xb[i] = make_float4(vb.x * z, vb.y * z, vb.z * z, vb.w * z);
+    }
+    pa += (int64_t)X3_ROWS * a.K;
+    pb += (int64_t)X3_ROWS * a.Nf;
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  unsigned char* wrA = sm + fq * X3_PITCH + kg * 8;
+  unsigned char* wrB = wrA + X3_OPERAND;
+  // fragment addresses: feature 32*tile + li -> quad 8*tile + li/4, feature-in-quad li%4; k half lh
+  const unsigned char* rdA = sm + (8 * wave + (li >> 2)) * X3_PITCH + (li & 3) * 64 + lh * 16;
+  const unsigned char* rdB = sm + X3_OPERAND + (li >> 2) * X3_PITCH + (li & 3) * 64 + lh * 16;
+
+  auto split_store = [&](const float4 (&xa)[4], const float4 (&xb)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3(comp(xa[0], c) * za, comp(xa[1], c) * za, h0, m0, l0);
+      split3(comp(xa[2], c) * za, comp(xa[3], c) * za, h1, m1, l1);
+      *reinterpret_cast<uint2*>(wrA + c * 64) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(wrA + X3_PLANE + c * 64) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(wrA + 2 * X3_PLANE + c * 64) = make_uint2(l0, l1);
+      split3(comp(xb[0], c) * zb, comp(xb[1], c) * zb, h0, m0, l0);
+      split3(comp(xb[2], c) * zb, comp(xb[3], c) * zb, h1, m1, l1);
+      *reinterpret_cast<uint2*>(wrB + c * 64) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(wrB + X3_PLANE + c * 64) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(wrB + 2 * X3_PLANE + c * 64) = make_uint2(l0, l1);
+    }
+  };
+  auto multiply = [&]() {
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(rdA + sh * 32));
+      const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(rdA + X3_PLANE + sh * 32));
+      const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(rdA + 2 * X3_PLANE + sh * 32));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const unsigned char* q = rdB + t * 8 * X3_PITCH + sh * 32;
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q));
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + X3_PLANE));
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + 2 * X3_PLANE));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);  // small terms first
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+      }
+    }
+  };
+
+  int64_t r = r0;
+  const int64_t full_end = r0 + ((r1 - r0) / X3_ROWS) * X3_ROWS;  // end of the whole steps
+  if (full_end - r0 >= 2 * X3_DEPTH * X3_ROWS) {
+#pragma unroll
+    for (int d = 0; d < X3_DEPTH; ++d) fetch_full(sa[d], sb[d]);
+    for (; r + 2 * X3_DEPTH * X3_ROWS <= full_end; r += X3_DEPTH * X3_ROWS) {
+#pragma unroll
+      for (int d = 0; d < X3_DEPTH; ++d) {
+        __syncthreads();  // the previous step's fragments have been read
+        split_store(sa[d], sb[d]);
+        fetch_full(sa[d], sb[d]);  // refill this set for step +DEPTH
+        __syncthreads();
+        multiply();
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < X3_DEPTH; ++d) {  // drain the ring
+      __syncthreads();
+      split_store(sa[d], sb[d]);
+      __syncthreads();
+      multiply();
+    }
+    r += X3_DEPTH * X3_ROWS;
+  }
+  for (; r < r1; r += X3_ROWS) {  // what is left of the chunk (and chunks too short for the ring)
+    fetch_any(sa[0], sb[0], r);
+    __syncthreads();
+    split_store(sa[0], sb[0]);
+    __syncthreads();
+    multiply();
+  }
+  float* P = a.part + ((int64_t)blockIdx.x) * a.K * a.Nf;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = nbase + t * 32 + li;
+    if (n < a.Nf) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = kbase + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        if (kk < a.K) P[(int64_t)kk * a.Nf + n] = acc[t][i];
+      }
+    }
+  }
+}
+
 // small dW: rows staged through LDS in tiles of DW_ROWS.  With few outputs (K*Nf <= 128, the
 // reference's 2x6 / 6x6) the 256 threads form 256/(K*Nf) row groups that each take every g-th row
 // of the tile, so all lanes work; with more outputs each thread owns up to 4 output elements.
@@ -385,19 +591,31 @@ __global__ __launch_bounds__(256) void gemm_dw_small_kernel(DwArgs a) {
   }
 }
 
-// dW[b][o] = sum over chunks (ascending lanes, fixed butterfly) of part[b][chunk][o]: one wave per output
+// dW[b][o] = sum over chunks of part[b][chunk][o].  A block owns 64 consecutive outputs; its four
+// waves take the chunks c = w, w+4, ... (lanes along the outputs: every load is one coalesced 256-byte
+// row of a slab), four independent fp64 sums per lane in flight, combined in a fixed order.
 __global__ __launch_bounds__(256) void gemm_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
                                                               int64_t n_out, int32_t chunks, int64_t total) {
-  const int lane = threadIdx.x & 63;
-  const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (idx >= total) return;  // whole wave
-  const int64_t b = idx / n_out, o = idx % n_out;
+  __shared__ double sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + lane;       // flat (batch, output)
+  const bool in = idx < total;
+  const int64_t b = in ? idx / n_out : 0, o = in ? idx % n_out : 0;
   const float* p = part + b * chunks * n_out + o;
-  double s = 0.0;
-  for (int c = lane; c < chunks; c += kWave) s += (double)p[(int64_t)c * n_out];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) dW[idx] = (float)s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int c = w;
+  for (; c + 12 < chunks; c += 16) {
+    const float v0 = in ? p[(int64_t)c * n_out] : 0.f, v1 = in ? p[(int64_t)(c + 4) * n_out] : 0.f;
+    const float v2 = in ? p[(int64_t)(c + 8) * n_out] : 0.f, v3 = in ? p[(int64_t)(c + 12) * n_out] : 0.f;
+    s0 += (double)v0;
+    s1 += (double)v1;
+    s2 += (double)v2;
+    s3 += (double)v3;
+  }
+  for (; c < chunks; c += 4) s0 += in ? (double)p[(int64_t)c * n_out] : 0.0;
+  sh[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && in) dW[idx] = (float)((sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]));
 }
 
 static bool use_small(int K, int Nf) { return (K < 16 || Nf < 16) && K <= 64 && Nf <= 64; }
@@ -407,7 +625,7 @@ static void dw_plan(int64_t R, int64_t rows_per_batch, int64_t* n_batch, int* ch
   const int64_t br = rows_per_batch ? rows_per_batch : R;
   const int64_t nb = br ? (R + br - 1) / br : 1;
   int64_t c = (br + 511) / 512;  // >= 512 rows per chunk
-  int64_t cmax = 2048 / (nb > 0 ? nb : 1);
+  int64_t cmax = 1536 / (nb > 0 ? nb : 1);  // two rounds of the 768 blocks (3 per CU) the bf16x3 kernel keeps resident
   if (cmax < 1) cmax = 1;
   if (c > cmax) c = cmax;
   if (c < 1) c = 1;
@@ -497,13 +715,18 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
     hipLaunchKernelGGL(gemm_dw_small_kernel, dim3(gx), dim3(256), smem, st, a);
   } else {
     const unsigned gy = (unsigned)(((K + 127) / 128) * ((Nf + 127) / 128));
-    hipLaunchKernelGGL(gemm_dw_lds_kernel, dim3(gx, gy), dim3(256), 0, st, a);
+    const bool x3 = dw_bf16x3_enabled() && K % 4 == 0 && Nf % 4 == 0 &&
+                    reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 16 == 0;
+    if (x3)
+      hipLaunchKernelGGL(gemm_dw_bf16x3_kernel, dim3(gx, gy), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(gemm_dw_lds_kernel, dim3(gx, gy), dim3(256), 0, st, a);
   }
   int rc = check_launch("gemm_dw");
   if (rc) return rc;
   const int64_t n_out = (int64_t)K * Nf;
   const int64_t total = nb * n_out;
-  hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st,
+  hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
                      (const float*)workspace, dW, n_out, chunks, total);
   return check_launch("gemm_dw_reduce");
 }
