@@ -56,6 +56,8 @@ def parse():
     p.add_argument("--force-collectives", action="store_true",
                    help="run the exchange (RCCL) code path even at --gpus 1 (diagnostic)")
     p.add_argument("--cpu-nodes", type=int, default=250_000, help="N of the CPU-baseline sample")
+    p.add_argument("--watchdog", type=int, default=0,
+                   help="diagnostic: dump every thread's Python traceback to stderr after this many seconds")
     return p.parse_args()
 
 
@@ -103,6 +105,9 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=False)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
