@@ -56,8 +56,9 @@ def parse():
     p.add_argument("--force-collectives", action="store_true",
                    help="run the exchange (RCCL) code path even at --gpus 1 (diagnostic)")
     p.add_argument("--cpu-nodes", type=int, default=250_000, help="N of the CPU-baseline sample")
-    p.add_argument("--watchdog", type=int, default=0,
-                   help="diagnostic: dump every thread's Python traceback to stderr after this many seconds")
+    p.add_argument("--watchdog", type=int, default=600,
+                   help="diagnostic: dump every thread's Python traceback to stderr once, after this many seconds "
+                        "(a default run takes 2-3 minutes; 0 disables)")
     return p.parse_args()
 
 
