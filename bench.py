@@ -11,29 +11,36 @@ Inputs are generated on the device (seeded by global slice index) and are reside
 before the timed region.  One unit of work = one stored non-zero of one slice ("edge-slice").
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 --steps 10 --warmup 3        # starts its own 8 ranks (see launch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3
 
-Rank 0 prints ONE JSON line (driver contract) with `roofline` (dominant kernel = forward
-SpMM, HIP events on the launch stream) and `cpu_baseline` (the oracle executed the
-reference's way on the host cores, on a bounded sample).
+Rank 0 prints ONE JSON line (driver contract), the last line of the job's stdout, with
+  roofline      dominant kernel = forward SpMM (fused with the GEMM epilogue), HIP events on the launch stream
+  cpu_baseline  the oracle executed the reference's way on the host cores (N = 1 only, bounded sample)
+  epochs        training-epoch time of the reference-shaped configs S1-S3 (GPU eager / hipGraph /
+                untouched-script mode vs the CPU oracle; north_star's >= 10x Reddit-LP target), N = 1 only
+  ranks         world size as RCCL itself reports it, and the device every rank ran on
+Every rank carries a hard deadline (--deadline): stacks are dumped and the process exits non-zero,
+so a stalled multi-rank job ends instead of hanging until somebody's timeout.
 """
 import argparse
+import gc
 import json
 import os
 import sys
+import threading
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+T0 = time.perf_counter()
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
@@ -45,6 +52,9 @@ def parse():
     p.add_argument("--band", type=int, default=20)
     p.add_argument("--exchange", choices=["a2a", "allgather"], default="a2a")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-epochs", action="store_true", help="skip the S1-S3 training-epoch block (N = 1 only)")
+    p.add_argument("--no-compare-exchange", action="store_true",
+                   help="skip the a2a / allgather side-by-side leg of multi-rank runs")
     p.add_argument("--no-fuse", action="store_true", help="run P2 and P3 as separate kernels")
     p.add_argument("--no-pipeline", action="store_true", help="exchange all slices before computing")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
@@ -55,95 +65,310 @@ def parse():
                    help="block slots the fused kernel leaves free for RCCL's kernels (default: the layer's choice)")
     p.add_argument("--force-collectives", action="store_true",
                    help="run the exchange (RCCL) code path even at --gpus 1 (diagnostic)")
-    p.add_argument("--cpu-nodes", type=int, default=250_000, help="N of the CPU-baseline sample")
+    p.add_argument("--cpu-nodes", type=int, default=250_000, help="N of the repeated CPU-baseline sample")
+    p.add_argument("--cpu-full-nodes", type=int, default=-1,
+                   help="N of the identical-N CPU point (SURVEY §8d); -1 = --nodes, 0 = skip")
+    p.add_argument("--compare-nodes", type=int, default=250_000,
+                   help="N of the reduced-size a2a / allgather comparison (fits at every world size)")
+    p.add_argument("--epoch-reps", type=int, default=50, help="GPU epochs timed per config in the epochs block")
+    p.add_argument("--cpu-epoch-reps", type=int, default=5, help="CPU epochs timed per config and thread count")
     p.add_argument("--watchdog", type=int, default=600,
-                   help="diagnostic: dump every thread's Python traceback to stderr once, after this many seconds "
-                        "(a default run takes 2-3 minutes; 0 disables)")
-    return p.parse_args()
+                   help="dump every thread's Python stack to stderr once after this many seconds (0 disables)")
+    p.add_argument("--deadline", type=int, default=1500,
+                   help="hard limit: after this many seconds every rank dumps its stacks and exits non-zero (0 disables)")
+    return p.parse_args(argv)
+
+
+def stage(msg):
+    """Progress marker on stderr (where a stalled run stopped is the first thing one needs)."""
+    r = os.environ.get("RANK", "0")
+    sys.stderr.write(f"[bench r{r} +{time.perf_counter() - T0:7.1f}s] {msg}\n")
+    sys.stderr.flush()
+
+
+# ---------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no torchrun around it
+# ---------------------------------------------------------------------------------------
+def launch(args):
+    """Start the N ranks as FRESH processes (`python -m torch.distributed.run … bench.py …`) from a
+    parent that never touches the GPU, relay their output, and return their exit code.  The
+    parent enforces the deadline too: it kills the process group it started (and only that)."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    stage(f"launching {args.gpus} ranks: {' '.join(cmd[1:8])} …")
+    p = subprocess.Popen(cmd, env=env, start_new_session=True)
+    limit = (args.deadline + 120) if args.deadline > 0 else None
+    try:
+        return p.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        stage(f"ranks still running after {limit} s: killing process group {p.pid}")
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+    except KeyboardInterrupt:
+        os.killpg(p.pid, signal.SIGTERM)
+        raise
+
+
+def arm_deadlines(args):
+    import faulthandler
+    if args.deadline > 0:
+        # C-level timer thread: needs no GIL, fires even when the main thread is stuck inside a
+        # collective or a device synchronise.  Dumps every Python stack, then _exit(1); torchrun
+        # then tears the other ranks down, so the whole job ends non-zero.
+        faulthandler.dump_traceback_later(args.deadline, exit=True)
+    if args.watchdog > 0 and (args.deadline <= 0 or args.watchdog < args.deadline):
+        def soft():
+            time.sleep(args.watchdog)
+            sys.stderr.write(f"[bench r{os.environ.get('RANK', '0')}] watchdog: still running after {args.watchdog} s\n")
+            faulthandler.dump_traceback(all_threads=True)
+        threading.Thread(target=soft, daemon=True).start()
+
+
+# ---------------------------------------------------------------------------------------
+# CPU legs (the oracle is imported only here: bench.py's cpu_baseline leg)
+# ---------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        return [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        return "unknown"
 
 
 def cpu_baseline(args):
-    """The oracle's layer fwd+bwd (list of COO fp64, one sparse.mm per slice, autograd) on the
-    host cores, on a bounded sample: 2 slices of the same degree/F at N = cpu-nodes.  Timed at
-    two thread counts (all cores, and 32: torch's sparse kernels do not scale to hundreds of
-    threads) and the faster one is reported with the threads it used."""
+    """The oracle's layer fwd+bwd (list of COO fp64, one sparse.mm per slice, fp32 GEMM, autograd: the
+    reference's way) on the host cores, 2 slices of the S4 graph (same degree / F):
+      * the identical-N point SURVEY §8d defines (N = --nodes): 2 repetitions, each reported;
+      * a smaller sample (N = --cpu-nodes) with a warm-up and 3 repetitions, for the spread.
+    `value` is the identical-N rate when it was run, else the small sample's.  Threads: torch's
+    sparse kernels do not scale to hundreds of threads (256 threads were slower than 32 on the
+    EPYC 9575F in round 1), so min(32, cores) is used and stated."""
+    import torch
     from oracle import tmgcn_oracle as orc
     from tmgcn_amd import synth
 
     ncpu = os.cpu_count() or 1
-    Tc, Nc, F = 2, min(args.nodes, args.cpu_nodes), args.feat
-    A = synth.device_er_csr(Tc, Nc, args.deg, "cpu")
-    At = A.to_coo_list(torch.float64)
-    X = synth.device_features(Tc, Nc, F, "cpu").double()
-    M = torch.from_numpy(synth.band_M(Tc, args.band, "matlab"))
-    g = torch.Generator().manual_seed(1)
-    W = torch.randn(F, F, generator=g) * 0.1
-    dY = torch.randn(Tc, Nc, F, generator=g)
-    best = None
-    for threads in sorted({ncpu, min(32, ncpu)}):
-        torch.set_num_threads(threads)
-        orc.layer_fwd_bwd(M, At, X, W, dY)  # warm-up (allocator, thread pool)
-        reps, t0 = 0, time.perf_counter()
-        while True:
+    threads = min(32, ncpu)
+    torch.set_num_threads(threads)
+    Tc, F = 2, args.feat
+
+    def sample(Nc, reps, warm):
+        A = synth.device_er_csr(Tc, Nc, args.deg, "cpu")
+        At = A.to_coo_list(torch.float64)
+        X = synth.device_features(Tc, Nc, F, "cpu").double()
+        M = torch.from_numpy(synth.band_M(Tc, args.band, "matlab"))
+        g = torch.Generator().manual_seed(1)
+        W = torch.randn(F, F, generator=g) * 0.1
+        dY = torch.randn(Tc, Nc, F, generator=g)
+        if warm:
             orc.layer_fwd_bwd(M, At, X, W, dY)
-            reps += 1
-            el = time.perf_counter() - t0
-            if el > 6.0 or reps >= 3:
-                break
-        rate = A.nnz * reps / el
-        if best is None or rate > best[0]:
-            best = (rate, threads, reps, el)
-    rate, threads, reps, el = best
-    try:
-        model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-    except Exception:
-        model = "unknown"
-    return {"value": rate, "unit": "edge-slices/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x fwd+bwd of {Tc} slices, N={Nc}, deg={args.deg}+1, F={F}->{F} "
-                      f"(oracle = reference's way on torch CPU, best of {{{ncpu}, {min(32, ncpu)}}} threads, {model}); "
-                      f"{el / reps:.2f} s each"}
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            orc.layer_fwd_bwd(M, At, X, W, dY)
+            times.append(time.perf_counter() - t0)
+        return {"nodes": Nc, "slices": Tc, "edge_slices": A.nnz, "reps_s": [round(t, 3) for t in times],
+                "rate_best": A.nnz / min(times), "rate_mean": A.nnz * len(times) / sum(times)}
+
+    stage(f"cpu_baseline: N={args.cpu_nodes} sample, {threads} threads")
+    small = sample(min(args.nodes, args.cpu_nodes), 3, True)
+    full_n = args.nodes if args.cpu_full_nodes < 0 else args.cpu_full_nodes
+    full = None
+    if full_n and full_n > small["nodes"]:
+        stage(f"cpu_baseline: identical-N point N={full_n}")
+        full = sample(full_n, 2, False)
+    head = full or small
+    return {"value": head["rate_best"], "unit": "edge-slices/s", "cores": threads, "kind": "port",
+            "sample": f"oracle = the reference's way on torch CPU (COO fp64, sparse.mm per slice, autograd), {_cpu_model()}, "
+                      f"{threads} of {ncpu} hardware threads; fwd+bwd of {Tc} slices, deg={args.deg}+1, F={F}->{F}; "
+                      f"value = best of {len(head['reps_s'])} repetitions at N={head['nodes']} "
+                      f"({', '.join(str(t) for t in head['reps_s'])} s); extrapolates to T slices by T/2 (slices are independent)",
+            "identical_n": full, "small_sample": small}
 
 
-def main():
-    args = parse()
-    if args.watchdog > 0:
-        import faulthandler
-        faulthandler.dump_traceback_later(args.watchdog, exit=False)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    if args.single_device:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+EPOCH_MODELS = {  # the scripts' model per config
+    "S1": dict(kind="gcn2", hidden=[6, 6, 2], nonlin="selu"),   # experiment_bitcoin_our.py:107 (2-layer)
+    "S2": dict(kind="gcn", hidden=[6, 2]),                      # experiment_reddit_our_link_prediction.py:65
+    "S3": dict(kind="gcn2", hidden=[6, 6, 2], nonlin="selu", bf16=True),  # AMLSim, bf16 weights
+    "P128": dict(kind="gcn2", hidden=[128, 128, 2], nonlin="relu", scale=0.05),  # BASELINE.md §2 probe, wide features
+}
 
-    import torch.distributed as dist
-    if world > 1 or args.force_collectives:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+def gpu_epochs(g, spec, epochs, mode):
+    """Seconds per training epoch (zero_grad, gcn(), weighted CE, backward, SGD step — the loop of
+    experiment_reddit_our_link_prediction.py:75-81) on the device.
+    mode: "eager"   device targets + nn.CrossEntropyLoss on device logits
+          "graph"   the same epoch captured into one hipGraph and replayed
+          "fused"   eager with tmgcn_amd.WeightedCrossEntropy (the opt-in fused loss)
+          "script"  what an untouched reference script does: `import tmgcn_amd.ehf as ehf`,
+                    host-side targets, class weights and criterion (hosted.DeviceResult)"""
+    import torch
+    if mode == "script":
+        import tmgcn_amd.ehf as ehf
+    else:
+        import tmgcn_amd.layers as ehf
+    At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
+    edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels)
+    if mode != "script":
+        labels = labels.cuda()
+    torch.manual_seed(0)
+    kw = dict(condensed_W=True, use_Minv=False, param_dtype=torch.bfloat16 if spec.get("bf16") else torch.float32)
+    if spec["kind"] == "gcn":
+        m = ehf.EmbeddingGCN(At, X, edges, M, hidden_feat=spec["hidden"], **kw)
+    else:
+        m = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=spec["hidden"], nonlin2=spec["nonlin"], **kw)
+    if "scale" in spec:  # N(0,1) weights at width 128 overflow the activations; both sides scale the same way
+        with torch.no_grad():
+            for q in m.parameters():
+                q.mul_(spec["scale"])
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+    if mode == "fused":
+        from tmgcn_amd.losses import WeightedCrossEntropy
+        crit = WeightedCrossEntropy(torch.tensor([0.9, 0.1])).cuda()
+    elif mode == "script":
+        crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1]))
+    else:
+        crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1], device="cuda"))
+
+    def epoch():
+        opt.zero_grad(set_to_none=True)
+        loss = crit(m(), labels)
+        loss.backward()
+        opt.step()
+        return loss
+
+    first = float(epoch().detach())
+    for _ in range(3):
+        epoch()
+    if mode == "graph":
+        from tmgcn_amd.graphs import GraphedTrainStep
+        step = GraphedTrainStep(m, crit, opt, labels)
+        for _ in range(3):
+            step()
+        run = step
+    else:
+        run = epoch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        run()
+    torch.cuda.synchronize()
+    return first, (time.perf_counter() - t0) / epochs
+
+
+def cpu_epochs(g, spec, epochs, threads):
+    """The same epoch on the CPU oracle (the reference's way), `threads` torch threads."""
+    import torch
+    from oracle import tmgcn_oracle as orc
+    torch.set_num_threads(threads)
+    At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
+    edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels)
+    torch.manual_seed(0)
+    F = [X.shape[-1]] + spec["hidden"]
+    p = {k: torch.nn.Parameter(v * spec.get("scale", 1.0)) for k, v in orc.draw_params(spec["kind"], g.T, F).items()}
+    AtXt = orc.compute_AtXt(M, At, X)  # cached at construction, as the reference does (ehf:195)
+    src, dst = orc.flat_edge_index(edges, g.N)
+    opt = torch.optim.SGD(list(p.values()), lr=0.01, momentum=0.9)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1]))
+
+    def epoch():
+        opt.zero_grad()
+        if spec["kind"] == "gcn":
+            out = orc.gcn_forward(AtXt, p["W"], p["U"], src, dst)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            out = orc.gcn2_forward(AtXt, At, M, p["W1"], p["W2"], p["U"], src, dst, nonlin=spec["nonlin"])
+        loss = crit(out, labels)
+        loss.backward()
+        opt.step()
+        return float(loss)
 
-    from tmgcn_amd import _lib, ops, synth
+    first = epoch()
+    times = []
+    for _ in range(epochs):
+        t0 = time.perf_counter()
+        epoch()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return first, times[len(times) // 2]
+
+
+def epochs_block(args, configs=("S1", "S2", "S3"), modes=("eager", "graph", "fused", "script")):
+    """north_star's epoch-throughput target (>= 10x the reference's CPU epoch on Reddit link
+    prediction at 1 GPU), as a record: per config the GPU epoch in every mode, the CPU oracle's
+    epoch (median of --cpu-epoch-reps at 8 and at 32 threads, the better one reported) and the
+    ratio for an untouched script ("script" mode) and for the best mode."""
+    from tmgcn_amd import synth
+    ncpu = os.cpu_count() or 1
+    out = {}
+    for name in configs:
+        stage(f"epochs: {name}")
+        spec = EPOCH_MODELS[name]
+        g = synth.dynamic_graph(**synth.CONFIGS[name], seed=0)
+        rec = {"model": spec["kind"], "T": g.T, "N": g.N, "E": int(g.edges.shape[1]),
+               "nnz_At": int(sum(c.nnz for c in g.Ct)), "gpu_epochs_timed": args.epoch_reps,
+               "cpu_epochs_timed": args.cpu_epoch_reps}
+        loss_gpu = None
+        for mode in modes:
+            first, sec = gpu_epochs(g, spec, args.epoch_reps, mode)
+            rec[f"gpu_ms_{mode}"] = round(sec * 1e3, 4)
+            loss_gpu = first if loss_gpu is None else loss_gpu
+        cpu = {}
+        loss_cpu = None
+        for th in sorted({min(8, ncpu), min(32, ncpu)}):   # all 256 threads is pathological on these small ops
+            loss_cpu, cpu[th] = cpu_epochs(g, spec, args.cpu_epoch_reps, th)
+        th_best = min(cpu, key=cpu.get)
+        rec.update({"cpu_ms": round(cpu[th_best] * 1e3, 2), "cpu_threads": th_best,
+                    "cpu_ms_by_threads": {str(k): round(v * 1e3, 2) for k, v in cpu.items()},
+                    "first_loss_gpu": loss_gpu, "first_loss_cpu": loss_cpu})
+        best = min(rec[f"gpu_ms_{m}"] for m in modes)
+        rec["speedup_script_mode"] = round(rec["cpu_ms"] / rec["gpu_ms_script"], 1) if "script" in modes else None
+        rec["speedup_best_mode"] = round(rec["cpu_ms"] / best, 1)
+        out[name] = rec
+        gc.collect()
+    out["note"] = ("epoch = zero_grad, gcn(), class-weighted CE, backward, SGD step (experiment_reddit_our_link_prediction.py:75-81); "
+                   "S1/S2/S3 are synthetic stand-ins of the Bitcoin-OTC / Reddit-LP / AMLSim shapes (SURVEY §8d); CPU = the oracle "
+                   f"run the reference's way on {_cpu_model()}, median epoch")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# the layer bench proper
+# ---------------------------------------------------------------------------------------
+def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_timer=True):
+    """Build this rank's shard of the S4 layer at N nodes and time `steps` fwd+bwd steps.
+    Returns a dict; every device tensor dies with this frame."""
+    import torch
+    from tmgcn_amd import ops, synth
     from tmgcn_amd.dist import ShardedTMGCNLayer
-    _lib.load()  # fail loudly if the HIP library is missing
 
-    G, Tl, N, F = world, args.slices_per_gpu, args.nodes, args.feat
+    G, Tl, F = world, args.slices_per_gpu, args.feat
     T = Tl * G
     k0 = rank * Tl
     A = synth.device_er_csr(Tl, N, args.deg, dev, first_slice=k0)
     A.transpose()  # backward operand, built once (plan time, not timed)
     M = synth.band_M(T, args.band, "matlab")
-    layer = ShardedTMGCNLayer(A, M, T, group=None, exchange=args.exchange, fuse=False if args.no_fuse else None,
+    layer = ShardedTMGCNLayer(A, M, T, group=None, exchange=exchange, fuse=False if args.no_fuse else None,
                               pipeline=not args.no_pipeline, force_collectives=args.force_collectives,
                               grid_reserve=args.grid_reserve)
     shape = layer.input_shape(F)
-    if layer.collective and args.exchange == "a2a":
+    if layer.collective and exchange == "a2a":
         # node shard of the synthetic features: slice k seeded by k, columns of this rank's nodes
         X = synth.device_features(T, shape[1], F, dev, first_slice=1000 * rank)
     else:
@@ -166,16 +391,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    stage(f"layer[{exchange}, N={N}]: inputs resident, warm-up")
+    for _ in range(warmup):
         step()
-    ops.kernels.timer = ops.KernelTimer()
+    if want_timer:
+        ops.kernels.timer = ops.KernelTimer()
     fence()
+    stage(f"layer[{exchange}, N={N}]: timing {steps} steps")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    kt = ops.kernels.timer.summary()
+    kt = ops.kernels.timer.summary() if want_timer else {}
     ops.kernels.timer = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -186,62 +414,173 @@ def main():
         total_nnz = int(n.item())
     else:
         total_nnz = A.nnz
+    stage(f"layer[{exchange}, N={N}]: {elapsed / steps * 1e3:.1f} ms/step")
+    return {"elapsed": elapsed, "kt": kt, "nnz_rank": A.nnz, "rows_rank": A.n_rows, "total_nnz": total_nnz,
+            "collective": layer.collective, "grid_reserve": layer.grid_reserve, "T": T,
+            "peak_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
+
+
+def free_device_memory():
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def traffic_record(N, F, Tl):
+    """HBM-side traffic of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py);
+    None when the passes were taken at another problem size."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(pmc))
+        if rec.get("nodes") == N and rec.get("feat") == F and rec.get("slices_per_gpu") == Tl:
+            return rec["spmm_hbm_bytes_per_launch"], {
+                "file": "profiles/pmc_traffic.json", "profile": rec.get("profile"),
+                "derived_by": rec.get("derived_by", "tools/pmc_traffic.py"),
+                "meaning": "fabric-side bytes (L2 <-> Infinity Fabric: FETCH_SIZE x2 on gfx950 + WRITE_SIZE) from separate "
+                           "rocprofv3 --pmc passes of this workload, NOT measured in this run; Infinity-Cache hits are "
+                           "included, so HBM itself moves at most this"}
+    except Exception:
+        pass
+    return None, None
+
+
+def worker(args):
+    arm_deadlines(args)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    stage("importing torch")
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.single_device:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import torch.distributed as dist
+    ranks_info = None
+    if world > 1 or args.force_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # one node by contract: keep every bootstrap socket on loopback (the container hostname
+        # may not resolve, and a resolver time-out looks exactly like a stalled first run)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        stage(f"init_process_group({args.backend}) world={world}")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                       # first collective: communicator set-up happens here
+        torch.cuda.synchronize()
+        stage("first all-reduce done")
+        prop = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local, "device": f"cuda:{local}", "name": prop.name,
+                "pci_bus_id": getattr(prop, "pci_bus_id", None), "uuid": str(getattr(prop, "uuid", "")) or None,
+                "pid": os.getpid()}
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, mine)
+        ranks_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                      "rccl_ranks": int(one.item()) if args.backend == "nccl" else None,
+                      "allreduce_sum_of_ones": int(one.item()), "devices": gathered}
+
+    from tmgcn_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+
+    N, F, Tl = args.nodes, args.feat, args.slices_per_gpu
+    res = run_layer(args, dist, dev, rank, world, args.exchange, N, args.steps, args.warmup)
+    free_device_memory()
+
+    compare = None
+    if (world > 1 or args.force_collectives) and not args.no_compare_exchange and res["collective"]:
+        # a2a (node -> slice re-partition, the xGMI-first form) and the north-star's literal all-gather
+        # side by side.  The all-gather materialises [T,N,F] (forward) and again for the reduce-scatter
+        # input (backward) on every GPU, so at S4 size it only fits for small G: the pair is always
+        # measured at a reduced N, and at full N wherever it fits (decided collectively).
+        compare = {"reduced_n": {"nodes": min(N, args.compare_nodes)}}
+        for ex in ("a2a", "allgather"):
+            r = run_layer(args, dist, dev, rank, world, ex, min(N, args.compare_nodes), 3, 1, want_timer=False)
+            compare["reduced_n"][ex + "_ms_per_step"] = round(r["elapsed"] / 3 * 1e3, 3)
+            free_device_memory()
+        slab = Tl * N * F * 4
+        need = (2 * world + 8) * slab + 2 * res["nnz_rank"] * 8 + (2 << 30)
+        free_b, _total = torch.cuda.mem_get_info(dev)
+        ok = torch.tensor([1 if free_b > 1.1 * need else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        other = "allgather" if args.exchange == "a2a" else "a2a"
+        compare["full_n"] = {"nodes": N, args.exchange + "_ms_per_step": round(res["elapsed"] / args.steps * 1e3, 3),
+                             "allgather_needs_gb_per_gpu": round(need / 1e9, 1)}
+        if int(ok.item()) or other == "a2a":
+            r = run_layer(args, dist, dev, rank, world, other, N, 3, 1, want_timer=False)
+            compare["full_n"][other + "_ms_per_step"] = round(r["elapsed"] / 3 * 1e3, 3)
+            free_device_memory()
+        else:
+            compare["full_n"][other + "_ms_per_step"] = None
+            compare["full_n"]["note"] = "all-gather of [T,N,F] (+ its reduce-scatter input) does not fit beside the layer at this world size"
 
     out = None
     if rank == 0:
+        elapsed, kt = res["elapsed"], res["kt"]
         # roofline of the dominant kernel (forward SpMM): SURVEY §8d no-reuse gather model,
         # bytes per edge-slice = 8 (col+val) + F*4 (gathered row) + (4 + F*4)/d (rowptr + output row)
-        d = A.nnz / A.n_rows
+        d = res["nnz_rank"] / res["rows_rank"]
         bytes_per_unit = 8 + F * 4 + (4 + F * 4) / d
         # dominant kernel: the forward SpMM — fused with the GEMM epilogue when the widths allow
         # (then it also writes Y; only P2's own bytes are counted, conservatively)
         dom = "spmm_gemm" if "spmm_gemm" in kt else "spmm"
         sp = kt[dom]
         # one launch per step at N = 1; the pipelined multi-GPU path launches slice by slice
-        units_per_launch = A.nnz * args.steps / sp["launches"]
+        units_per_launch = res["nnz_rank"] * args.steps / sp["launches"]
         achieved = bytes_per_unit * units_per_launch / (sp["avg_ms"] * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("nodes") == N and rec.get("feat") == F and rec.get("slices_per_gpu") == Tl:
-                    traffic = rec["spmm_hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        traffic, traffic_source = traffic_record(N, F, Tl)
+        if sp["launches"] != args.steps:
+            traffic, traffic_source = None, None
         out = {
             "metric": "TM-GCN layer fwd+bwd throughput (edges x T)/s",
-            "value": total_nnz * args.steps / elapsed,
+            "value": res["total_nnz"] * args.steps / elapsed,
             "unit": "edge-slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"S4 TM-GCN layer fwd+bwd: {Tl} slices/GPU (T={T}), N={N}, "
+            "config": {"workload": f"S4 TM-GCN layer fwd+bwd: {Tl} slices/GPU (T={res['T']}), N={N}, "
                                    f"deg={args.deg}+self, F={F}->{F}, band-M b={args.band}, fp32",
-                       "exchange": args.exchange if layer.collective else "none", "grid_reserve": layer.grid_reserve,
-                       "edge_slices_per_step": total_nnz},
-            "roofline": {"kernel": "spmm_gemm_kernel (forward P2 + fused P3)" if dom == "spmm_gemm" else "spmm_vec4_kernel (forward P2)", "bound": "hbm", "achieved": achieved,
+                       "exchange": args.exchange if res["collective"] else "none", "grid_reserve": res["grid_reserve"],
+                       "edge_slices_per_step": res["total_nnz"]},
+            "roofline": {"kernel": "spmm_gemm_kernel (forward P2 + fused P3)" if dom == "spmm_gemm" else "spmm_vec4_kernel (forward P2)",
+                         "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic if sp["launches"] == args.steps else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "achieved_is": "algorithmic bytes (SURVEY §8d no-reuse gather model) / measured launch time, as a "
+                                        "fraction of the 8 TB/s spec; part of the gather is served by the 256 MB Infinity Cache",
                          "bytes_per_edge_slice": bytes_per_unit, "edge_slices_per_launch": units_per_launch,
                          "avg_launch_ms": sp["avg_ms"]},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
-            "peak_hbm_gb_rank0": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+            "peak_hbm_gb_rank0": round(res["peak_gb"], 1),
         }
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
+        if compare is not None:
+            out["exchange_compare"] = compare
         if "gemm_dW" in kt:
             # the one GEMM that still runs as its own kernel (dW = AXᵀ·dY); the forward / dA GEMMs run
             # inside the fused SpMM kernels, hidden under the gather.  It multiplies on the bf16 matrix
             # cores after an exact 3-way split of the fp32 operands: 6 bf16 MFMA products per fp32 term.
             t_dw = kt["gemm_dW"]["avg_ms"] * 1e-3
-            fp32_tf = 2.0 * A.n_rows * F * F / t_dw / 1e12
+            fp32_tf = 2.0 * res["rows_rank"] * F * F / t_dw / 1e12
             out["mfma"] = {"kernel": "gemm_dw_bf16x3_kernel (dW)", "bound": "mfma", "achieved": 6.0 * fp32_tf,
                            "peak": 2500.0, "unit": "TFLOP/s", "frac": 6.0 * fp32_tf / 2500.0,
                            "dtype": "bf16 planes of an exact 3-way fp32 split (v_mfma_f32_32x32x16_bf16), fp32 accumulate",
                            "fp32_equivalent_tflops": fp32_tf, "f32_mfma_peak_tflops": 157.3,
-                           "hbm_gbs": A.n_rows * 2 * F * 4 / t_dw / 1e9}
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args)
+                           "hbm_gbs": res["rows_rank"] * 2 * F * 4 / t_dw / 1e9}
+        if world == 1:  # the CPU legs are reported at N = 1 only
+            if not args.no_epochs:
+                out["epochs"] = epochs_block(args)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args)
     # RCCL prints its version banner through C stdio, which is flushed only at exit when stdout is
     # a pipe/file: every rank flushes it BEFORE the last barrier so that rank 0's JSON line is the
     # last line of the job's stdout.
@@ -252,10 +591,21 @@ def main():
         pass
     sys.stdout.flush()
     if dist.is_initialized():
+        stage("final barrier")
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    stage("done")
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one.  Nothing in this process has touched the GPU
+        # (torch is not even imported), the ranks are fresh processes.
+        sys.exit(launch(args))
+    worker(args)
 
 
 if __name__ == "__main__":

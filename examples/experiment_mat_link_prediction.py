@@ -5,15 +5,18 @@
     stage 2 (experiment_*_our_link_prediction.py)   load_data -> node features -> negative edges ->
             split -> EmbeddingGCN / EmbeddingGCN2 -> SGD on the weighted CE -> MAP / MRR
 
-Stage 2 below is written the way the reference's scripts are — host-side targets, class weights,
-criterion and bookkeeping — with ``import tmgcn_amd.ehf as ehf`` as the one changed line.  The raw
-rows are synthetic (a planted-community stream; no dataset ships with the reference, no network).
+Stage 2 calls the ``ehf`` surface the way a reference script does (host-side targets, class
+weights and criterion; ``import tmgcn_amd.ehf as ehf`` is the one line such a script changes) but
+keeps its own bookkeeping: one record per evaluation, a JSON summary at the end.  The contract of
+the untouched scripts themselves is pinned against the real reference in
+tests/test_gpu_experiment.py (fixture G9).  The raw rows are synthetic (a planted-community
+stream; no dataset ships with the reference, no network).
 
     python examples/experiment_mat_link_prediction.py [--epochs 300] [--layers 2] [--nodes 1000]
 """
 import argparse
 import os
-import pickle
+import json
 import random
 import sys
 import tempfile
@@ -69,53 +72,55 @@ preprocess.save_content(data_loc + mat_f_name, content)
 print("preprocessing: %d raw rows -> %s in %.2f s (nnz C = %d, nnz Ct_train = %d)"
       % (len(raw), mat_f_name, time.perf_counter() - tic, len(content["C_vals"]), len(content["Ct_train_vals"])))
 
-# ---- stage 2: the experiment script ----------------------------------------------------------------
+# ---- stage 2: model, training, evaluation -----------------------------------------------------
 A, A_labels, Ct_train_2, Ct_val_2, Ct_test_2, N, M = ehf.load_data(data_loc, mat_f_name, S_train, S_val, S_test, transformed=True)
 X_train, X_val, X_test = ehf.create_node_features(A, S_train, S_val, S_test, same_block_size=True)
-edges = A_labels._indices()
-edges_aug, labels = ehf.augment_edges(edges, N, beta1, beta2, cutoff)
+edges_aug, labels = ehf.augment_edges(A_labels._indices(), N, beta1, beta2, cutoff)
 (edges_train, target_train, e_train, edges_val, target_val, e_val, K_val,
  edges_test, target_test, e_test, K_test) = ehf.split_data(edges_aug, labels, S_train, S_val, S_test, same_block_size=True)
 
-class_weights = t.tensor([alpha, 1.0 - alpha])
+model_kw = dict(condensed_W=True, use_Minv=False)
 if no_layers == 2:
-    gcn = ehf.EmbeddingGCN2(Ct_train_2[:-1], X_train[:-1], e_train, M[:-1, :-1], hidden_feat=[6, 6, 2],
-                            condensed_W=True, use_Minv=False, nonlin2="selu")
+    gcn = ehf.EmbeddingGCN2(Ct_train_2[:-1], X_train[:-1], e_train, M[:-1, :-1], hidden_feat=[6, 6, 2], nonlin2="selu", **model_kw)
 else:
-    gcn = ehf.EmbeddingGCN(Ct_train_2[:-1], X_train[:-1], e_train, M[:-1, :-1], hidden_feat=[6, 2],
-                           condensed_W=True, use_Minv=False)
+    gcn = ehf.EmbeddingGCN(Ct_train_2[:-1], X_train[:-1], e_train, M[:-1, :-1], hidden_feat=[6, 2], **model_kw)
 optimizer = t.optim.SGD(gcn.parameters(), lr=lr, momentum=momentum)
-criterion = nn.CrossEntropyLoss(weight=class_weights)
-ep_acc_loss = np.zeros((no_epochs, 9))  # (MAP_train, MRR_train, loss_train, MAP_val, MRR_val, loss_val, MAP_test, MRR_test, loss_test)
-train_mask = edges_train[0] != 0
+criterion = nn.CrossEntropyLoss(weight=t.tensor([alpha, 1.0 - alpha]))
+in_window = edges_train[0] != 0                      # the first slice has no predecessor to predict it from
+y_train, pairs_train = target_train[in_window], edges_train[:, in_window]
 
+
+def held_out(At_list, X, e, K, target, pairs):
+    """Forward on another window; the last K labelled edges are the ones that count (split_data)."""
+    logits = gcn(At_list[:-1], X[:-1], e)[-K:]
+    MAP, MRR = ehf.compute_MAP_MRR(logits, target[-K:], pairs[:, -K:])
+    return {"MAP": float(MAP), "MRR": float(MRR), "loss": float(criterion(logits, target[-K:]))}
+
+
+history, losses = [], []
 tic = time.perf_counter()
 for ep in range(no_epochs):
     optimizer.zero_grad()
-    output_train = gcn()
-    loss_train = criterion(output_train, target_train[train_mask])
-    loss_train.backward()
+    logits = gcn()
+    loss = criterion(logits, y_train)
+    loss.backward()
     optimizer.step()
-
-    with t.no_grad():
-        if ep % args.eval_every == 0 or ep == no_epochs - 1:
-            MAP_train, MRR_train = ehf.compute_MAP_MRR(output_train, target_train[train_mask], edges_train[:, train_mask])
-            output_val = gcn(Ct_val_2[:-1], X_val[:-1], e_val)
-            MAP_val, MRR_val = ehf.compute_MAP_MRR(output_val[-K_val:], target_val[-K_val:], edges_val[:, -K_val:])
-            loss_val = criterion(output_val[-K_val:], target_val[-K_val:])
-            output_test = gcn(Ct_test_2[:-1], X_test[:-1], e_test)
-            MAP_test, MRR_test = ehf.compute_MAP_MRR(output_test[-K_test:], target_test[-K_test:], edges_test[:, -K_test:])
-            loss_test = criterion(output_test[-K_test:], target_test[-K_test:])
-            print("alpha/Tr/Ep %.2f/%d/%d. Train MAP/MRR %.16f/%.16f. Train loss %.16f." % (alpha, 0, ep, MAP_train, MRR_train, loss_train))
-            print("alpha/Tr/Ep %.2f/%d/%d. Val MAP/MRR %.16f/%.16f. Val loss %.16f." % (alpha, 0, ep, MAP_val, MRR_val, loss_val))
-            print("alpha/Tr/Ep %.2f/%d/%d. Test MAP/MRR %.16f/%.16f. Test loss %.16f.\n" % (alpha, 0, ep, MAP_test, MRR_test, loss_test))
-        ep_acc_loss[ep] = [MAP_train, MRR_train, loss_train, MAP_val, MRR_val, loss_val, MAP_test, MRR_test, loss_test]
+    losses.append(loss.detach())
+    if ep % args.eval_every == 0 or ep == no_epochs - 1:
+        with t.no_grad():
+            MAP, MRR = ehf.compute_MAP_MRR(logits, y_train, pairs_train)
+            rec = {"epoch": ep,
+                   "train": {"MAP": float(MAP), "MRR": float(MRR), "loss": float(loss)},
+                   "val": held_out(Ct_val_2, X_val, e_val, K_val, target_val, edges_val),
+                   "test": held_out(Ct_test_2, X_test, e_test, K_test, target_test, edges_test)}
+        history.append(rec)
+        print("epoch %4d   " % ep + "   ".join("%s: MAP %.4f MRR %.4f loss %.4f" % (k, v["MAP"], v["MRR"], v["loss"])
+                                                for k, v in rec.items() if k != "epoch"))
 t.cuda.synchronize()
-print("%d epochs in %.2f s (%d labelled training edges, logits on %s)"
-      % (no_epochs, time.perf_counter() - tic, int(train_mask.sum()), output_train.device))
-print("FINAL: Train MAP/MRR %.16f/%.16f. Train loss %.16f." % (MAP_train, MRR_train, loss_train))
-print("FINAL: Val MAP/MRR %.16f/%.16f. Val loss %.16f." % (MAP_val, MRR_val, loss_val))
-print("FINAL: Test MAP/MRR %.16f/%.16f. Test loss %.16f." % (MAP_test, MRR_test, loss_test))
-with open(data_loc + "results_OUR_layers%d_synthetic_link_prediction" % no_layers, "wb") as f:
-    pickle.dump(ep_acc_loss, f)
-assert ep_acc_loss[-1, 2] < ep_acc_loss[0, 2], "training loss did not go down"
+elapsed = time.perf_counter() - tic
+summary = {"layers": no_layers, "epochs": no_epochs, "seconds": round(elapsed, 3), "labelled_training_edges": int(in_window.sum()),
+           "logits_device": str(logits.device), "first_loss": float(losses[0]), "last_loss": float(losses[-1]), "final": history[-1]}
+print("summary: " + json.dumps(summary))
+with open(data_loc + "link_prediction_history.json", "w") as f:
+    json.dump({"summary": summary, "history": history}, f)
+assert summary["last_loss"] < summary["first_loss"], "training loss did not go down"

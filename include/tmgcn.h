@@ -44,16 +44,19 @@ typedef enum {
 /* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
 enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
 
+/* ABI version 2: no process-wide settings.  What used to be tmgcn_config_set() knobs are
+ * per-call arguments (grid_reserve of tmgcn_spmm_gemm_f32, algo of tmgcn_gemm_dw_f32): two callers
+ * in one process never see each other's choices. */
 int tmgcn_abi_version(void);
 const char* tmgcn_last_error(void);
-/* Process-wide tuning knobs (performance only, never results).
- *   "persistent_grid_reserve"  block slots the persistent fused kernel leaves free (default 0);
- *                              the sharded layer sets it so that RCCL's kernels on the side
- *                              stream can become resident next to the compute kernel.
- *   "dw_bf16x3"                1 (default): tmgcn_gemm_dw_f32 multiplies on the bf16 matrix cores after an
- *                              exact 3-way split of the fp32 operands (fp32-accurate, reproducible);
- *                              0: the exact-f32 MFMA kernel. */
-int tmgcn_config_set(const char* key, int64_t value);
+
+/* algorithm of tmgcn_gemm_dw_f32 (performance / instruction choice only; both are fp32-accurate,
+ * atomic-free and bitwise reproducible) */
+enum {
+  TMGCN_DW_AUTO = 0,    /* bf16 matrix cores after an exact 3-way split of the fp32 operands where the
+                           shapes allow (K, Nf >= 16, multiples of 4, 16-byte aligned), else exact f32 */
+  TMGCN_DW_F32MFMA = 1  /* always the exact-f32 MFMA kernel (v_mfma_f32_32x32x2_f32) */
+};
 
 /* ---- P1: tube-fibre M-transform ------------------------------------------------
  * Replaces  t.matmul(self.M, X.reshape(self.T,-1)).reshape(X.size())
@@ -103,7 +106,9 @@ int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int32_t* col, c
  * 471-472 + 486-489).  With the transposed CSR and trans_w=1 it is the backward pair, using
  * Âᵀ(dY·Wᵀ) = (Âᵀ·dY)·Wᵀ.  X is [n_rows][K]; W, trans_w, rows_per_batch, w_batch_stride, act,
  * pre_act as in tmgcn_gemm_f32.  AX (optional, may be NULL) receives the SpMM result
- * [n_rows][K] itself (needed for dW).  Supported when tmgcn_spmm_gemm_supported(K, Nf) != 0
+ * [n_rows][K] itself (needed for dW).  grid_reserve (>= 0, performance only, never results): block
+ * slots of the persistent grid THIS launch leaves free — the sharded layer passes one per CU so that
+ * RCCL's exchange kernels on a side stream can become resident next to the compute kernel.  Supported when tmgcn_spmm_gemm_supported(K, Nf) != 0
  * (K a multiple of 8 in [16, 128] with Nf <= 128 — MFMA epilogue — or K in {1,2,3,4,6,8} with Nf <= 16 —
  * the reference's real widths, FMA epilogue); otherwise call the two kernels separately.
  */
@@ -112,7 +117,7 @@ int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* 
                         const float* X, int64_t n_rows, int32_t N, int32_t K,
                         const float* W, int32_t Nf, int32_t trans_w,
                         int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
-                        float* Y, float* AX, float* pre_act, void* stream);
+                        float* Y, float* AX, float* pre_act, int32_t grid_reserve, void* stream);
 
 /* ---- P3: feature·weight contraction ----------------------------------------------
  * Replaces  t.matmul(AtXt, Wt)  ehf:222, 330, 340, 344, 349, 415, 486-489.
@@ -134,11 +139,12 @@ int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* pre_act,
  * (partial slabs, reduced in a fixed order: bitwise reproducible).
  * For K, Nf >= 16 (multiples of 4, 16-byte aligned operands) the products run as v_mfma_f32_32x32x16_bf16
  * on three bf16 planes per operand, x = hi + mid + lo exactly, keeping the six plane products above
- * 2^-24 |a·b|: the accuracy of an fp32 FMA chain at 2.7x the f32 MFMA rate.
+ * 2^-24 |a·b|: the accuracy of an fp32 FMA chain at 2.7x the f32 MFMA rate (algo = TMGCN_DW_AUTO;
+ * TMGCN_DW_F32MFMA selects the exact-f32 MFMA kernel for this call).
  */
 int64_t tmgcn_gemm_dw_workspace_bytes(int64_t R, int32_t K, int32_t Nf, int64_t rows_per_batch);
 int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW,
-                      int64_t R, int32_t K, int32_t Nf, int64_t rows_per_batch,
+                      int64_t R, int32_t K, int32_t Nf, int64_t rows_per_batch, int32_t algo,
                       void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- P5: pointwise non-linearity between layers (ehf:284-289, 332-334, 486) -------
@@ -174,16 +180,18 @@ int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const int64_t* d
  * Same value as  nn.CrossEntropyLoss(weight=w)(logits, target)  used by every experiment script
  * (experiment_reddit_our_link_prediction.py:69, 79): loss = Σ w[t]·nll / Σ w[t].  One streaming
  * pass each way with fp64 block sums in fixed order; C <= 8.  stats_out: 2 doubles {Σ w·nll, Σ w}
- * kept by the caller for the backward.  A target outside [0, C) carries no weight and gets a
- * zero gradient (the criterion's ignore_index = -100 is such a target).
+ * kept by the caller for the backward.  A target equal to ignore_index (outside [0, C); the
+ * criterion's default is -100) carries no weight and gets a zero gradient.  Any other target
+ * outside [0, C) is corrupt input: the loss and every gradient come out NaN (torch device-asserts
+ * there) — loud without a host synchronisation.
  */
 int64_t tmgcn_wce_workspace_bytes(int64_t E);
 int tmgcn_wce_fwd_f32(const float* logits, const int64_t* target, const float* weight, int64_t E,
-                      int32_t C, float* loss_out, double* stats_out, void* workspace,
+                      int32_t C, int64_t ignore_index, float* loss_out, double* stats_out, void* workspace,
                       int64_t workspace_bytes, void* stream);
 int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* weight,
                       const double* stats, const float* grad_loss, int64_t E, int32_t C,
-                      float* dlogits, void* stream);
+                      int64_t ignore_index, float* dlogits, void* stream);
 
 /* ---- adjacency pipeline on the device ----------------------------------
  * Replaces the reference's offline preprocessing loops: read_data.py:88-111 (symmetrise),

@@ -127,8 +127,18 @@ def gcn2_forward(AtXt, At_train, M, W1, W2, U, src, dst, nonlin="relu", use_Minv
     return edge_head(Z, src, dst, U)
 
 
+def pad_slices(AX: torch.Tensor, T: int) -> torch.Tensor:
+    """ehf:470: `AX = t.zeros(self.T, self.N, F)` — a call with fewer slices than the model's T
+    leaves the remaining slices zero."""
+    if AX.shape[0] >= T:
+        return AX
+    return torch.cat((AX, AX.new_zeros((T - AX.shape[0],) + tuple(AX.shape[1:]))), dim=0)
+
+
 def kwgcn_forward(AX, A_train, W1, U, src, dst, W2=None, nonlin="relu"):
-    """EmbeddingKWGCN.forward, ehf:485-497."""
+    """EmbeddingKWGCN.forward, ehf:485-497.  AX may hold fewer slices than A_train (a validation
+    window shorter than the training one): it is zero-padded to len(A_train) as ehf:470 does."""
+    AX = pad_slices(AX, len(A_train))
     if W2 is not None:
         Y = ACTS[nonlin](torch.matmul(AX, W1)).double()
         Z = torch.matmul(slice_spmm(A_train, Y), W2)

@@ -51,7 +51,7 @@ class OracleKernels:
     def spmm_gemm_supported(self, K, Nf):
         return (K % 8 == 0 and 16 <= K <= 128 and Nf <= 128) or (K in (1, 2, 3, 4, 6, 8) and Nf <= 16)  # the device rule
 
-    def spmm_gemm(self, A, X, W, trans_w=False, act=None, want_ax=False, want_pre=False, tag=None, out=None):
+    def spmm_gemm(self, A, X, W, trans_w=False, act=None, want_ax=False, want_pre=False, tag=None, out=None, grid_reserve=0):
         lists = _view_coo(A)
         AX = orc.slice_spmm(lists, X.double())
         Y, pre = self.gemm(AX, W, trans_w=trans_w, act=act, want_pre=True)
@@ -70,7 +70,7 @@ class OracleKernels:
         Y = orc.ACTS[act](pre) if act else pre
         return (Y, pre if act else None) if want_pre else Y
 
-    def gemm_dw(self, A, dY, per_slice):
+    def gemm_dw(self, A, dY, per_slice, algo=None):
         if per_slice:
             return torch.einsum("tnk,tnf->tkf", A.double(), dY.double()).float()
         return torch.einsum("tnk,tnf->kf", A.double(), dY.double()).float()

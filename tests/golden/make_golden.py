@@ -145,14 +145,20 @@ def g3():
 # ------------------------------------------------------------------------------ G4
 def g4():
     g = synth.dynamic_graph(9, 40, 60, seed=4, no_diag=3)
+    # a SHORTER validation window (the baseline scripts train on 150 slices and validate on 25):
+    # compute_AX zero-pads to the training T (ehf:469-473) and layer 2 runs over all of self.A
+    gv = synth.dynamic_graph(4, 40, 50, seed=44, no_diag=3)
     base = graph_inputs(g)
+    base.update(graph_inputs(gv, prefix="val_"))
     tgt = torch.tensor(g.labels)
     for hf, nl in (([6, 2], "relu"), ([6, 5, 2], "selu"), ([6, 5, 2], "leaky")):
         torch.manual_seed(31)
         m = ehf.EmbeddingKWGCN(ref_list(g.C), torch.tensor(g.X), torch.tensor(g.edges), hidden_feat=hf, nonlin2=nl)
         p0 = {n + "0": p.detach().numpy().copy() for n, p in m.named_parameters()}
         out, loss, grads = loss_and_grads(m, tgt)
-        save(f"g4_kwgcn_{len(hf) - 1}layer_{nl}", seed=31, logits=out, loss=loss,
+        with torch.no_grad():
+            out_val = m(ref_list(gv.C), torch.tensor(gv.X), torch.tensor(gv.edges)).numpy()
+        save(f"g4_kwgcn_{len(hf) - 1}layer_{nl}", seed=31, logits=out, loss=loss, logits_val=out_val,
              **{"d" + n: v for n, v in grads.items()}, **p0, **base)
 
 

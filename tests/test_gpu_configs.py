@@ -40,16 +40,27 @@ def _oracle(orc, kind, g, At, X, M, edges, labels, params, nonlin, dtype, dlogit
     return ref.detach(), {n: q.grad for n, q in p.items()}, dlogits
 
 
-def _check(got, ref32, truth, what):
-    """Bar at full size: within the stated 1e-5 of the reference-way fp32 result, OR at least as
-    close to the fp64 truth as twice the reference's own fp32 result is (sums over 10^5-10^6 terms:
-    the reference's fp32 reduction order is itself only good to a few 1e-5 there)."""
+CLAUSES = []   # one record per assertion: which clause of the bar it met, with the measured errors
+
+
+def _check(got, ref32, truth, what, strict=False):
+    """Bar at full size.  Clause A (the stated one): within 1e-5 of the reference-way
+    fp32 result.  Clause B (fallback for sums over 10^5-10^6 terms, where the reference's own fp32
+    reduction order is only good to a few 1e-5): at least as close to the fp64 truth as twice the
+    reference's own fp32 result is.  `strict` (S1, S3: small sums) accepts clause A only.  Every
+    call records which clause it needed and the measured errors (written to
+    gpurun_out/parity_clauses.json by the last test of this file)."""
     from _util import max_rel_err
     e_ref = max_rel_err(got, ref32)
     e_truth = max_rel_err(got, truth)
     e_ref_truth = max_rel_err(ref32, truth)
-    assert e_ref <= REL_TOL or e_truth <= max(REL_TOL, 2 * e_ref_truth), \
-        f"{what}: vs reference-fp32 {e_ref:.2e}, vs fp64 truth {e_truth:.2e} (reference itself {e_ref_truth:.2e})"
+    a = e_ref <= REL_TOL
+    b = e_truth <= max(REL_TOL, 2 * e_ref_truth)
+    CLAUSES.append({"what": what, "clause": "A (<=1e-5 vs reference-way fp32)" if a else
+                    ("B (closer to fp64 truth than 2x the reference's own fp32 error)" if b else "FAILED"),
+                    "err_vs_ref32": e_ref, "err_vs_fp64": e_truth, "ref32_vs_fp64": e_ref_truth, "strict": strict})
+    assert a or (b and not strict), \
+        f"{what}: vs reference-fp32 {e_ref:.2e}, vs fp64 truth {e_truth:.2e} (reference itself {e_ref_truth:.2e}); strict={strict}"
 
 
 def _run_model(name, kind, hidden, nonlin="selu", param_dtype=torch.float32, scale=1.0):
@@ -77,9 +88,9 @@ def _run_model(name, kind, hidden, nonlin="selu", param_dtype=torch.float32, sca
 
 def test_S1_bitcoin_shaped_2layer_fp32():
     m, out, (ref32, g32), (ref64, g64) = _run_model("S1", "gcn2", [6, 6, 2])
-    _check(out, ref32, ref64, "S1 logits")
+    _check(out, ref32, ref64, "S1 logits", strict=True)
     for n, q in m.named_parameters():
-        _check(q.grad, g32[n], g64[n], "S1 d" + n)
+        _check(q.grad, g32[n], g64[n], "S1 d" + n, strict=True)
 
 
 def test_S2_reddit_lp_shaped_1layer_fp32():
@@ -96,7 +107,7 @@ def test_S3_amlsim_shaped_bf16_weights():
     (<= 2^-8 relative), inside the stated bf16 tolerance 2e-2."""
     m, out, (ref32, g32), (ref64, g64) = _run_model("S3", "gcn2", [6, 6, 2], param_dtype=torch.bfloat16)
     assert all(q.dtype == torch.bfloat16 for q in m.parameters())
-    _check(out, ref32, ref64, "S3 logits")
+    _check(out, ref32, ref64, "S3 logits", strict=True)
     for n, q in m.named_parameters():
         assert q.grad.dtype == torch.bfloat16
         assert_close(q.grad.float(), g32[n], 2e-2, "S3 d" + n)
@@ -163,3 +174,19 @@ def test_S0_sbm_config_on_gpu():
     for n, q in m2.named_parameters():
         _check(q.grad, g32[n], g64[n], "S0 d" + n)
     assert torch.isfinite(out).all()
+
+
+def test_zz_write_parity_clause_record():
+    """Last test of the file: which clause of the bar every S0-S3 assertion needed, with the errors."""
+    import json
+    import os
+    assert CLAUSES, "the S-config tests did not run before this one"
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_clauses.json"), "w") as f:
+            json.dump(CLAUSES, f, indent=1)
+    except OSError:
+        pass
+    print(json.dumps(CLAUSES))
+    assert all(c["clause"] != "FAILED" for c in CLAUSES)

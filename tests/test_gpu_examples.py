@@ -20,7 +20,7 @@ def _run(*argv):
 def test_mat_link_prediction_example(layers):
     out = _run(os.path.join("examples", "experiment_mat_link_prediction.py"), "--epochs", "40", "--layers", str(layers),
                "--nodes", "300", "--edges-per-slice", "400", "--eval-every", "20")
-    assert "FINAL: Test MAP/MRR" in out and "logits on cuda" in out
+    assert "summary: {" in out and '"logits_device": "cuda' in out and "test: MAP" in out
 
 
 def test_synthetic_example():

@@ -194,23 +194,36 @@ def test_gemm_dw_bf16_split_is_fp32_accurate(K, Nf, R):
     """dW runs on the bf16 matrix cores through an exact 3-way split of the fp32 operands (hi + mid +
     lo planes, six plane products per term).  Against an fp64 product, on operands whose rows span
     six orders of magnitude, it must be as accurate as the exact-f32 MFMA kernel it replaces — both
-    are selectable through tmgcn_config_set("dw_bf16x3", 0 | 1) — and bit-reproducible."""
-    from tmgcn_amd import _lib
-    lib = _lib.load()
+    are selectable per call (algo = TMGCN_DW_F32MFMA | TMGCN_DW_AUTO) — and bit-reproducible."""
     g = torch.Generator().manual_seed(R)
     A = (torch.randn(1, R, K, generator=g) * torch.exp(torch.randn(1, R, 1, generator=g) * 3)).to(DEV)
     dY = torch.randn(1, R, Nf, generator=g).to(DEV)
     ref = A[0].double().T @ dY[0].double()
     err = {}
-    try:
-        for mode in (0, 1):
-            _lib.check(lib.tmgcn_config_set(b"dw_bf16x3", mode), "config_set")
-            got = ops.kernels.gemm_dw(A, dY, False)
-            err[mode] = max_rel_err(got, ref)
-            assert torch.equal(got, ops.kernels.gemm_dw(A, dY, False)), "dW not reproducible"
-    finally:
-        lib.tmgcn_config_set(b"dw_bf16x3", 1)
+    for mode, algo in ((0, "f32mfma"), (1, "auto")):
+        got = ops.kernels.gemm_dw(A, dY, False, algo=algo)
+        err[mode] = max_rel_err(got, ref)
+        assert torch.equal(got, ops.kernels.gemm_dw(A, dY, False, algo=algo)), "dW not reproducible"
     assert err[1] <= 2e-6 and err[1] <= 2 * err[0] + 1e-7, err
+
+
+def test_grid_reserve_is_per_launch_not_process_wide():
+    """Two layers with different reserves in one process: each launch gets its own grid (read back
+    from the launch through the kernel timer hook), results identical, and an unsharded launch that
+    follows a reserved one is back at the full grid — there is no process-wide setting (ABI v2)."""
+    from tmgcn_amd import _lib
+    lib = _lib.load()
+    assert not hasattr(lib, "tmgcn_config_set")
+    A = rand_csr(2, 40000, 9.0, 3).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(2, 40000, 64, generator=g).to(DEV)
+    W = torch.randn(64, 64, generator=g).to(DEV)
+    y0, _, _ = ops.kernels.spmm_gemm(A, X, W)
+    y1, _, _ = ops.kernels.spmm_gemm(A, X, W, grid_reserve=256)
+    y2, _, _ = ops.kernels.spmm_gemm(A, X, W, grid_reserve=0)
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
+    with pytest.raises(RuntimeError):
+        ops.kernels.spmm_gemm(A, X, W, grid_reserve=-1)
 
 
 def test_gemm_many_rows_persistent_loop():
@@ -347,6 +360,22 @@ def test_edge_head_fwd_bwd(F, C, E):
     assert torch.equal(Z2.grad, Zg.grad) and torch.equal(U2.grad, Ug.grad)
 
 
+def test_edge_index_is_validated_before_any_launch():
+    """The forward kernel gathers Z[t*N+node] unchecked, so the index is checked once per edge set
+    (ADVICE r1): slice >= T, node >= N or a negative entry raise (IndexError, as the reference's
+    ``Y.reshape(-1,F)[idx]`` does, and RuntimeError for callers that catch that)."""
+    ok = torch.tensor([[0, 1], [1, 2], [3, 4]])
+    ops.EdgeIndex(ok, 10, DEV, T=2)
+    for bad in ([[0, 2], [1, 2], [3, 4]], [[0, 1], [1, 10], [3, 4]], [[0, 1], [1, 2], [3, -1]], [[-1, 1], [1, 2], [3, 4]]):
+        for dev in ("cpu", DEV):
+            with pytest.raises(IndexError):
+                ops.EdgeIndex(torch.tensor(bad).to(dev), 10, DEV, T=2)
+            with pytest.raises(RuntimeError):
+                ops.EdgeIndex(torch.tensor(bad).to(dev), 10, DEV, T=2)
+    with pytest.raises(RuntimeError):
+        ops.EdgeIndex(torch.zeros(2, 5, dtype=torch.int64), 10, DEV, T=2)
+
+
 def test_edge_head_wide_falls_back():
     assert not ops.kernels.edge_head_supported(300, 2)
     Z = torch.randn(2, 10, 300, device=DEV)
@@ -358,6 +387,39 @@ def test_edge_head_wide_falls_back():
 
 
 # ------------------------------------------------------------------------------------- weighted CE (opt-in)
+def test_weighted_cross_entropy_ignore_index_and_corrupt_labels():
+    """ignore_index targets are skipped exactly as torch skips them; any OTHER label outside [0, C)
+    (torch device-asserts there) makes the loss and every gradient NaN — loud, never a silently
+    smaller training set."""
+    from tmgcn_amd.losses import WeightedCrossEntropy
+    g = torch.Generator().manual_seed(3)
+    E, C = 5000, 3
+    z = torch.randn(E, C, generator=g)
+    t = torch.randint(0, C, (E,), generator=g)
+    w = torch.rand(C, generator=g) + 0.1
+    t_ign = t.clone()
+    t_ign[::5] = -100
+    zr = z.double().clone().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss(weight=w.double())(zr, t_ign)
+    ref.backward()
+    zg = z.to(DEV).requires_grad_(True)
+    loss = WeightedCrossEntropy(w)(zg, t_ign.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert_close(zg.grad, zr.grad, 1e-6, "wce grad with ignore_index")
+    assert float(zg.grad[::5].abs().max()) == 0.0
+    for corrupt in (C, -1, 7):
+        t_bad = t.clone()
+        t_bad[17] = corrupt
+        zb = z.to(DEV).requires_grad_(True)
+        lb = WeightedCrossEntropy(w)(zb, t_bad.to(DEV))
+        lb.backward()
+        assert torch.isnan(lb) and torch.isnan(zb.grad).all(), corrupt
+    with pytest.raises(RuntimeError):                                   # an in-range class cannot be the ignored one
+        WeightedCrossEntropy(w, ignore_index=1)(z.to(DEV), t.to(DEV))
+
+
+
 @pytest.mark.parametrize("E,C", [(1, 2), (1000, 2), (5000, 3), (300, 8), (3_000_001, 2)])
 def test_weighted_cross_entropy_matches_torch_fp64(E, C):
     from tmgcn_amd.losses import WeightedCrossEntropy

@@ -93,6 +93,15 @@ def test_g4_kwgcn(name):
     assert_close(out, d["logits"], TOL, name)
     for n in g:
         assert_close(g[n], d["d" + n], TOL, name + " d" + n)
+    # validation-style call on a SHORTER slice list (the baseline scripts: 25 vs 150 slices):
+    # AX zero-padded to the training T, layer 2 over all of self.A (ehf:469-473, 486-487)
+    v = _inputs(d, "val_")
+    assert v["T"] < i["T"]
+    with torch.no_grad():
+        out_val = m(v["A"], v["X"], v["edges"])
+    assert_close(out_val, d["logits_val"], TOL, name + " shorter validation window")
+    with pytest.raises(RuntimeError):                       # more slices than the model holds: ehf raises too
+        m(i["A"] + v["A"], torch.cat((i["X"], v["X"])), i["edges"])
 
 
 def test_g5_chess():

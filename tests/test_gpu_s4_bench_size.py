@@ -1,0 +1,143 @@
+"""GPU: the bench-size S4 shard itself (the configuration bench.py's headline number is quoted on):
+T = 16 slices, N = 2,000,000, 32+1 stored non-zeros per row, F = 128 -> 128, fused P2+P3 kernel,
+bf16x3 dW at R = 32 M rows — checked against the C oracle (oracle/tmgcn_ref.c: ref_mtransform,
+ref_spmm, ref_gemm, ref_gemm_dw; fp64 accumulation as ehf:204-207 does) on sampled rows:
+
+  * 4,096 sampled nodes, the SAME in every slice; only those rows' CSR segments and the rows of
+    the dense operand they gather are copied to the host;
+  * P1:  Xt[:, ids]                 vs ref_mtransform on the sampled tube fibres
+  * P2+P3:  Y[k, ids]               vs ref_gemm(ref_spmm(segments, gathered Xt rows), W), per slice
+  * P3ᵀ+P2ᵀ+P1ᵀ:  dX[:, ids]        vs Mᵀ ×₁ ref_gemm(ref_spmm(transposed segments, gathered dY rows), Wᵀ)
+  * dW: the same kernel on a strided row subsample vs ref_gemm_dw, and the full-size result vs
+    an fp64 product formed on the device, plus <W, dW> = <Y, dY> = <X, dX> at full size.
+Needs ~150 GB of HBM (skipped on smaller devices).  Reference statements: ehf:203-208, 222."""
+import numpy as np
+import pytest
+import torch
+
+from _util import REL_TOL, assert_close, cptr, load_c_oracle
+from tmgcn_amd import ops, synth
+from tmgcn_amd.dist import ShardedTMGCNLayer
+
+pytestmark = pytest.mark.gpu
+
+T, N, F, DEG, BAND, S = 16, 2_000_000, 128, 32, 20, 4096
+
+
+def _segments(A, k, ids):
+    """Host copies of the CSR segments of rows `ids` of slice k: (rowptr_sub, col (in-slice), val)."""
+    r = ids + k * A.N
+    lo, hi = A.rowptr[r], A.rowptr[r + 1]
+    cnt = (hi - lo)
+    sub = torch.zeros(ids.numel() + 1, dtype=torch.int64, device=ids.device)
+    torch.cumsum(cnt, 0, out=sub[1:])
+    total = int(sub[-1])
+    # position p of the concatenated segments -> global offset
+    seg = torch.repeat_interleave(torch.arange(ids.numel(), device=ids.device), cnt)
+    off = torch.arange(total, device=ids.device) - sub[seg] + lo[seg]
+    return sub.cpu(), A.col[off].long(), A.val[off].cpu(), total
+
+
+def _oracle_rows(lib, sub, val, gathered, W, trans_w):
+    """ref_gemm(ref_spmm(...)) for the sampled rows.  `gathered` holds, for every stored non-zero of
+    the sampled rows in order, the dense row it multiplies — so the sub-problem's column index is
+    simply the position."""
+    nnz, Fk = gathered.shape
+    n_rows = sub.numel() - 1
+    Nsub = max(nnz, n_rows)
+    Xs = torch.zeros(Nsub, Fk, dtype=torch.float32)
+    Xs[:nnz] = gathered
+    col = torch.arange(nnz, dtype=torch.int32)
+    AX = torch.empty(n_rows, Fk, dtype=torch.float32)
+    lib.ref_spmm(cptr(sub), cptr(col), cptr(val), cptr(Xs), cptr(AX), n_rows, Nsub, Fk)
+    Nf = W.shape[0] if trans_w else W.shape[1]
+    Y = torch.empty(n_rows, Nf, dtype=torch.float32)
+    lib.ref_gemm(cptr(AX), cptr(W), cptr(Y), n_rows, Fk, Nf, int(trans_w), 0, 0)
+    return Y, AX
+
+
+def test_s4_bench_shard_against_the_c_oracle():
+    if torch.cuda.get_device_properties(0).total_memory < 200e9:
+        pytest.skip("needs a 288 GB device")
+    lib = load_c_oracle()
+    dev = torch.device("cuda", 0)
+    K = ops.kernels
+    assert K.name == "hip"
+    A = synth.device_er_csr(T, N, DEG, dev)
+    At = A.transpose()
+    M64 = synth.band_M(T, BAND, "matlab")
+    X = synth.device_features(T, N, F, dev).requires_grad_(True)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    W = (torch.randn(F, F, device=dev, generator=g) * 0.1).requires_grad_(True)
+    g.manual_seed(99)
+    dY = torch.randn(T, N, F, device=dev, generator=g)
+
+    # --- the bench's step, through the same layer object bench.py uses --------------------
+    layer = ShardedTMGCNLayer(A, M64, T)
+    assert K.spmm_gemm_supported(F, F)                 # the fused kernel is the one that runs
+    K.timer = ops.KernelTimer()
+    Y = layer(X, W)
+    Y.backward(dY)
+    tags = set(K.timer.summary())
+    K.timer = None
+    assert {"mtransform", "spmm_gemm", "spmm_gemm_T", "gemm_dW", "mtransform_T"} <= tags, tags
+    Y, dX, dW = Y.detach(), X.grad, W.grad
+
+    ids = torch.randperm(N, device=dev, generator=g)[:S].sort().values
+    Wc = W.detach().cpu().contiguous()
+    Mc = torch.from_numpy(np.ascontiguousarray(M64))
+
+    # --- P1 on the sampled tube fibres ----------------------------------------------------
+    Xt = K.mtransform(layer.Mop, X.detach())
+    Xs = X.detach()[:, ids, :].contiguous().cpu()                        # [T, S, F]
+    ref = torch.empty_like(Xs)
+    lib.ref_mtransform(cptr(Mc), T, 0, cptr(Xs), cptr(ref), S * F)
+    assert_close(Xt[:, ids, :], ref, REL_TOL, "S4 P1 sampled fibres")
+
+    # --- P2+P3 forward and the P3ᵀ+P2ᵀ backward, slice by slice --------------------------------
+    dXt_ref = torch.empty(T, S, F, dtype=torch.float32)
+    worst_y = 0.0
+    for k in range(T):
+        sub, col, val, nnz = _segments(A, k, ids)
+        assert nnz == S * (DEG + 1)
+        gathered = Xt[k][col].cpu()
+        y_ref, _ = _oracle_rows(lib, sub, val, gathered, Wc, False)
+        assert_close(Y[k][ids], y_ref, REL_TOL, f"S4 Y slice {k}")
+        worst_y = max(worst_y, float((Y[k][ids].cpu() - y_ref).abs().max() / y_ref.abs().max()))
+        # backward: dXt[k] = Âᵀ_k (dY_k Wᵀ)  ==  (Âᵀ_k dY_k) Wᵀ
+        sub, col, val, nnz = _segments(At, k, ids)
+        gathered = dY[k][col].cpu()
+        dXt_ref[k], _ = _oracle_rows(lib, sub, val, gathered, Wc, True)
+    dX_ref = torch.empty_like(dXt_ref)
+    lib.ref_mtransform(cptr(Mc), T, 1, cptr(dXt_ref), cptr(dX_ref), S * F)
+    assert_close(dX[:, ids, :], dX_ref, REL_TOL, "S4 dX sampled rows")
+    del Xt
+
+    # --- dW -----------------------------------------------------------------------------------
+    Y2, AX, _ = K.spmm_gemm(A, K.mtransform(layer.Mop, X.detach()), W.detach(), want_ax=True)
+    assert torch.equal(Y2, Y)                                            # reproducible, bit for bit
+    del Y2
+    dW2 = K.gemm_dw(AX, dY, per_slice=False)
+    assert torch.equal(dW2, dW)
+    # (a) the same kernel on a strided row subsample vs the C oracle
+    stride = 509                                                         # prime: hits every slice and row phase
+    A_sub = AX.reshape(-1, F)[::stride].contiguous()
+    dY_sub = dY.reshape(-1, F)[::stride].contiguous()
+    Rs = A_sub.shape[0]
+    dW_sub = K.gemm_dw(A_sub.view(1, Rs, F), dY_sub.view(1, Rs, F), per_slice=False)
+    ref = torch.empty(F, F, dtype=torch.float32)
+    a_h, d_h = A_sub.cpu(), dY_sub.cpu()
+    lib.ref_gemm_dw(cptr(a_h), cptr(d_h), cptr(ref), Rs, F, F, 0)
+    assert_close(dW_sub, ref, REL_TOL, "S4 dW strided subsample vs C oracle")
+    # (b) the full 32 M-row reduction vs an fp64 product formed on the device, slice by slice
+    acc = torch.zeros(F, F, dtype=torch.float64, device=dev)
+    for k in range(T):
+        acc += AX[k].double().t() @ dY[k].double()
+    assert_close(dW, acc, REL_TOL, "S4 dW full size vs fp64")
+    # (c) the adjoint identities tie the three results together at full size
+    lhs = sum(float((Y[k].double() * dY[k].double()).sum()) for k in range(T))
+    rhs_x = sum(float((X.detach()[k].double() * dX[k].double()).sum()) for k in range(T))
+    rhs_w = float((W.detach().double() * dW.double()).sum())
+    assert abs(lhs - rhs_x) <= 1e-5 * abs(lhs), (lhs, rhs_x)
+    assert abs(lhs - rhs_w) <= 1e-5 * abs(lhs), (lhs, rhs_w)
+    print(f"S4 bench shard: worst sampled-row error of Y {worst_y:.2e}")

@@ -119,6 +119,12 @@ def test_g4_kwgcn(name):
     assert_close(out, d["logits"], 1e-6, name)
     for k in p:
         assert_close(g[k], d["d" + k], 2e-6, name + " d" + k)
+    v = _inputs(d, prefix="val_")                               # shorter validation window, zero-padded (ehf:470)
+    assert v["T"] < i["T"]
+    vs, vd = orc.flat_edge_index(v["edges"], v["N"])
+    with torch.no_grad():
+        out_val = orc.kwgcn_forward(orc.slice_spmm(v["A"], v["X"]), i["A"], p["W1"], p["U"], vs, vd, p.get("W2"), nl)
+    assert_close(out_val, d["logits_val"], 1e-6, name + " val")
 
 
 def test_g5_chess_pipeline_and_model():

@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libtmgcn_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tmgcn.h")
 
 ACT_IDS = {None: 0, "none": 0, "relu": 1, "leaky": 2, "selu": 3}
+DW_ALGOS = {None: 0, "auto": 0, "f32mfma": 1}   # TMGCN_DW_AUTO / TMGCN_DW_F32MFMA
+ABI_VERSION = 2
 
 
 class TmgcnLibraryError(RuntimeError):
@@ -26,22 +28,21 @@ _i64 = C.c_int64
 SIGNATURES = {
     "tmgcn_abi_version": (C.c_int, []),
     "tmgcn_last_error": (C.c_char_p, []),
-    "tmgcn_config_set": (C.c_int, [C.c_char_p, _i64]),
     "tmgcn_mtransform_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_spmm_csr_batched_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_spmm_csr_batched_f32_hint": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, C.c_float, _p]),
     "tmgcn_spmm_gemm_supported": (C.c_int, [_i32, _i32]),
-    "tmgcn_spmm_gemm_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _i32, _i64, _i64, _i32, _p, _p, _p, _p]),
+    "tmgcn_spmm_gemm_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _i32, _i64, _i64, _i32, _p, _p, _p, _i32, _p]),
     "tmgcn_gemm_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _p]),
     "tmgcn_gemm_dw_workspace_bytes": (_i64, [_i64, _i32, _i32, _i64]),
-    "tmgcn_gemm_dw_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i64, _p, _i64, _p]),
+    "tmgcn_gemm_dw_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i64, _i32, _p, _i64, _p]),
     "tmgcn_edge_head_supported": (C.c_int, [_i32, _i32]),
     "tmgcn_edge_head_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_edge_head_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "tmgcn_edge_head_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i64, _p]),
     "tmgcn_wce_workspace_bytes": (_i64, [_i64]),
-    "tmgcn_wce_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
-    "tmgcn_wce_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
+    "tmgcn_wce_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _i64, _p]),
+    "tmgcn_wce_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i64, _p, _p]),
     "tmgcn_adj_make_keys": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "tmgcn_coo_sort_reduce_workspace_bytes": (_i64, [_i64]),
     "tmgcn_coo_sort_reduce": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),

@@ -41,12 +41,6 @@ constexpr int kWave = 64;  // gfx950 wavefront
 // Grid size of a persistent kernel: CUs x resident blocks per CU (occupancy API, capped at 4:
 // MI355X_MICROARCH.md warns the API can over-report by one for SGPR-heavy kernels; a persistent
 // grid that is not fully resident runs its tail blocks serially).  Cached per kernel.
-// Blocks to leave free when sizing a persistent grid (tmgcn_config_set("persistent_grid_reserve")):
-// in the multi-GPU path RCCL's kernels run on a side stream and can only become resident if the
-// persistent compute kernels do not hold every block slot of every CU.
-int persistent_grid_reserve();
-// dW through the 3-way bf16 split on the bf16 matrix cores (tmgcn_config_set("dw_bf16x3")), default on
-bool dw_bf16x3_enabled();
 
 template <typename K>
 inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0) {
@@ -69,9 +63,12 @@ inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0) {
   return cached;
 }
 
+// Persistent grid minus `reserve` block slots (a per-call argument of the C-ABI): in the multi-GPU
+// path RCCL's kernels run on a side stream and can only become resident if the persistent compute
+// kernel does not hold every block slot of every CU.
 template <typename K>
-inline int persistent_grid_reserved(K kernel, int block_threads, size_t dyn_smem = 0) {
-  int g = persistent_grid(kernel, block_threads, dyn_smem) - persistent_grid_reserve();
+inline int persistent_grid_reserved(K kernel, int block_threads, int reserve, size_t dyn_smem = 0) {
+  int g = persistent_grid(kernel, block_threads, dyn_smem) - reserve;
   return g < 64 ? 64 : g;
 }
 

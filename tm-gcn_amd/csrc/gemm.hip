@@ -688,9 +688,10 @@ extern "C" int64_t tmgcn_gemm_dw_workspace_bytes(int64_t R, int32_t K, int32_t N
 }
 
 extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int64_t R, int32_t K,
-                                  int32_t Nf, int64_t rows_per_batch, void* workspace,
+                                  int32_t Nf, int64_t rows_per_batch, int32_t algo, void* workspace,
                                   int64_t workspace_bytes, void* stream) {
   TMGCN_REQUIRE(R >= 0 && K > 0 && Nf > 0, "gemm_dw: bad shape");
+  TMGCN_REQUIRE(algo == TMGCN_DW_AUTO || algo == TMGCN_DW_F32MFMA, "gemm_dw: unknown algo %d", algo);
   TMGCN_REQUIRE(rows_per_batch >= 0, "gemm_dw: negative rows_per_batch");
   TMGCN_REQUIRE(dW, "gemm_dw: null dW");
   hipStream_t st = (hipStream_t)stream;
@@ -715,7 +716,7 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
     hipLaunchKernelGGL(gemm_dw_small_kernel, dim3(gx), dim3(256), smem, st, a);
   } else {
     const unsigned gy = (unsigned)(((K + 127) / 128) * ((Nf + 127) / 128));
-    const bool x3 = dw_bf16x3_enabled() && K % 4 == 0 && Nf % 4 == 0 &&
+    const bool x3 = algo == TMGCN_DW_AUTO && K % 4 == 0 && Nf % 4 == 0 &&
                     reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(dY) % 16 == 0;
     if (x3)
       hipLaunchKernelGGL(gemm_dw_bf16x3_kernel, dim3(gx, gy), dim3(256), 0, st, a);

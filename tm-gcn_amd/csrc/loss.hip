@@ -28,7 +28,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 // partial[b] = {Σ w·nll, Σ w} over the edges of block b (grid-stride, fixed assignment)
 __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ tgt,
                                                        const float* __restrict__ w, int64_t E, int C,
-                                                       double* __restrict__ partial) {
+                                                       int64_t ignore_index, double* __restrict__ partial) {
   __shared__ double sh[4];
   double num = 0.0, den = 0.0;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)
       if (c < C) s += expf(v[c] - mx);
-    // a target outside [0, C) carries no weight (nn.CrossEntropyLoss's ignore_index = -100 lands here)
+    // target == ignore_index carries no weight (nn.CrossEntropyLoss's -100).  Any OTHER label outside
+    // [0, C) is an error in the caller's data (torch device-asserts there): it poisons both sums with
+    // NaN, so the loss and — through stats[1] — every gradient come out NaN instead of the model
+    // silently training on a subset.  No host synchronisation needed to make it loud.
     const int64_t t64 = tgt[e];
     const bool valid = t64 >= 0 && t64 < C;
     const int t = valid ? (int)t64 : 0;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)
       if (c == t) zt = v[c];
-    const double wt = valid ? (double)w[t] : 0.0;
+    const double wt = valid ? (double)w[t] : (t64 == ignore_index ? 0.0 : (double)NAN);
     num += wt * ((double)mx + (double)logf(s) - (double)zt);
     den += wt;
   }
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(64) void wce_finish_kernel(const double* __restrict
 __global__ __launch_bounds__(256) void wce_bwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ tgt,
                                                        const float* __restrict__ w, const double* __restrict__ stats,
                                                        const float* __restrict__ gout, int64_t E, int C,
-                                                       float* __restrict__ dz) {
+                                                       int64_t ignore_index, float* __restrict__ dz) {
   const float g = gout[0];
   const double den = stats[1];
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
@@ -113,7 +116,8 @@ __global__ __launch_bounds__(256) void wce_bwd_kernel(const float* __restrict__ 
     const int64_t t64 = tgt[e];
     const bool valid = t64 >= 0 && t64 < C;
     const int t = valid ? (int)t64 : 0;
-    const float scale = valid ? (float)((double)g * (double)w[t] / den) : 0.f;
+    // den is NaN when the forward met an invalid label: every valid row's gradient is NaN then
+    const float scale = valid ? (float)((double)g * (double)w[t] / den) : (t64 == ignore_index ? 0.f : NAN);
     const float inv = 1.f / s;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)
@@ -135,8 +139,10 @@ using namespace tmgcn;
 extern "C" int64_t tmgcn_wce_workspace_bytes(int64_t E) { return (int64_t)loss_blocks(E) * 2 * sizeof(double) + 64; }
 
 extern "C" int tmgcn_wce_fwd_f32(const float* logits, const int64_t* target, const float* weight, int64_t E,
-                                  int32_t C, float* loss_out, double* stats_out, void* workspace,
-                                  int64_t workspace_bytes, void* stream) {
+                                  int32_t C, int64_t ignore_index, float* loss_out, double* stats_out,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+  TMGCN_REQUIRE(ignore_index < 0 || ignore_index >= C, "wce: ignore_index %lld names a real class (C=%d)",
+                (long long)ignore_index, C);
   TMGCN_REQUIRE(E > 0 && C >= 1 && C <= kLossMaxC, "wce: need E > 0 and 1 <= C <= %d (got E=%lld C=%d)", kLossMaxC,
                 (long long)E, C);
   TMGCN_REQUIRE(logits && target && weight && loss_out && stats_out && workspace, "wce: null pointer");
@@ -146,17 +152,18 @@ extern "C" int tmgcn_wce_fwd_f32(const float* logits, const int64_t* target, con
   }
   hipStream_t st = (hipStream_t)stream;
   const int nb = loss_blocks(E);
-  hipLaunchKernelGGL(wce_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, target, weight, E, C, (double*)workspace);
+  hipLaunchKernelGGL(wce_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, target, weight, E, C, ignore_index,
+                     (double*)workspace);
   hipLaunchKernelGGL(wce_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, nb, loss_out, stats_out);
   return check_launch("wce_fwd");
 }
 
 extern "C" int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* weight,
                                   const double* stats, const float* grad_loss, int64_t E, int32_t C,
-                                  float* dlogits, void* stream) {
+                                  int64_t ignore_index, float* dlogits, void* stream) {
   TMGCN_REQUIRE(E > 0 && C >= 1 && C <= kLossMaxC, "wce_bwd: bad shape");
   TMGCN_REQUIRE(logits && target && weight && stats && grad_loss && dlogits, "wce_bwd: null pointer");
   hipLaunchKernelGGL(wce_bwd_kernel, dim3(loss_blocks(E) * 2), dim3(256), 0, (hipStream_t)stream, logits, target,
-                     weight, stats, grad_loss, E, C, dlogits);
+                     weight, stats, grad_loss, E, C, ignore_index, dlogits);
   return check_launch("wce_bwd");
 }

@@ -13,10 +13,6 @@ constexpr int kCounterPool = 4096;  // 64 groups of 64: launches in flight on di
 constexpr int kMaxDevices = 16;
 __device__ unsigned int g_tile_counters[kCounterPool];
 
-static std::atomic<int> g_grid_reserve{0};
-int persistent_grid_reserve() { return g_grid_reserve.load(); }
-static std::atomic<int> g_dw_bf16x3{1};
-bool dw_bf16x3_enabled() { return g_dw_bf16x3.load() != 0; }
 
 unsigned int* acquire_tile_counters(hipStream_t stream, int n) {
   if (n < 1 || n > 64) return nullptr;
@@ -98,22 +94,8 @@ static unsigned stream_grid(int64_t n) {
 
 using namespace tmgcn;
 
-extern "C" int tmgcn_abi_version(void) { return 1; }
+extern "C" int tmgcn_abi_version(void) { return 2; }
 
-extern "C" int tmgcn_config_set(const char* key, int64_t value) {
-  TMGCN_REQUIRE(key, "config_set: null key");
-  if (strcmp(key, "persistent_grid_reserve") == 0) {
-    TMGCN_REQUIRE(value >= 0 && value <= 4096, "config_set: persistent_grid_reserve out of range");
-    g_grid_reserve.store((int)value);
-    return TMGCN_OK;
-  }
-  if (strcmp(key, "dw_bf16x3") == 0) {
-    g_dw_bf16x3.store(value != 0);
-    return TMGCN_OK;
-  }
-  set_error("config_set: unknown key '%s'", key);
-  return TMGCN_ERR_INVALID;
-}
 extern "C" const char* tmgcn_last_error(void) { return g_err; }
 
 extern "C" int tmgcn_act_fwd_f32(const float* x, float* y, int64_t n, int32_t act, void* stream) {

@@ -244,7 +244,9 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
                                     const float* X, int64_t n_rows, int32_t N, int32_t K,
                                     const float* W, int32_t Nf, int32_t trans_w,
                                     int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
-                                    float* Y, float* AX, float* pre_act, void* stream) {
+                                    float* Y, float* AX, float* pre_act, int32_t grid_reserve,
+                                    void* stream) {
+  TMGCN_REQUIRE(grid_reserve >= 0 && grid_reserve <= 4096, "spmm_gemm: grid_reserve %d out of range [0, 4096]", grid_reserve);
   TMGCN_REQUIRE(n_rows >= 0 && N > 0, "spmm_gemm: bad shape n_rows=%lld N=%d", (long long)n_rows, N);
   TMGCN_REQUIRE(tmgcn_spmm_gemm_supported(K, Nf),
                 "spmm_gemm: unsupported widths K=%d Nf=%d (need K a multiple of 8 in [16,128] with Nf <= 128, or K in {1,2,3,4,6,8} with Nf <= 16); "
@@ -286,7 +288,7 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
   hipStream_t st = (hipStream_t)stream;
 #define TMGCN_FUSED_CASE(KK, L, UU)                                                              \
   case KK: {                                                                                     \
-    int64_t gx = persistent_grid_reserved(spmm_gemm_kernel<L, UU, KK / 8>, 256);                 \
+    int64_t gx = persistent_grid_reserved(spmm_gemm_kernel<L, UU, KK / 8>, 256, grid_reserve);                 \
     if (gx > a.n_tiles) gx = a.n_tiles;                                                          \
     hipLaunchKernelGGL((spmm_gemm_kernel<L, UU, KK / 8>), dim3((unsigned)gx), dim3(256), 0, st, a); \
     break;                                                                                       \

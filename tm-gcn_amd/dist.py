@@ -169,7 +169,8 @@ class _PipelinedCore(torch.autograd.Function):
                 dist.all_to_all_single(Xt[kk].view(G, Nl, F), send[kk], group=layer.group)
             Wk = W[kk:kk + 1] if per_slice_w else W
             K.spmm_gemm(layer.A_views[kk], Xt[kk:kk + 1], Wk, act=act, want_ax=need_w, want_pre=act_on,
-                        out=(Y[kk:kk + 1], AX[kk:kk + 1] if need_w else None, pre[kk:kk + 1] if act_on else None))
+                        out=(Y[kk:kk + 1], AX[kk:kk + 1] if need_w else None, pre[kk:kk + 1] if act_on else None),
+                        grid_reserve=layer.grid_reserve)
         ctx.layer, ctx.act, ctx.shape = layer, (act if act_on else None), (Tl, G, Nl, F)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(W, AX if need_w else empty, pre if act_on else empty)
@@ -198,7 +199,7 @@ class _PipelinedCore(torch.autograd.Function):
             for kk in range(Tl):
                 Wk = W[kk:kk + 1] if per_slice_w else W
                 K.spmm_gemm(layer.At_views[kk], dY[kk:kk + 1], Wk, trans_w=True, tag="spmm_gemm_T",
-                            out=(dXt[kk:kk + 1], None, None))
+                            out=(dXt[kk:kk + 1], None, None), grid_reserve=layer.grid_reserve)
                 if use_streams:
                     ev = torch.cuda.Event()
                     ev.record(main)
@@ -244,10 +245,7 @@ class ShardedTMGCNLayer:
         # world size 1) is left free whenever a real exchange runs beside it.
         if grid_reserve is None:
             grid_reserve = 256 if (self.G > 1 and pipeline and exchange == "a2a") else 0
-        self.grid_reserve = grid_reserve
-        if grid_reserve and A_local.device.type == "cuda":
-            from . import _lib
-            _lib.check(_lib.load().tmgcn_config_set(b"persistent_grid_reserve", int(grid_reserve)), "tmgcn_config_set")
+        self.grid_reserve = int(grid_reserve)   # passed with every fused launch of THIS layer; nothing process-wide
         self._comm_stream = None
         self._views = None
         self.group = group

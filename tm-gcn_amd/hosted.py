@@ -83,5 +83,7 @@ def _fused_cross_entropy(input, target, weight=None, size_average=None, ignore_i
     elif weight.dtype != torch.float32 or weight.numel() != input.shape[1]:
         return None
     plain = lambda x: x.as_subclass(torch.Tensor) if isinstance(x, DeviceResult) else x
-    out = _WCE.apply(plain(input).contiguous(), plain(target).contiguous(), plain(weight).contiguous())
+    # labels outside [0, C) other than ignore_index come back as a NaN loss / NaN gradients (loss.hip),
+    # where torch would device-assert: corrupt targets are loud either way
+    out = _WCE.apply(plain(input).contiguous(), plain(target).contiguous(), plain(weight).contiguous(), ignore_index)
     return out.as_subclass(DeviceResult)

@@ -121,7 +121,7 @@ class EmbeddingGCN(_Deliver, nn.Module):
         self.W = _param(torch.randn(*w_shape), dev, param_dtype)                      # ehf:189/191
         self.U = _param(torch.randn(2 * self.F[1], self.F[2]), dev, param_dtype)     # ehf:192
         self.AtXt = self.compute_AtXt(_adj(At, self.N, dev), _feat(X, dev))   # ehf:195
-        self._edges = _EdgeIndex(edges, self.N, dev)
+        self._edges = _EdgeIndex(edges, self.N, dev, T=self.T)
         self.dev = dev
 
     def compute_AtXt(self, At: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
@@ -131,7 +131,7 @@ class EmbeddingGCN(_Deliver, nn.Module):
     def forward(self, At=None, X=None, edges=None):
         if _is_recompute_call(At, X, edges):
             AtXt = self.compute_AtXt(_adj(At, self.N, self.dev), _feat(X, self.dev))
-            eidx = _EdgeIndex(edges, self.N, self.dev)
+            eidx = _EdgeIndex(edges, self.N, self.dev, T=self.T)
         else:
             AtXt, eidx = self.AtXt, self._edges
         Y = ops.feature_gemm(AtXt, _w(self.W))                               # ehf:222
@@ -197,7 +197,7 @@ class EmbeddingGCN2(_Deliver, nn.Module):
         self.U = _param(torch.randn(self.F[2] * 2, self.F[3]), dev, param_dtype)      # ehf:283
         self.At = _adj(At, self.N, dev)                                            # ehf:267
         self.AtXt = self.compute_AtXt(self.At, _feat(X, dev))                      # ehf:293
-        self._edges = _EdgeIndex(edges, self.N, dev)
+        self._edges = _EdgeIndex(edges, self.N, dev, T=self.T)
         self.dev = dev
 
     def compute_AX(self, A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
@@ -211,7 +211,7 @@ class EmbeddingGCN2(_Deliver, nn.Module):
     def forward(self, At=None, X=None, edges=None):
         if _is_recompute_call(At, X, edges):
             AtXt = self.compute_AtXt(_adj(At, self.N, self.dev), _feat(X, self.dev))
-            eidx = _EdgeIndex(edges, self.N, self.dev)
+            eidx = _EdgeIndex(edges, self.N, self.dev, T=self.T)
         else:
             AtXt, eidx = self.AtXt, self._edges
         W1, W2, U = _w(self.W1), _w(self.W2), _w(self.U)
@@ -252,18 +252,27 @@ class EmbeddingKWGCN(_Deliver, nn.Module):
         self.A = _adj(A, self.N, dev)
         if self.A.T != self.T:
             raise RuntimeError(f"adjacency has {self.A.T} slices but X has T={self.T}")
-        self._edges = _EdgeIndex(edges, self.N, dev)
+        self._edges = _EdgeIndex(edges, self.N, dev, T=self.T)
         self.AX = self.compute_AX(self.A, _feat(X, dev))                           # ehf:464
         self.dev = dev
 
     def compute_AX(self, A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
-        """ehf:469-473."""
-        return ops.spmm(A, X)
+        """ehf:469-473 — a [self.T, N, F] buffer whose first len(A) slices are Â_k·X_k and whose
+        remaining slices stay zero: the baseline scripts validate on fewer slices than they train
+        on (25 vs 150), and layer 2 then runs over all T slices of the training adjacency."""
+        if A.T > self.T:
+            raise RuntimeError(f"adjacency has {A.T} slices but the model was built for T={self.T} (ehf:470-472)")
+        if X.shape[0] < A.T:
+            raise RuntimeError(f"X has {X.shape[0]} slices but the adjacency has {A.T}")
+        AX = ops.spmm(A, X if X.shape[0] == A.T else X[:A.T].contiguous())
+        if A.T < self.T:
+            AX = torch.cat((AX, AX.new_zeros(self.T - A.T, self.N, AX.shape[-1])), dim=0)
+        return AX
 
     def forward(self, A=None, X=None, edges=None):
         if _is_recompute_call(A, X, edges):
             AX = self.compute_AX(_adj(A, self.N, self.dev), _feat(X, self.dev))
-            eidx = _EdgeIndex(edges, self.N, self.dev)
+            eidx = _EdgeIndex(edges, self.N, self.dev, T=self.T)
         else:
             AX, eidx = self.AX, self._edges
         if self.no_layers == 2:

@@ -43,15 +43,36 @@ def _want(t: torch.Tensor, name: str, dtype=torch.float32):
     return t
 
 
+class EdgeIndexError(IndexError, RuntimeError):
+    """An edge (slice, src, dst) outside the embedding tensor.  The reference's
+    ``Y.reshape(-1,F)[idx]`` raises IndexError there; the kernels gather unchecked, so the
+    check is made once per edge set, before anything is launched."""
+
+
 class EdgeIndex:
     """Flat row indices t*N+node of every labelled edge (ehf:196-198), plus — built lazily, once
-    per edge set — the inverted index the atomic-free head backward walks."""
+    per edge set — the inverted index the atomic-free head backward walks.  With T given, every
+    edge is checked against 0 <= slice < T and 0 <= node < N at construction (one pass where the
+    edges live, one host sync per edge set): the forward kernel has no row count to check against."""
 
-    def __init__(self, edges: torch.Tensor, N: int, device):
-        e = edges.detach().to(device=device, dtype=torch.int64)
+    def __init__(self, edges: torch.Tensor, N: int, device, T: Optional[int] = None):
+        e = edges.detach()
+        if e.dim() != 2 or e.shape[0] != 3:
+            raise RuntimeError(f"edges must be [3, E] (slice, src, dst), got {tuple(e.shape)}")
+        if e.numel():
+            bad = (e[1:] < 0) | (e[1:] >= N)
+            bad = bad[0] | bad[1] | (e[0] < 0)
+            if T is not None:
+                bad = bad | (e[0] >= T)
+            if bool(bad.any()):
+                j = int(torch.nonzero(bad)[0])
+                raise EdgeIndexError(f"edge {j} = (slice {int(e[0, j])}, src {int(e[1, j])}, dst {int(e[2, j])}) is outside "
+                                     f"the embedding tensor (T={T}, N={N})")
+        e = e.to(device=device, dtype=torch.int64)
         self.src = (e[0] * N + e[1]).contiguous()
         self.dst = (e[0] * N + e[2]).contiguous()
         self.E = int(self.src.numel())
+        self.T = T
         self._inv = None
 
     def inverted(self, R: int):
@@ -59,7 +80,7 @@ class EdgeIndex:
         if self._inv is None or self._inv[0] != R:
             if self.E and (int(self.src.max()) >= R or int(self.dst.max()) >= R or
                            int(self.src.min()) < 0 or int(self.dst.min()) < 0):
-                raise RuntimeError("edge index out of range for the embedding matrix")
+                raise EdgeIndexError("edge index out of range for the embedding matrix")
             ids = torch.arange(self.E, device=self.src.device, dtype=torch.int64) * 2
             rows = torch.cat((self.src, self.dst))
             ent = torch.cat((ids, ids + 1))
@@ -177,9 +198,11 @@ class HipKernels:
         return bool(_lib.load().tmgcn_spmm_gemm_supported(K, Nf))
 
     def spmm_gemm(self, A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, trans_w=False, act=None,
-                  want_ax=False, want_pre=False, tag="spmm_gemm", out=None):
+                  want_ax=False, want_pre=False, tag="spmm_gemm", out=None, grid_reserve=0):
         """act((Â ⋆ X) · Wop) in one launch.  Returns (Y, AX or None, pre or None).
-        out = (Y, AX, pre) writes into caller-provided (views of) tensors instead of allocating."""
+        out = (Y, AX, pre) writes into caller-provided (views of) tensors instead of allocating.
+        grid_reserve: block slots this launch leaves free (the pipelined sharded layer's RCCL
+        kernels need them); a per-call argument, nothing process-wide."""
         lib = _lib.load()
         _want(X, "spmm_gemm X")
         _want(W, "spmm_gemm W")
@@ -203,7 +226,7 @@ class HipKernels:
         rc = self._run(tag, X.device, lambda: lib.tmgcn_spmm_gemm_f32(
             _ptr(A.rowptr), _ptr(A.col), _ptr(A.val), _ptr(X), A.n_rows, A.N, K, _ptr(W), wn,
             int(bool(trans_w)), N if per_slice else 0, W.shape[-1] * W.shape[-2] if per_slice else 0, act_id,
-            _ptr(Y), _ptr(AX), _ptr(pre), _stream(X)))
+            _ptr(Y), _ptr(AX), _ptr(pre), int(grid_reserve), _stream(X)))
         _lib.check(rc, "tmgcn_spmm_gemm_f32")
         return Y, AX, pre
 
@@ -227,7 +250,9 @@ class HipKernels:
         _lib.check(rc, "tmgcn_gemm_f32")
         return (Y, pre) if want_pre else Y
 
-    def gemm_dw(self, A: torch.Tensor, dY: torch.Tensor, per_slice: bool) -> torch.Tensor:
+    def gemm_dw(self, A: torch.Tensor, dY: torch.Tensor, per_slice: bool, algo=None) -> torch.Tensor:
+        """dW = Σ_r A[r]ᵀ dY[r].  algo: None / "auto" (bf16x3 split on the bf16 matrix cores where the
+        shapes allow) or "f32mfma" (exact-f32 MFMA kernel) — per call."""
         lib = _lib.load()
         _want(A, "gemm_dw A")
         _want(dY, "gemm_dw dY")
@@ -243,7 +268,7 @@ class HipKernels:
             self._dw_ws[key] = ws
         dW = torch.empty((T, K, Nf) if per_slice else (K, Nf), dtype=torch.float32, device=A.device)
         rc = self._run("gemm_dW", A.device, lambda: lib.tmgcn_gemm_dw_f32(
-            _ptr(A), _ptr(dY), _ptr(dW), R, K, Nf, rpb, _ptr(ws), ws.numel(), _stream(A)))
+            _ptr(A), _ptr(dY), _ptr(dW), R, K, Nf, rpb, _lib.DW_ALGOS[algo], _ptr(ws), ws.numel(), _stream(A)))
         _lib.check(rc, "tmgcn_gemm_dw_f32")
         return dW
 

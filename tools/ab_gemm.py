@@ -16,7 +16,7 @@ p, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
 def load(path):
     lib = C.CDLL(path)
     lib.tmgcn_gemm_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i64, i64, i32, p]
-    lib.tmgcn_gemm_dw_f32.argtypes = [p, p, p, i64, i32, i32, i64, p, i64, p]
+    lib.tmgcn_gemm_dw_f32.argtypes = [p, p, p, i64, i32, i32, i64, i32, p, i64, p]
     lib.tmgcn_gemm_dw_workspace_bytes.restype = i64
     lib.tmgcn_gemm_dw_workspace_bytes.argtypes = [i64, i32, i32, i64]
     return lib
@@ -42,7 +42,7 @@ def run(lib, which):
         return lib.tmgcn_gemm_f32(ptr(A), ptr(W), ptr(Y), None, R, K, Nf, 0, 0, 0, 0, st)
     if which == "gemm_dA":
         return lib.tmgcn_gemm_f32(ptr(dY), ptr(W), ptr(Y), None, R, Nf, K, 1, 0, 0, 0, st)
-    return lib.tmgcn_gemm_dw_f32(ptr(A), ptr(dY), ptr(dW), R, K, Nf, 0, ptr(ws), ws.numel(), st)
+    return lib.tmgcn_gemm_dw_f32(ptr(A), ptr(dY), ptr(dW), R, K, Nf, 0, 0, ptr(ws), ws.numel(), st)
 
 
 res = {}
