@@ -297,7 +297,7 @@ def cpu_epochs(g, spec, epochs, threads):
         loss = crit(out, labels)
         loss.backward()
         opt.step()
-        return float(loss)
+        return float(loss.detach())
 
     first = epoch()
     times = []

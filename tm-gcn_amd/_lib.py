@@ -86,6 +86,33 @@ def load():
     return lib
 
 
+TORCH_LIB_PATH = os.path.join(_HERE, "libtmgcn_torch.so")
+_torch_ops = None
+
+
+def load_torch_ops():
+    """Load the TORCH_LIBRARY layer (libtmgcn_torch.so, built from csrc/torch_ops.cpp) once and
+    return ``torch.ops.tmgcn``.  No fallback: a missing library raises."""
+    global _torch_ops
+    if _torch_ops is not None:
+        return _torch_ops
+    load()                                            # the C-ABI library it links against
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise TmgcnLibraryError(
+            f"{TORCH_LIB_PATH} not found: build the torch extension layer first "
+            "(make -C tm-gcn_amd/csrc torch, or __graft_entry__.build()).")
+    import torch
+    try:
+        torch.ops.load_library(TORCH_LIB_PATH)
+    except OSError as e:
+        raise TmgcnLibraryError(f"cannot load {TORCH_LIB_PATH}: {e}") from e
+    ops = torch.ops.tmgcn
+    if int(ops.abi_version()) != ABI_VERSION:
+        raise TmgcnLibraryError(f"{TORCH_LIB_PATH} was built against ABI {int(ops.abi_version())}, expected {ABI_VERSION}")
+    _torch_ops = ops
+    return ops
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().tmgcn_last_error().decode("utf-8", "replace")

@@ -1,0 +1,582 @@
+// torch_ops.cpp — the PyTorch-ROCm extension layer over the C-ABI (include/tmgcn.h):
+// TORCH_LIBRARY(tmgcn) operators with registered autograd, so that the Python host
+// (tm-gcn_amd/ops.py) reaches the gfx950 kernels through torch.ops.tmgcn.* — one dispatcher
+// call per operator instead of a ctypes argument list per launch, and the backward formulas of
+// the reference's autograd as C++ autograd functions.
+//
+//   kernel-level ops (one C-ABI launch each, no autograd)
+//     tmgcn::mtransform          tmgcn_mtransform_f32              ehf:204, 308, 346, 404; Minv ehf:224
+//     tmgcn::spmm_csr_batched    tmgcn_spmm_csr_batched_f32_hint   ehf:206-207, 303-304, 310-311, 471-472
+//     tmgcn::spmm_gemm(_out)     tmgcn_spmm_gemm_f32               the two statements above + ehf:222 in one launch
+//     tmgcn::bgemm               tmgcn_gemm_f32                    ehf:222, 330, 344, 349, 486-489
+//     tmgcn::bgemm_dW            tmgcn_gemm_dw_f32                 autograd of ehf:222
+//     tmgcn::edge_head_fwd/bwd   tmgcn_edge_head_*_f32             ehf:228-232, 351-355, 491-495
+//     tmgcn::act_fwd/bwd         tmgcn_act_*_f32                   ehf:284-289
+//     tmgcn::wce_fwd/bwd         tmgcn_wce_*_f32                   experiment_reddit_our_link_prediction.py:69, 79
+//   differentiable ops (registered under the Autograd key)
+//     tmgcn::m_transform, tmgcn::spmm, tmgcn::feature_gemm, tmgcn::spmm_feature_gemm,
+//     tmgcn::edge_head, tmgcn::activation, tmgcn::weighted_ce
+//
+// No kernels live here: every launch goes through the C-ABI shared library (libtmgcn_hip.so),
+// on torch's current HIP stream.  Errors surface as RuntimeError (TORCH_CHECK), the reference's
+// convention.  Built by `make -C tm-gcn_amd/csrc torch` (g++; __graft_entry__.build()).
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <torch/library.h>
+
+#include <tuple>
+#include <vector>
+
+#include "tmgcn.h"
+
+namespace {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+using OptTensor = c10::optional<Tensor>;
+
+inline void* ptr(const Tensor& t) {
+  return (t.defined() && t.numel()) ? const_cast<void*>(t.const_data_ptr()) : nullptr;
+}
+inline void* stream_of(const Tensor& t) {
+  return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream();
+}
+inline void want(const Tensor& t, const char* name, at::ScalarType dt = at::kFloat) {
+  TORCH_CHECK(t.defined(), name, ": undefined tensor");
+  TORCH_CHECK(t.is_cuda(), name, ": expected a ROCm (cuda) tensor, got device ", t.device(),
+              "; the TM-GCN layer has no CPU path");
+  TORCH_CHECK(t.scalar_type() == dt, name, ": expected dtype ", dt, ", got ", t.scalar_type());
+  TORCH_CHECK(t.is_contiguous(), name, ": expected a contiguous tensor");
+}
+inline void ok(int rc, const char* what) {
+  TORCH_CHECK(rc == 0, what, " failed (status ", rc, "): ", tmgcn_last_error());
+}
+inline Tensor none_like(const Tensor& t) { return at::empty({0}, t.options()); }
+inline bool has(const Tensor& t) { return t.defined() && t.numel() > 0; }
+
+// ---------------------------------------------------------------------------------------
+// kernel-level operators
+// ---------------------------------------------------------------------------------------
+Tensor mtransform(const Tensor& M, const Tensor& X, bool transpose, int64_t row_off, int64_t col_off,
+                  int64_t T_out, int64_t band_lo, int64_t band_hi, int64_t x_group_rows,
+                  int64_t y_group_rows) {
+  want(M, "mtransform M");
+  want(X, "mtransform X");
+  TORCH_CHECK(M.dim() == 2 && M.size(0) == M.size(1), "mtransform: M must be square");
+  TORCH_CHECK(X.dim() >= 1, "mtransform: X needs a leading time mode");
+  c10::DeviceGuard g(X.device());
+  const int64_t T_in = X.size(0);
+  if (T_out < 0) T_out = T_in;
+  const int64_t C = T_in ? X.numel() / T_in : 0;
+  auto sizes = X.sizes().vec();
+  sizes[0] = T_out;
+  Tensor Y = at::empty(sizes, X.options());
+  ok(tmgcn_mtransform_f32((const float*)ptr(M), (int32_t)M.size(0), (int32_t)M.size(0), transpose ? 1 : 0,
+                          (int32_t)row_off, (int32_t)col_off, (int32_t)T_out, (int32_t)T_in,
+                          (int32_t)band_lo, (int32_t)band_hi, (const float*)ptr(X), (float*)ptr(Y), C,
+                          (int32_t)x_group_rows, (int32_t)y_group_rows, stream_of(X)),
+     "tmgcn_mtransform_f32");
+  return Y;
+}
+
+void check_csr(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& X, int64_t N,
+               const char* who) {
+  want(rowptr, "rowptr", at::kLong);
+  want(col, "col", at::kInt);
+  want(val, "val");
+  TORCH_CHECK(X.dim() == 3 && X.size(1) == N && (X.size(0) * N + 1) == rowptr.numel(), who, ": X ",
+              X.sizes(), " does not match adjacency T=", N ? (rowptr.numel() - 1) / N : 0, " N=", N);
+  TORCH_CHECK(val.device() == X.device(), who, ": adjacency and X live on different devices");
+}
+
+Tensor spmm_csr_batched(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& X,
+                        int64_t N, double avg_nnz_per_row) {
+  want(X, "spmm X");
+  check_csr(rowptr, col, val, X, N, "spmm");
+  c10::DeviceGuard g(X.device());
+  Tensor Y = at::empty_like(X);
+  ok(tmgcn_spmm_csr_batched_f32_hint((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col),
+                                     (const float*)ptr(val), (const float*)ptr(X), (float*)ptr(Y),
+                                     X.size(0) * N, (int32_t)N, (int32_t)X.size(2), (float)avg_nnz_per_row,
+                                     stream_of(X)),
+     "tmgcn_spmm_csr_batched_f32");
+  return Y;
+}
+
+struct WShape {
+  bool per_slice;
+  int64_t wk, wn, stride;
+};
+WShape w_shape(const Tensor& W, bool trans_w, int64_t T, int64_t K, const char* who) {
+  TORCH_CHECK(W.dim() == 2 || W.dim() == 3, who, ": W must be [K,Nf] or [T,K,Nf]");
+  WShape s;
+  s.per_slice = W.dim() == 3;
+  const int64_t a = W.size(-2), b = W.size(-1);
+  s.wk = trans_w ? b : a;
+  s.wn = trans_w ? a : b;
+  s.stride = s.per_slice ? a * b : 0;
+  TORCH_CHECK(s.wk == K && (!s.per_slice || W.size(0) == T), who, ": size mismatch, operand [", T, ",*,", K,
+              "] W ", W.sizes(), " trans_w=", trans_w);
+  return s;
+}
+
+void spmm_gemm_launch(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& X, int64_t N,
+                      const Tensor& W, bool trans_w, int64_t act, const Tensor& Y, const Tensor& AX,
+                      const Tensor& pre, int64_t grid_reserve) {
+  const WShape s = w_shape(W, trans_w, X.size(0), X.size(2), "spmm_gemm");
+  ok(tmgcn_spmm_gemm_f32((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val),
+                         (const float*)ptr(X), X.size(0) * N, (int32_t)N, (int32_t)X.size(2),
+                         (const float*)ptr(W), (int32_t)s.wn, trans_w ? 1 : 0, s.per_slice ? N : 0, s.stride,
+                         (int32_t)act, (float*)ptr(Y), (float*)ptr(AX), (float*)ptr(pre), (int32_t)grid_reserve,
+                         stream_of(X)),
+     "tmgcn_spmm_gemm_f32");
+}
+
+std::tuple<Tensor, Tensor, Tensor> spmm_gemm(const Tensor& rowptr, const Tensor& col, const Tensor& val,
+                                             const Tensor& X, int64_t N, const Tensor& W, bool trans_w,
+                                             int64_t act, bool want_ax, bool want_pre, int64_t grid_reserve) {
+  want(X, "spmm_gemm X");
+  want(W, "spmm_gemm W");
+  check_csr(rowptr, col, val, X, N, "spmm_gemm");
+  c10::DeviceGuard g(X.device());
+  const WShape s = w_shape(W, trans_w, X.size(0), X.size(2), "spmm_gemm");
+  Tensor Y = at::empty({X.size(0), N, s.wn}, X.options());
+  Tensor AX = want_ax ? at::empty_like(X) : Tensor();
+  Tensor pre = (want_pre && act != TMGCN_ACT_NONE) ? at::empty_like(Y) : Tensor();
+  spmm_gemm_launch(rowptr, col, val, X, N, W, trans_w, act, Y, AX, pre, grid_reserve);
+  return {Y, AX.defined() ? AX : none_like(X), pre.defined() ? pre : none_like(X)};
+}
+
+// writes into caller-provided (views of) tensors: the slice-by-slice pipelined multi-GPU path
+void spmm_gemm_out(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& X, int64_t N,
+                   const Tensor& W, bool trans_w, int64_t act, Tensor Y, const OptTensor& AX,
+                   const OptTensor& pre, int64_t grid_reserve) {
+  want(X, "spmm_gemm X");
+  want(W, "spmm_gemm W");
+  want(Y, "spmm_gemm out Y");
+  check_csr(rowptr, col, val, X, N, "spmm_gemm");
+  c10::DeviceGuard g(X.device());
+  const WShape s = w_shape(W, trans_w, X.size(0), X.size(2), "spmm_gemm");
+  TORCH_CHECK(Y.dim() == 3 && Y.size(0) == X.size(0) && Y.size(1) == N && Y.size(2) == s.wn,
+              "spmm_gemm: out Y ", Y.sizes(), " != [", X.size(0), ",", N, ",", s.wn, "]");
+  Tensor ax = AX.has_value() ? *AX : Tensor(), pr = pre.has_value() ? *pre : Tensor();
+  if (ax.defined()) want(ax, "spmm_gemm out AX");
+  if (pr.defined()) want(pr, "spmm_gemm out pre");
+  spmm_gemm_launch(rowptr, col, val, X, N, W, trans_w, act, Y, ax, pr, grid_reserve);
+}
+
+std::tuple<Tensor, Tensor> bgemm(const Tensor& A, const Tensor& W, bool trans_w, int64_t act, bool want_pre) {
+  want(A, "gemm A");
+  want(W, "gemm W");
+  TORCH_CHECK(A.dim() == 3, "gemm: A must be [T,N,K]");
+  c10::DeviceGuard g(A.device());
+  const int64_t T = A.size(0), N = A.size(1), K = A.size(2);
+  const WShape s = w_shape(W, trans_w, T, K, "gemm");
+  Tensor Y = at::empty({T, N, s.wn}, A.options());
+  Tensor pre = (want_pre && act != TMGCN_ACT_NONE) ? at::empty_like(Y) : Tensor();
+  ok(tmgcn_gemm_f32((const float*)ptr(A), (const float*)ptr(W), (float*)ptr(Y), (float*)ptr(pre), T * N,
+                    (int32_t)K, (int32_t)s.wn, trans_w ? 1 : 0, s.per_slice ? N : 0, s.stride, (int32_t)act,
+                    stream_of(A)),
+     "tmgcn_gemm_f32");
+  return {Y, pre.defined() ? pre : none_like(A)};
+}
+
+Tensor bgemm_dW(const Tensor& A, const Tensor& dY, bool per_slice, int64_t algo) {
+  want(A, "gemm_dw A");
+  want(dY, "gemm_dw dY");
+  TORCH_CHECK(A.dim() == 3 && dY.dim() == 3 && A.size(0) == dY.size(0) && A.size(1) == dY.size(1),
+              "gemm_dw: A ", A.sizes(), " and dY ", dY.sizes(), " do not match");
+  c10::DeviceGuard g(A.device());
+  const int64_t T = A.size(0), N = A.size(1), K = A.size(2), Nf = dY.size(2), R = T * N;
+  const int64_t rpb = per_slice ? N : 0;
+  const int64_t need = tmgcn_gemm_dw_workspace_bytes(R, (int32_t)K, (int32_t)Nf, rpb);
+  // scratch from torch's caching allocator: stream-ordered, no synchronisation, graph-capturable
+  Tensor ws = at::empty({need > 0 ? need : 1}, A.options().dtype(at::kByte));
+  Tensor dW = per_slice ? at::empty({T, K, Nf}, A.options()) : at::empty({K, Nf}, A.options());
+  ok(tmgcn_gemm_dw_f32((const float*)ptr(A), (const float*)ptr(dY), (float*)ptr(dW), R, (int32_t)K, (int32_t)Nf,
+                       rpb, (int32_t)algo, ptr(ws), ws.numel(), stream_of(A)),
+     "tmgcn_gemm_dw_f32");
+  return dW;
+}
+
+Tensor edge_head_fwd(const Tensor& Z2, const Tensor& src, const Tensor& dst, const Tensor& U) {
+  want(Z2, "edge_head Z");
+  want(U, "edge_head U");
+  want(src, "edge_head src", at::kLong);
+  want(dst, "edge_head dst", at::kLong);
+  TORCH_CHECK(Z2.dim() == 2 && U.dim() == 2 && U.size(0) == 2 * Z2.size(1), "edge_head: U ", U.sizes(),
+              " does not match F=", Z2.size(1));
+  c10::DeviceGuard g(Z2.device());
+  const int64_t E = src.numel(), F = Z2.size(1), C = U.size(1);
+  Tensor out = at::empty({E, C}, Z2.options());
+  ok(tmgcn_edge_head_fwd_f32((const float*)ptr(Z2), (const int64_t*)ptr(src), (const int64_t*)ptr(dst),
+                             (const float*)ptr(U), (float*)ptr(out), E, (int32_t)F, (int32_t)C, stream_of(Z2)),
+     "tmgcn_edge_head_fwd_f32");
+  return out;
+}
+
+std::tuple<Tensor, Tensor> edge_head_bwd(const Tensor& Z2, const Tensor& src, const Tensor& dst, const Tensor& U,
+                                         const Tensor& dout, const Tensor& eptr, const Tensor& eidx, bool need_dz,
+                                         bool need_du) {
+  want(Z2, "edge_head Z");
+  want(U, "edge_head U");
+  want(dout, "edge_head dout");
+  want(eptr, "edge_head eptr", at::kLong);
+  want(eidx, "edge_head eidx", at::kLong);
+  c10::DeviceGuard g(Z2.device());
+  const int64_t R = Z2.size(0), F = Z2.size(1), C = U.size(1), E = src.numel();
+  TORCH_CHECK(eptr.numel() == R + 1 && eidx.numel() == 2 * E, "edge_head_bwd: inverted index does not match R=", R,
+              " E=", E);
+  Tensor dZ = need_dz ? at::empty_like(Z2) : Tensor();
+  Tensor dU = need_du ? at::empty_like(U) : Tensor();
+  const int64_t need = tmgcn_edge_head_bwd_workspace_bytes(E, (int32_t)F, (int32_t)C);
+  Tensor ws = at::empty({need > 0 ? need : 1}, Z2.options().dtype(at::kByte));
+  ok(tmgcn_edge_head_bwd_f32((const float*)ptr(Z2), (const int64_t*)ptr(src), (const int64_t*)ptr(dst),
+                             (const float*)ptr(U), (const float*)ptr(dout), (const int64_t*)ptr(eptr),
+                             (const int64_t*)ptr(eidx), (float*)ptr(dZ), (float*)ptr(dU), R, E, (int32_t)F,
+                             (int32_t)C, ptr(ws), ws.numel(), stream_of(Z2)),
+     "tmgcn_edge_head_bwd_f32");
+  return {dZ.defined() ? dZ : none_like(Z2), dU.defined() ? dU : none_like(Z2)};
+}
+
+Tensor act_fwd(const Tensor& x, int64_t act) {
+  want(x, "act x");
+  c10::DeviceGuard g(x.device());
+  Tensor y = at::empty_like(x);
+  ok(tmgcn_act_fwd_f32((const float*)ptr(x), (float*)ptr(y), x.numel(), (int32_t)act, stream_of(x)),
+     "tmgcn_act_fwd_f32");
+  return y;
+}
+
+Tensor act_bwd(const Tensor& x, const Tensor& dy, int64_t act) {
+  want(x, "act x");
+  want(dy, "act dy");
+  TORCH_CHECK(x.numel() == dy.numel(), "act_bwd: size mismatch");
+  c10::DeviceGuard g(x.device());
+  Tensor dx = at::empty_like(x);
+  ok(tmgcn_act_bwd_f32((const float*)ptr(x), (const float*)ptr(dy), (float*)ptr(dx), x.numel(), (int32_t)act,
+                       stream_of(x)),
+     "tmgcn_act_bwd_f32");
+  return dx;
+}
+
+std::tuple<Tensor, Tensor> wce_fwd(const Tensor& logits, const Tensor& target, const Tensor& weight,
+                                   int64_t ignore_index) {
+  want(logits, "wce logits");
+  want(weight, "wce weight");
+  want(target, "wce target", at::kLong);
+  TORCH_CHECK(logits.dim() == 2 && weight.numel() == logits.size(1) && target.numel() == logits.size(0),
+              "wce: shapes logits ", logits.sizes(), " target ", target.sizes(), " weight ", weight.sizes());
+  c10::DeviceGuard g(logits.device());
+  const int64_t E = logits.size(0), C = logits.size(1);
+  Tensor loss = at::empty({}, logits.options());
+  Tensor stats = at::empty({2}, logits.options().dtype(at::kDouble));
+  Tensor ws = at::empty({tmgcn_wce_workspace_bytes(E)}, logits.options().dtype(at::kByte));
+  ok(tmgcn_wce_fwd_f32((const float*)ptr(logits), (const int64_t*)ptr(target), (const float*)ptr(weight), E,
+                       (int32_t)C, ignore_index, (float*)loss.data_ptr(), (double*)stats.data_ptr(), ptr(ws),
+                       ws.numel(), stream_of(logits)),
+     "tmgcn_wce_fwd_f32");
+  return {loss, stats};
+}
+
+Tensor wce_bwd(const Tensor& logits, const Tensor& target, const Tensor& weight, const Tensor& stats,
+               const Tensor& g, int64_t ignore_index) {
+  want(logits, "wce logits");
+  want(g, "wce grad");
+  c10::DeviceGuard gd(logits.device());
+  Tensor dz = at::empty_like(logits);
+  ok(tmgcn_wce_bwd_f32((const float*)ptr(logits), (const int64_t*)ptr(target), (const float*)ptr(weight),
+                       (const double*)stats.data_ptr(), (const float*)g.data_ptr(), logits.size(0),
+                       (int32_t)logits.size(1), ignore_index, (float*)ptr(dz), stream_of(logits)),
+     "tmgcn_wce_bwd_f32");
+  return dz;
+}
+
+bool spmm_gemm_supported(int64_t K, int64_t Nf) { return tmgcn_spmm_gemm_supported((int32_t)K, (int32_t)Nf) != 0; }
+bool edge_head_supported(int64_t F, int64_t C) { return tmgcn_edge_head_supported((int32_t)F, (int32_t)C) != 0; }
+int64_t abi_version() { return tmgcn_abi_version(); }
+
+// ---------------------------------------------------------------------------------------
+// differentiable operators (explicit adjoints: what autograd derives for the reference)
+// ---------------------------------------------------------------------------------------
+struct MTransformFn : public torch::autograd::Function<MTransformFn> {
+  // Y[k] = Σ_j M[ro+k][co+j] X[j]   =>   dX[j] = Σ_k Mᵀ[co+j][ro+k] dY[k]
+  static Tensor forward(AutogradContext* ctx, const Tensor& X, const Tensor& M, int64_t band_lo, int64_t band_hi,
+                        int64_t row_off, int64_t col_off, int64_t T_out, int64_t xg, int64_t yg) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->save_for_backward({M});
+    ctx->saved_data["lo"] = band_lo;
+    ctx->saved_data["hi"] = band_hi;
+    ctx->saved_data["ro"] = row_off;
+    ctx->saved_data["co"] = col_off;
+    ctx->saved_data["T_in"] = X.size(0);
+    ctx->saved_data["xg"] = xg;
+    ctx->saved_data["yg"] = yg;
+    return mtransform(M, X, false, row_off, col_off, T_out, band_lo, band_hi, xg, yg);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const Tensor M = ctx->get_saved_variables()[0];
+    auto& d = ctx->saved_data;
+    Tensor dX = mtransform(M, grads[0].contiguous(), true, d["co"].toInt(), d["ro"].toInt(), d["T_in"].toInt(),
+                           d["hi"].toInt(), d["lo"].toInt(), d["yg"].toInt(), d["xg"].toInt());
+    return {dX, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+struct SpmmFn : public torch::autograd::Function<SpmmFn> {
+  // sparse.mm backward: dX_k = Â_kᵀ dY_k (Â is a constant: no gradient, as in the reference)
+  static Tensor forward(AutogradContext* ctx, const Tensor& X, const Tensor& rowptr, const Tensor& col,
+                        const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col, const OptTensor& t_val,
+                        int64_t N, double avg) {
+    const bool need = X.requires_grad() && at::GradMode::is_enabled();
+    at::AutoDispatchBelowADInplaceOrView guard;
+    if (need) {
+      TORCH_CHECK(t_rowptr.has_value() && t_col.has_value() && t_val.has_value(),
+                  "spmm: X requires grad but no transposed adjacency was passed");
+      ctx->save_for_backward({*t_rowptr, *t_col, *t_val});
+    }
+    ctx->saved_data["N"] = N;
+    ctx->saved_data["avg"] = avg;
+    return spmm_csr_batched(rowptr, col, val, X, N, avg);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto sv = ctx->get_saved_variables();
+    Tensor dX = spmm_csr_batched(sv[0], sv[1], sv[2], grads[0].contiguous(), ctx->saved_data["N"].toInt(),
+                                 ctx->saved_data["avg"].toDouble());
+    return {dX, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+struct FeatureGemmFn : public torch::autograd::Function<FeatureGemmFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& A, const Tensor& W, int64_t act) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto [Y, pre] = bgemm(A, W, false, act, act != TMGCN_ACT_NONE);
+    ctx->saved_data["act"] = act;
+    ctx->save_for_backward({A, W, pre});
+    return Y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto sv = ctx->get_saved_variables();
+    const Tensor &A = sv[0], &W = sv[1], &pre = sv[2];
+    const int64_t act = ctx->saved_data["act"].toInt();
+    Tensor dY = grads[0].contiguous();
+    if (act != TMGCN_ACT_NONE) dY = act_bwd(pre, dY, act);
+    Tensor dA, dW;
+    if (ctx->needs_input_grad(0)) dA = std::get<0>(bgemm(dY, W, true, TMGCN_ACT_NONE, false));
+    if (ctx->needs_input_grad(1)) dW = bgemm_dW(A, dY, W.dim() == 3, TMGCN_DW_AUTO);
+    return {dA, dW, Tensor()};
+  }
+};
+
+struct SpmmFeatureGemmFn : public torch::autograd::Function<SpmmFeatureGemmFn> {
+  // Fused P2+P3.  Backward uses Âᵀ(dY·Wᵀ) = (Âᵀ·dY)·Wᵀ: the same fused kernel on dY.
+  static Tensor forward(AutogradContext* ctx, const Tensor& X, const Tensor& W, const Tensor& rowptr,
+                        const Tensor& col, const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col,
+                        const OptTensor& t_val, int64_t N, double avg, int64_t act, int64_t grid_reserve) {
+    const bool grad = at::GradMode::is_enabled();
+    const bool need_x = grad && X.requires_grad(), need_w = grad && W.requires_grad();
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto [Y, AX, pre] = spmm_gemm(rowptr, col, val, X, N, W, false, act, need_w, need_x || need_w, grid_reserve);
+    if (need_x)
+      TORCH_CHECK(t_rowptr.has_value() && t_col.has_value() && t_val.has_value(),
+                  "spmm_feature_gemm: X requires grad but no transposed adjacency was passed");
+    ctx->save_for_backward({W, AX, pre, need_x ? *t_rowptr : Tensor(), need_x ? *t_col : Tensor(),
+                            need_x ? *t_val : Tensor()});
+    ctx->saved_data["N"] = N;
+    ctx->saved_data["avg"] = avg;
+    ctx->saved_data["act"] = act;
+    ctx->saved_data["reserve"] = grid_reserve;
+    return Y;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto sv = ctx->get_saved_variables();
+    const Tensor &W = sv[0], &AX = sv[1], &pre = sv[2];
+    const int64_t N = ctx->saved_data["N"].toInt(), act = ctx->saved_data["act"].toInt();
+    Tensor dY = grads[0].contiguous();
+    if (act != TMGCN_ACT_NONE) dY = act_bwd(pre, dY, act);
+    Tensor dX, dW;
+    if (ctx->needs_input_grad(0)) {
+      if (spmm_gemm_supported(dY.size(-1), W.size(-2)))
+        dX = std::get<0>(spmm_gemm(sv[3], sv[4], sv[5], dY, N, W, true, TMGCN_ACT_NONE, false, false,
+                                   ctx->saved_data["reserve"].toInt()));
+      else  // the transposed widths have no fused kernel: dA = dY·Wᵀ, then Âᵀ·dA
+        dX = spmm_csr_batched(sv[3], sv[4], sv[5], std::get<0>(bgemm(dY, W, true, TMGCN_ACT_NONE, false)), N,
+                              ctx->saved_data["avg"].toDouble());
+    }
+    if (ctx->needs_input_grad(1)) dW = bgemm_dW(AX, dY, W.dim() == 3, TMGCN_DW_AUTO);
+    return {dX, dW, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+struct EdgeHeadFn : public torch::autograd::Function<EdgeHeadFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& Z, const Tensor& U, const Tensor& src, const Tensor& dst,
+                        const OptTensor& eptr, const OptTensor& eidx) {
+    const bool need = at::GradMode::is_enabled() && (Z.requires_grad() || U.requires_grad());
+    at::AutoDispatchBelowADInplaceOrView guard;
+    Tensor Z2 = Z.contiguous().reshape({-1, Z.size(-1)});
+    if (need) {
+      TORCH_CHECK(eptr.has_value() && eidx.has_value(), "edge_head: gradients needed but no inverted edge index passed");
+      ctx->save_for_backward({Z2, U, src, dst, *eptr, *eidx});
+    }
+    ctx->saved_data["zshape"] = Z.sizes().vec();
+    return edge_head_fwd(Z2, src, dst, U);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto sv = ctx->get_saved_variables();
+    const bool nz = ctx->needs_input_grad(0), nu = ctx->needs_input_grad(1);
+    auto [dZ, dU] = edge_head_bwd(sv[0], sv[2], sv[3], sv[1], grads[0].contiguous(), sv[4], sv[5], nz, nu);
+    Tensor gz = nz ? dZ.reshape(ctx->saved_data["zshape"].toIntVector()) : Tensor();
+    return {gz, nu ? dU : Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+struct ActivationFn : public torch::autograd::Function<ActivationFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& x, int64_t act) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    ctx->save_for_backward({x});
+    ctx->saved_data["act"] = act;
+    return act_fwd(x, act);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    return {act_bwd(ctx->get_saved_variables()[0], grads[0].contiguous(), ctx->saved_data["act"].toInt()), Tensor()};
+  }
+};
+
+struct WeightedCeFn : public torch::autograd::Function<WeightedCeFn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& logits, const Tensor& target, const Tensor& weight,
+                        int64_t ignore_index) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto [loss, stats] = wce_fwd(logits, target, weight, ignore_index);
+    ctx->save_for_backward({logits, target, weight, stats});
+    ctx->saved_data["ign"] = ignore_index;
+    return loss;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto sv = ctx->get_saved_variables();
+    Tensor g = grads[0].contiguous().to(at::kFloat);
+    return {wce_bwd(sv[0], sv[1], sv[2], sv[3], g, ctx->saved_data["ign"].toInt()), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+Tensor m_transform_ad(const Tensor& X, const Tensor& M, int64_t band_lo, int64_t band_hi, int64_t row_off,
+                      int64_t col_off, int64_t T_out, int64_t xg, int64_t yg) {
+  return MTransformFn::apply(X, M, band_lo, band_hi, row_off, col_off, T_out, xg, yg);
+}
+Tensor spmm_ad(const Tensor& X, const Tensor& rowptr, const Tensor& col, const Tensor& val, const OptTensor& t_rowptr,
+               const OptTensor& t_col, const OptTensor& t_val, int64_t N, double avg) {
+  return SpmmFn::apply(X, rowptr, col, val, t_rowptr, t_col, t_val, N, avg);
+}
+Tensor feature_gemm_ad(const Tensor& A, const Tensor& W, int64_t act) { return FeatureGemmFn::apply(A, W, act); }
+Tensor spmm_feature_gemm_ad(const Tensor& X, const Tensor& W, const Tensor& rowptr, const Tensor& col,
+                            const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col,
+                            const OptTensor& t_val, int64_t N, double avg, int64_t act, int64_t grid_reserve) {
+  return SpmmFeatureGemmFn::apply(X, W, rowptr, col, val, t_rowptr, t_col, t_val, N, avg, act, grid_reserve);
+}
+Tensor edge_head_ad(const Tensor& Z, const Tensor& U, const Tensor& src, const Tensor& dst, const OptTensor& eptr,
+                    const OptTensor& eidx) {
+  return EdgeHeadFn::apply(Z, U, src, dst, eptr, eidx);
+}
+Tensor activation_ad(const Tensor& x, int64_t act) { return ActivationFn::apply(x, act); }
+Tensor weighted_ce_ad(const Tensor& logits, const Tensor& target, const Tensor& weight, int64_t ignore_index) {
+  return WeightedCeFn::apply(logits, target, weight, ignore_index);
+}
+
+}  // namespace
+
+TORCH_LIBRARY(tmgcn, m) {
+  // kernel-level
+  m.def("mtransform(Tensor M, Tensor X, bool transpose, int row_off, int col_off, int T_out, int band_lo, int band_hi, "
+        "int x_group_rows, int y_group_rows) -> Tensor");
+  m.def("spmm_csr_batched(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, float avg_nnz_per_row) -> Tensor");
+  m.def("spmm_gemm(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, Tensor W, bool trans_w, int act, "
+        "bool want_ax, bool want_pre, int grid_reserve) -> (Tensor, Tensor, Tensor)");
+  m.def("spmm_gemm_out(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, Tensor W, bool trans_w, int act, "
+        "Tensor(a!) Y, Tensor(b!)? AX, Tensor(c!)? pre, int grid_reserve) -> ()");
+  m.def("bgemm(Tensor A, Tensor W, bool trans_w, int act, bool want_pre) -> (Tensor, Tensor)");
+  m.def("bgemm_dW(Tensor A, Tensor dY, bool per_slice, int algo) -> Tensor");
+  m.def("edge_head_fwd(Tensor Z2, Tensor src, Tensor dst, Tensor U) -> Tensor");
+  m.def("edge_head_bwd(Tensor Z2, Tensor src, Tensor dst, Tensor U, Tensor dout, Tensor eptr, Tensor eidx, "
+        "bool need_dz, bool need_du) -> (Tensor, Tensor)");
+  m.def("act_fwd(Tensor x, int act) -> Tensor");
+  m.def("act_bwd(Tensor x, Tensor dy, int act) -> Tensor");
+  m.def("wce_fwd(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> (Tensor, Tensor)");
+  m.def("wce_bwd(Tensor logits, Tensor target, Tensor weight, Tensor stats, Tensor g, int ignore_index) -> Tensor");
+  m.def("spmm_gemm_supported(int K, int Nf) -> bool", &spmm_gemm_supported);
+  m.def("edge_head_supported(int F, int C) -> bool", &edge_head_supported);
+  m.def("abi_version() -> int", &abi_version);
+  // differentiable
+  m.def("m_transform(Tensor X, Tensor M, int band_lo, int band_hi, int row_off, int col_off, int T_out, "
+        "int x_group_rows, int y_group_rows) -> Tensor");
+  m.def("spmm(Tensor X, Tensor rowptr, Tensor col, Tensor val, Tensor? t_rowptr, Tensor? t_col, Tensor? t_val, "
+        "int N, float avg_nnz_per_row) -> Tensor");
+  m.def("feature_gemm(Tensor A, Tensor W, int act) -> Tensor");
+  m.def("spmm_feature_gemm(Tensor X, Tensor W, Tensor rowptr, Tensor col, Tensor val, Tensor? t_rowptr, "
+        "Tensor? t_col, Tensor? t_val, int N, float avg_nnz_per_row, int act, int grid_reserve) -> Tensor");
+  m.def("edge_head(Tensor Z, Tensor U, Tensor src, Tensor dst, Tensor? eptr, Tensor? eidx) -> Tensor");
+  m.def("activation(Tensor x, int act) -> Tensor");
+  m.def("weighted_ce(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> Tensor");
+}
+
+// ROCm tensors carry the CUDA dispatch key in PyTorch-ROCm
+TORCH_LIBRARY_IMPL(tmgcn, CUDA, m) {
+  m.impl("mtransform", &mtransform);
+  m.impl("spmm_csr_batched", &spmm_csr_batched);
+  m.impl("spmm_gemm", &spmm_gemm);
+  m.impl("spmm_gemm_out", &spmm_gemm_out);
+  m.impl("bgemm", &bgemm);
+  m.impl("bgemm_dW", &bgemm_dW);
+  m.impl("edge_head_fwd", &edge_head_fwd);
+  m.impl("edge_head_bwd", &edge_head_bwd);
+  m.impl("act_fwd", &act_fwd);
+  m.impl("act_bwd", &act_bwd);
+  m.impl("wce_fwd", &wce_fwd);
+  m.impl("wce_bwd", &wce_bwd);
+  // below the Autograd key (inference mode, or called from inside another autograd node) the
+  // differentiable operators are their plain forwards
+  m.impl("m_transform", &m_transform_ad);
+  m.impl("spmm", &spmm_ad);
+  m.impl("feature_gemm", &feature_gemm_ad);
+  m.impl("spmm_feature_gemm", &spmm_feature_gemm_ad);
+  m.impl("edge_head", &edge_head_ad);
+  m.impl("activation", &activation_ad);
+  m.impl("weighted_ce", &weighted_ce_ad);
+}
+
+TORCH_LIBRARY_IMPL(tmgcn, Autograd, m) {
+  m.impl("m_transform", &m_transform_ad);
+  m.impl("spmm", &spmm_ad);
+  m.impl("feature_gemm", &feature_gemm_ad);
+  m.impl("spmm_feature_gemm", &spmm_feature_gemm_ad);
+  m.impl("edge_head", &edge_head_ad);
+  m.impl("activation", &activation_ad);
+  m.impl("weighted_ce", &weighted_ce_ad);
+}
+
+// a CPU tensor reaching a kernel-level op gets the reference-style RuntimeError, not "no kernel"
+TORCH_LIBRARY_IMPL(tmgcn, CPU, m) {
+  m.impl("mtransform", &mtransform);
+  m.impl("spmm_csr_batched", &spmm_csr_batched);
+  m.impl("spmm_gemm", &spmm_gemm);
+  m.impl("bgemm", &bgemm);
+  m.impl("bgemm_dW", &bgemm_dW);
+  m.impl("edge_head_fwd", &edge_head_fwd);
+  m.impl("act_fwd", &act_fwd);
+  m.impl("act_bwd", &act_bwd);
+  m.impl("m_transform", &m_transform_ad);
+  m.impl("spmm", &spmm_ad);
+  m.impl("feature_gemm", &feature_gemm_ad);
+  m.impl("spmm_feature_gemm", &spmm_feature_gemm_ad);
+  m.impl("edge_head", &edge_head_ad);
+  m.impl("activation", &activation_ad);
+  m.impl("weighted_ce", &weighted_ce_ad);
+}

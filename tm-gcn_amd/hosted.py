@@ -69,7 +69,7 @@ def _fused_cross_entropy(input, target, weight=None, size_average=None, ignore_i
                          reduction="mean", label_smoothing=0.0):
     """The fused kernel's result for the plain weighted / unweighted mean cross entropy, or None
     when the call uses anything it does not cover (torch's own implementation runs then)."""
-    from .losses import _WCE, MAX_CLASSES
+    from .losses import weighted_ce, MAX_CLASSES
     if (size_average is not None or reduce is not None or reduction != "mean" or label_smoothing != 0.0
             or not isinstance(input, torch.Tensor) or input.dim() != 2 or input.dtype != torch.float32
             or not input.is_cuda or input.shape[0] == 0 or input.shape[1] > MAX_CLASSES
@@ -85,5 +85,5 @@ def _fused_cross_entropy(input, target, weight=None, size_average=None, ignore_i
     plain = lambda x: x.as_subclass(torch.Tensor) if isinstance(x, DeviceResult) else x
     # labels outside [0, C) other than ignore_index come back as a NaN loss / NaN gradients (loss.hip),
     # where torch would device-assert: corrupt targets are loud either way
-    out = _WCE.apply(plain(input).contiguous(), plain(target).contiguous(), plain(weight).contiguous(), ignore_index)
+    out = weighted_ce(plain(input).contiguous(), plain(target).contiguous(), plain(weight).contiguous(), ignore_index)
     return out.as_subclass(DeviceResult)

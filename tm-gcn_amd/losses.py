@@ -9,41 +9,15 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .ops import _ptr, _stream, _want
 
 
 MAX_CLASSES = 8   # kLossMaxC in csrc/loss.hip
 
 
-class _WCE(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, logits, target, weight, ignore_index=-100):
-        lib = _lib.load()
-        _want(logits, "wce logits")
-        _want(weight, "wce weight")
-        _want(target, "wce target", torch.int64)
-        E, Cn = logits.shape
-        if weight.numel() != Cn or target.numel() != E:
-            raise RuntimeError(f"wce: shapes logits {tuple(logits.shape)} target {tuple(target.shape)} weight {tuple(weight.shape)}")
-        loss = torch.empty((), dtype=torch.float32, device=logits.device)
-        stats = torch.empty(2, dtype=torch.float64, device=logits.device)
-        ws = torch.empty(int(lib.tmgcn_wce_workspace_bytes(E)), dtype=torch.uint8, device=logits.device)
-        _lib.check(lib.tmgcn_wce_fwd_f32(_ptr(logits), _ptr(target), _ptr(weight), E, Cn, int(ignore_index), _ptr(loss),
-                                         _ptr(stats), _ptr(ws), ws.numel(), _stream(logits)), "tmgcn_wce_fwd_f32")
-        ctx.ignore_index = int(ignore_index)
-        ctx.save_for_backward(logits, target, weight, stats)
-        return loss
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        logits, target, weight, stats = ctx.saved_tensors
-        E, Cn = logits.shape
-        dz = torch.empty_like(logits)
-        g = g.contiguous().float()
-        _lib.check(lib.tmgcn_wce_bwd_f32(_ptr(logits), _ptr(target), _ptr(weight), _ptr(stats), _ptr(g), E, Cn,
-                                         ctx.ignore_index, _ptr(dz), _stream(logits)), "tmgcn_wce_bwd_f32")
-        return dz, None, None, None
+def weighted_ce(logits: torch.Tensor, target: torch.Tensor, weight: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """Σ w[t]·nll / Σ w[t] through the registered operator ``torch.ops.tmgcn.weighted_ce`` (C++ autograd
+    over tmgcn_wce_fwd_f32 / tmgcn_wce_bwd_f32)."""
+    return _lib.load_torch_ops().weighted_ce(logits, target, weight, int(ignore_index))
 
 
 class WeightedCrossEntropy(nn.Module):
@@ -58,4 +32,4 @@ class WeightedCrossEntropy(nn.Module):
 
     def forward(self, output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         w = self.weight if self.weight.device == output.device else self.weight.to(output.device)
-        return _WCE.apply(output.contiguous(), target.contiguous(), w, self.ignore_index)
+        return weighted_ce(output.contiguous(), target.contiguous(), w, self.ignore_index)

@@ -6,9 +6,11 @@
     activation    P5                               (ehf:284-289)
 
 Every operator runs the hand-written HIP kernels on the current torch stream; there is no
-CPU path — tensors that are not fp32 ROCm tensors raise.  ``kernels`` is the one object
-through which the operators reach the device code (tests of the sharding logic substitute
-it; the product never does).
+CPU path — tensors that are not fp32 ROCm tensors raise.  The device code is reached through
+the PyTorch-ROCm extension layer ``torch.ops.tmgcn.*`` (csrc/torch_ops.cpp: TORCH_LIBRARY
+operators with registered C++ autograd over the C-ABI of include/tmgcn.h).  ``kernels`` is the
+one object through which the operators reach it (tests of the sharding logic substitute it; the
+product never does).
 """
 from __future__ import annotations
 
@@ -149,13 +151,21 @@ class KernelTimer:
 
 
 class HipKernels:
-    """Thin launchers: validate, allocate the output, call the C-ABI on the current stream."""
+    """Kernel-level launchers: one ``torch.ops.tmgcn.*`` call each (tm-gcn_amd/csrc/torch_ops.cpp — the
+    TORCH_LIBRARY layer over the C-ABI; it validates, allocates the outputs and launches on torch's
+    current stream).  Loading fails loudly if either shared library is missing."""
 
     name = "hip"
 
     def __init__(self):
-        self._dw_ws = {}
         self.timer: Optional[KernelTimer] = None
+        self._ops = None
+
+    @property
+    def ops(self):
+        if self._ops is None:
+            self._ops = _lib.load_torch_ops()
+        return self._ops
 
     def _run(self, tag, dev, fn):
         return self.timer.launch(tag, dev, fn) if self.timer is not None else fn()
@@ -163,35 +173,13 @@ class HipKernels:
     # P1 ---------------------------------------------------------------------------------
     def mtransform(self, op: MOperator, X: torch.Tensor, transpose=False, row_off=0, col_off=0,
                    T_out: Optional[int] = None, x_group_rows=0, y_group_rows=0) -> torch.Tensor:
-        lib = _lib.load()
-        _want(X, "mtransform X")
-        T_in = X.shape[0]
-        if T_out is None:
-            T_out = T_in
-        C_ = X.numel() // max(1, T_in)
-        Y = torch.empty((T_out,) + tuple(X.shape[1:]), dtype=torch.float32, device=X.device)
         lo, hi = (op.band_hi, op.band_lo) if transpose else (op.band_lo, op.band_hi)
-        rc = self._run("mtransform_T" if transpose else "mtransform", X.device, lambda: lib.tmgcn_mtransform_f32(
-            _ptr(op.M), op.T, op.T, int(bool(transpose)), row_off, col_off, T_out, T_in, lo, hi, _ptr(X), _ptr(Y),
-            C_, x_group_rows, y_group_rows, _stream(X)))
-        _lib.check(rc, "tmgcn_mtransform_f32")
-        return Y
+        return self._run("mtransform_T" if transpose else "mtransform", X.device, lambda: self.ops.mtransform(
+            op.M, X, bool(transpose), row_off, col_off, -1 if T_out is None else T_out, lo, hi, x_group_rows, y_group_rows))
 
     # P2 ---------------------------------------------------------------------------------
     def spmm(self, A: BatchedCSR, X: torch.Tensor, tag="spmm") -> torch.Tensor:
-        lib = _lib.load()
-        _want(X, "spmm X")
-        if X.dim() != 3 or X.shape[0] != A.T or X.shape[1] != A.N:
-            raise RuntimeError(f"spmm: X {tuple(X.shape)} does not match adjacency T={A.T} N={A.N}")
-        if A.device != X.device:
-            raise RuntimeError("spmm: adjacency and X live on different devices")
-        F = X.shape[2]
-        Y = torch.empty_like(X)
-        rc = self._run(tag, X.device, lambda: lib.tmgcn_spmm_csr_batched_f32_hint(
-            _ptr(A.rowptr), _ptr(A.col), _ptr(A.val), _ptr(X), _ptr(Y), A.n_rows, A.N, F,
-            C.c_float(A.avg_nnz_per_row), _stream(X)))
-        _lib.check(rc, "tmgcn_spmm_csr_batched_f32")
-        return Y
+        return self._run(tag, X.device, lambda: self.ops.spmm_csr_batched(A.rowptr, A.col, A.val, X, A.N, A.avg_nnz_per_row))
 
     # P2+P3 fused ----------------------------------------------------------------------
     def spmm_gemm_supported(self, K: int, Nf: int) -> bool:
@@ -203,124 +191,47 @@ class HipKernels:
         out = (Y, AX, pre) writes into caller-provided (views of) tensors instead of allocating.
         grid_reserve: block slots this launch leaves free (the pipelined sharded layer's RCCL
         kernels need them); a per-call argument, nothing process-wide."""
-        lib = _lib.load()
-        _want(X, "spmm_gemm X")
-        _want(W, "spmm_gemm W")
-        if X.dim() != 3 or X.shape[0] != A.T or X.shape[1] != A.N:
-            raise RuntimeError(f"spmm_gemm: X {tuple(X.shape)} does not match adjacency T={A.T} N={A.N}")
-        T, N, K = X.shape
-        per_slice = W.dim() == 3
-        wk, wn = (W.shape[-1], W.shape[-2]) if trans_w else (W.shape[-2], W.shape[-1])
-        if wk != K or (per_slice and W.shape[0] != T):
-            raise RuntimeError(f"spmm_gemm: size mismatch X {tuple(X.shape)} W {tuple(W.shape)} trans_w={trans_w}")
         act_id = _lib.ACT_IDS[act]
         if out is not None:
             Y, AX, pre = out
-            _want(Y, "spmm_gemm out Y")
-            if tuple(Y.shape) != (T, N, wn):
-                raise RuntimeError(f"spmm_gemm: out Y {tuple(Y.shape)} != {(T, N, wn)}")
-        else:
-            Y = torch.empty((T, N, wn), dtype=torch.float32, device=X.device)
-            AX = torch.empty_like(X) if want_ax else None
-            pre = torch.empty_like(Y) if (want_pre and act_id) else None
-        rc = self._run(tag, X.device, lambda: lib.tmgcn_spmm_gemm_f32(
-            _ptr(A.rowptr), _ptr(A.col), _ptr(A.val), _ptr(X), A.n_rows, A.N, K, _ptr(W), wn,
-            int(bool(trans_w)), N if per_slice else 0, W.shape[-1] * W.shape[-2] if per_slice else 0, act_id,
-            _ptr(Y), _ptr(AX), _ptr(pre), int(grid_reserve), _stream(X)))
-        _lib.check(rc, "tmgcn_spmm_gemm_f32")
-        return Y, AX, pre
+            self._run(tag, X.device, lambda: self.ops.spmm_gemm_out(
+                A.rowptr, A.col, A.val, X, A.N, W, bool(trans_w), act_id, Y, AX, pre, int(grid_reserve)))
+            return Y, AX, pre
+        Y, AX, pre = self._run(tag, X.device, lambda: self.ops.spmm_gemm(
+            A.rowptr, A.col, A.val, X, A.N, W, bool(trans_w), act_id, bool(want_ax), bool(want_pre), int(grid_reserve)))
+        return Y, (AX if AX.numel() else None), (pre if pre.numel() else None)
 
     # P3 ---------------------------------------------------------------------------------
     def gemm(self, A: torch.Tensor, W: torch.Tensor, trans_w=False, act=None, want_pre=False):
         """A [T,N,K] · W ([K,Nf] shared or [T,K,Nf] per slice; transposed if trans_w)."""
-        lib = _lib.load()
-        _want(A, "gemm A")
-        _want(W, "gemm W")
-        T, N, K = A.shape
-        per_slice = W.dim() == 3
-        wk, wn = (W.shape[-1], W.shape[-2]) if trans_w else (W.shape[-2], W.shape[-1])
-        if wk != K or (per_slice and W.shape[0] != T):
-            raise RuntimeError(f"gemm: size mismatch A {tuple(A.shape)} W {tuple(W.shape)} trans_w={trans_w}")
-        Y = torch.empty((T, N, wn), dtype=torch.float32, device=A.device)
-        act_id = _lib.ACT_IDS[act]
-        pre = torch.empty_like(Y) if (want_pre and act_id) else None
-        rc = self._run("gemm_dA" if trans_w else "gemm", A.device, lambda: lib.tmgcn_gemm_f32(
-            _ptr(A), _ptr(W), _ptr(Y), _ptr(pre), T * N, K, wn, int(bool(trans_w)), N if per_slice else 0,
-            W.shape[-1] * W.shape[-2] if per_slice else 0, act_id, _stream(A)))
-        _lib.check(rc, "tmgcn_gemm_f32")
-        return (Y, pre) if want_pre else Y
+        Y, pre = self._run("gemm_dA" if trans_w else "gemm", A.device, lambda: self.ops.bgemm(
+            A, W, bool(trans_w), _lib.ACT_IDS[act], bool(want_pre)))
+        return (Y, pre if pre.numel() else None) if want_pre else Y
 
     def gemm_dw(self, A: torch.Tensor, dY: torch.Tensor, per_slice: bool, algo=None) -> torch.Tensor:
         """dW = Σ_r A[r]ᵀ dY[r].  algo: None / "auto" (bf16x3 split on the bf16 matrix cores where the
         shapes allow) or "f32mfma" (exact-f32 MFMA kernel) — per call."""
-        lib = _lib.load()
-        _want(A, "gemm_dw A")
-        _want(dY, "gemm_dw dY")
-        T, N, K = A.shape
-        Nf = dY.shape[2]
-        R = T * N
-        rpb = N if per_slice else 0
-        need = int(lib.tmgcn_gemm_dw_workspace_bytes(R, K, Nf, rpb))
-        key = (A.device, torch.cuda.current_stream(A.device).cuda_stream)
-        ws = self._dw_ws.get(key)
-        if ws is None or ws.numel() < need:
-            ws = torch.empty(max(need, 1), dtype=torch.uint8, device=A.device)
-            self._dw_ws[key] = ws
-        dW = torch.empty((T, K, Nf) if per_slice else (K, Nf), dtype=torch.float32, device=A.device)
-        rc = self._run("gemm_dW", A.device, lambda: lib.tmgcn_gemm_dw_f32(
-            _ptr(A), _ptr(dY), _ptr(dW), R, K, Nf, rpb, _lib.DW_ALGOS[algo], _ptr(ws), ws.numel(), _stream(A)))
-        _lib.check(rc, "tmgcn_gemm_dw_f32")
-        return dW
+        return self._run("gemm_dW", A.device, lambda: self.ops.bgemm_dW(A, dY, bool(per_slice), _lib.DW_ALGOS[algo]))
 
     # P4 ---------------------------------------------------------------------------------
     def edge_head_supported(self, F: int, Cn: int) -> bool:
         return bool(_lib.load().tmgcn_edge_head_supported(F, Cn))
 
     def edge_head_fwd(self, Z2: torch.Tensor, edges: "EdgeIndex", U: torch.Tensor) -> torch.Tensor:
-        lib = _lib.load()
-        _want(Z2, "edge_head Z")
-        _want(U, "edge_head U")
-        F, Cn = Z2.shape[1], U.shape[1]
-        if U.shape[0] != 2 * F:
-            raise RuntimeError(f"edge_head: U {tuple(U.shape)} does not match F={F}")
-        out = torch.empty(edges.E, Cn, dtype=torch.float32, device=Z2.device)
-        rc = self._run("edge_head", Z2.device, lambda: lib.tmgcn_edge_head_fwd_f32(
-            _ptr(Z2), _ptr(edges.src), _ptr(edges.dst), _ptr(U), _ptr(out), edges.E, F, Cn, _stream(Z2)))
-        _lib.check(rc, "tmgcn_edge_head_fwd_f32")
-        return out
+        return self._run("edge_head", Z2.device, lambda: self.ops.edge_head_fwd(Z2, edges.src, edges.dst, U))
 
     def edge_head_bwd(self, Z2, edges: "EdgeIndex", U, dout, need_dz=True, need_du=True):
-        lib = _lib.load()
-        _want(dout, "edge_head dout")
-        R, F = Z2.shape
-        Cn = U.shape[1]
-        eptr, eidx = edges.inverted(R)
-        dZ = torch.empty_like(Z2) if need_dz else None
-        dU = torch.empty_like(U) if need_du else None
-        need = int(lib.tmgcn_edge_head_bwd_workspace_bytes(edges.E, F, Cn))
-        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=Z2.device)
-        rc = self._run("edge_head_bwd", Z2.device, lambda: lib.tmgcn_edge_head_bwd_f32(
-            _ptr(Z2), _ptr(edges.src), _ptr(edges.dst), _ptr(U), _ptr(dout), _ptr(eptr), _ptr(eidx),
-            _ptr(dZ), _ptr(dU), R, edges.E, F, Cn, _ptr(ws), ws.numel(), _stream(Z2)))
-        _lib.check(rc, "tmgcn_edge_head_bwd_f32")
-        return dZ, dU
+        eptr, eidx = edges.inverted(Z2.shape[0])
+        dZ, dU = self._run("edge_head_bwd", Z2.device, lambda: self.ops.edge_head_bwd(
+            Z2, edges.src, edges.dst, U, dout, eptr, eidx, bool(need_dz), bool(need_du)))
+        return (dZ if need_dz else None), (dU if need_du else None)
 
     # P5 ---------------------------------------------------------------------------------
     def act_fwd(self, x: torch.Tensor, act) -> torch.Tensor:
-        lib = _lib.load()
-        _want(x, "act x")
-        y = torch.empty_like(x)
-        _lib.check(lib.tmgcn_act_fwd_f32(_ptr(x), _ptr(y), x.numel(), _lib.ACT_IDS[act], _stream(x)), "tmgcn_act_fwd_f32")
-        return y
+        return self.ops.act_fwd(x, _lib.ACT_IDS[act])
 
     def act_bwd(self, x: torch.Tensor, dy: torch.Tensor, act) -> torch.Tensor:
-        lib = _lib.load()
-        _want(x, "act x")
-        _want(dy, "act dy")
-        dx = torch.empty_like(x)
-        _lib.check(lib.tmgcn_act_bwd_f32(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _lib.ACT_IDS[act], _stream(x)),
-                   "tmgcn_act_bwd_f32")
-        return dx
+        return self.ops.act_bwd(x, dy, _lib.ACT_IDS[act])
 
 
 kernels = HipKernels()
@@ -440,20 +351,47 @@ class _Activation(torch.autograd.Function):
         return kernels.act_bwd(x, dy.contiguous(), ctx.act), None
 
 
+def _registered() -> bool:
+    """True when the operators should go through the registered differentiable ops of the torch
+    extension (torch.ops.tmgcn.m_transform / spmm / feature_gemm / spmm_feature_gemm / edge_head /
+    activation: C++ autograd, one dispatcher call per operator).  The Python autograd functions
+    above remain for two cases: a per-launch KernelTimer is attached (bench.py's roofline leg times
+    every launch, backward ones included), or `kernels` has been substituted (gloo tests of the
+    sharding logic)."""
+    return kernels.name == "hip" and kernels.timer is None
+
+
+def _csr_t(A: BatchedCSR, needed: bool):
+    """(t_rowptr, t_col, t_val) of the transposed adjacency (built once per adjacency) when a
+    gradient with respect to the dense operand will be asked for, else three Nones."""
+    if not needed:
+        return None, None, None
+    At = A.transpose()
+    return At.rowptr, At.col, At.val
+
+
 def m_transform(X: torch.Tensor, op: MOperator, row_off=0, col_off=0, T_out=None, x_group_rows=0,
                 y_group_rows=0) -> torch.Tensor:
     """P1: Y[k] = Σ_j M[row_off+k][col_off+j] · X[j]  along the first (time) mode.
     x_group_rows / y_group_rows: group-interleaved row storage of X / Y (include/tmgcn.h)."""
+    if _registered():
+        return kernels.ops.m_transform(X, op.M, op.band_lo, op.band_hi, row_off, col_off,
+                                       -1 if T_out is None else T_out, x_group_rows, y_group_rows)
     return _MTransform.apply(X, op, row_off, col_off, T_out, x_group_rows, y_group_rows)
 
 
 def spmm(A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
     """P2: Y[k] = Â_k · X[k] for all frontal slices in one launch."""
+    if _registered():
+        need = X.requires_grad and torch.is_grad_enabled()
+        return kernels.ops.spmm(X, A.rowptr, A.col, A.val, *_csr_t(A, need), A.N, A.avg_nnz_per_row)
     return _Spmm.apply(X, A)
 
 
 def feature_gemm(A: torch.Tensor, W: torch.Tensor, act=None) -> torch.Tensor:
     """P3 (+ fused P5): act(A · W), W shared ([K,Nf]) or per slice ([T,K,Nf])."""
+    if _registered():
+        return kernels.ops.feature_gemm(A, W, _lib.ACT_IDS[act])
     return _FeatureGemm.apply(A, W, act)
 
 
@@ -468,6 +406,10 @@ def spmm_feature_gemm(A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, act=None,
     if fuse and not can:
         raise RuntimeError(f"fused SpMM+GEMM does not support K={K}, Nf={Nf}")
     if fuse:
+        if _registered():
+            need = X.requires_grad and torch.is_grad_enabled()
+            return kernels.ops.spmm_feature_gemm(X, W, A.rowptr, A.col, A.val, *_csr_t(A, need), A.N,
+                                                 A.avg_nnz_per_row, _lib.ACT_IDS[act], 0)
         return _SpmmGemm.apply(X, W, A, act)
     return feature_gemm(spmm(A, X), W, act=act)
 
@@ -482,10 +424,16 @@ def edge_head(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, fuse: Optional
     if fuse and not can:
         raise RuntimeError(f"fused edge head does not support F={F}, C={Cn}")
     if fuse:
+        if _registered():
+            need = torch.is_grad_enabled() and (Z.requires_grad or U.requires_grad)
+            eptr, eidx = edges.inverted(Z.numel() // F) if need else (None, None)
+            return kernels.ops.edge_head(Z, U.contiguous(), edges.src, edges.dst, eptr, eidx)
         return _EdgeHead.apply(Z.contiguous(), U.contiguous(), edges)
     Zf = Z.reshape(-1, F)
     return torch.matmul(torch.cat((Zf[edges.src], Zf[edges.dst]), dim=1), U)
 
 
 def activation(x: torch.Tensor, act) -> torch.Tensor:
+    if _registered():
+        return kernels.ops.activation(x, _lib.ACT_IDS[act])
     return _Activation.apply(x, act)
