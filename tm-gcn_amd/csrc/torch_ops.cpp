@@ -331,8 +331,8 @@ struct SpmmFn : public torch::autograd::Function<SpmmFn> {
   // sparse.mm backward: dX_k = Â_kᵀ dY_k (Â is a constant: no gradient, as in the reference)
   static Tensor forward(AutogradContext* ctx, const Tensor& X, const Tensor& rowptr, const Tensor& col,
                         const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col, const OptTensor& t_val,
-                        int64_t N, double avg) {
-    const bool need = X.requires_grad() && at::GradMode::is_enabled();
+                        int64_t N, double avg, bool need) {
+    // `need` is decided by the caller: inside forward() autograd has already switched grad mode off
     at::AutoDispatchBelowADInplaceOrView guard;
     if (need) {
       TORCH_CHECK(t_rowptr.has_value() && t_col.has_value() && t_val.has_value(),
@@ -348,7 +348,7 @@ struct SpmmFn : public torch::autograd::Function<SpmmFn> {
     auto sv = ctx->get_saved_variables();
     Tensor dX = spmm_csr_batched(sv[0], sv[1], sv[2], grads[0].contiguous(), ctx->saved_data["N"].toInt(),
                                  ctx->saved_data["avg"].toDouble());
-    return {dX, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    return {dX, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -378,9 +378,8 @@ struct SpmmFeatureGemmFn : public torch::autograd::Function<SpmmFeatureGemmFn> {
   // Fused P2+P3.  Backward uses Âᵀ(dY·Wᵀ) = (Âᵀ·dY)·Wᵀ: the same fused kernel on dY.
   static Tensor forward(AutogradContext* ctx, const Tensor& X, const Tensor& W, const Tensor& rowptr,
                         const Tensor& col, const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col,
-                        const OptTensor& t_val, int64_t N, double avg, int64_t act, int64_t grid_reserve) {
-    const bool grad = at::GradMode::is_enabled();
-    const bool need_x = grad && X.requires_grad(), need_w = grad && W.requires_grad();
+                        const OptTensor& t_val, int64_t N, double avg, int64_t act, int64_t grid_reserve,
+                        bool need_x, bool need_w) {
     at::AutoDispatchBelowADInplaceOrView guard;
     auto [Y, AX, pre] = spmm_gemm(rowptr, col, val, X, N, W, false, act, need_w, need_x || need_w, grid_reserve);
     if (need_x)
@@ -411,14 +410,14 @@ struct SpmmFeatureGemmFn : public torch::autograd::Function<SpmmFeatureGemmFn> {
                               ctx->saved_data["avg"].toDouble());
     }
     if (ctx->needs_input_grad(1)) dW = bgemm_dW(AX, dY, W.dim() == 3, TMGCN_DW_AUTO);
-    return {dX, dW, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    return {dX,       dW,       Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+            Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
 struct EdgeHeadFn : public torch::autograd::Function<EdgeHeadFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& Z, const Tensor& U, const Tensor& src, const Tensor& dst,
-                        const OptTensor& eptr, const OptTensor& eidx) {
-    const bool need = at::GradMode::is_enabled() && (Z.requires_grad() || U.requires_grad());
+                        const OptTensor& eptr, const OptTensor& eidx, bool need) {
     at::AutoDispatchBelowADInplaceOrView guard;
     Tensor Z2 = Z.contiguous().reshape({-1, Z.size(-1)});
     if (need) {
@@ -434,7 +433,7 @@ struct EdgeHeadFn : public torch::autograd::Function<EdgeHeadFn> {
     const bool nz = ctx->needs_input_grad(0), nu = ctx->needs_input_grad(1);
     auto [dZ, dU] = edge_head_bwd(sv[0], sv[2], sv[3], sv[1], grads[0].contiguous(), sv[4], sv[5], nz, nu);
     Tensor gz = nz ? dZ.reshape(ctx->saved_data["zshape"].toIntVector()) : Tensor();
-    return {gz, nu ? dU : Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    return {gz, nu ? dU : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -474,17 +473,21 @@ Tensor m_transform_ad(const Tensor& X, const Tensor& M, int64_t band_lo, int64_t
 }
 Tensor spmm_ad(const Tensor& X, const Tensor& rowptr, const Tensor& col, const Tensor& val, const OptTensor& t_rowptr,
                const OptTensor& t_col, const OptTensor& t_val, int64_t N, double avg) {
-  return SpmmFn::apply(X, rowptr, col, val, t_rowptr, t_col, t_val, N, avg);
+  return SpmmFn::apply(X, rowptr, col, val, t_rowptr, t_col, t_val, N, avg,
+                       at::GradMode::is_enabled() && X.requires_grad());
 }
 Tensor feature_gemm_ad(const Tensor& A, const Tensor& W, int64_t act) { return FeatureGemmFn::apply(A, W, act); }
 Tensor spmm_feature_gemm_ad(const Tensor& X, const Tensor& W, const Tensor& rowptr, const Tensor& col,
                             const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col,
                             const OptTensor& t_val, int64_t N, double avg, int64_t act, int64_t grid_reserve) {
-  return SpmmFeatureGemmFn::apply(X, W, rowptr, col, val, t_rowptr, t_col, t_val, N, avg, act, grid_reserve);
+  const bool grad = at::GradMode::is_enabled();
+  return SpmmFeatureGemmFn::apply(X, W, rowptr, col, val, t_rowptr, t_col, t_val, N, avg, act, grid_reserve,
+                                  grad && X.requires_grad(), grad && W.requires_grad());
 }
 Tensor edge_head_ad(const Tensor& Z, const Tensor& U, const Tensor& src, const Tensor& dst, const OptTensor& eptr,
                     const OptTensor& eidx) {
-  return EdgeHeadFn::apply(Z, U, src, dst, eptr, eidx);
+  return EdgeHeadFn::apply(Z, U, src, dst, eptr, eidx,
+                           at::GradMode::is_enabled() && (Z.requires_grad() || U.requires_grad()));
 }
 Tensor activation_ad(const Tensor& x, int64_t act) { return ActivationFn::apply(x, act); }
 Tensor weighted_ce_ad(const Tensor& logits, const Tensor& target, const Tensor& weight, int64_t ignore_index) {

@@ -326,3 +326,118 @@ class ShardedTMGCNLayer:
         Nl, F = self.N // self.G, Y.shape[2]
         recv = _SliceToNode.apply(Y, self.group)          # [Tl][G][Nl][F], block kk = slice kk of every rank
         return recv.transpose(0, 1).reshape(self.T, Nl, F)
+
+
+# ---------------------------------------------------------------------------------------
+# slice sharding of the drop-in models (layers.EmbeddingGCN / EmbeddingGCN2 / EmbeddingKWGCN, group=…)
+# ---------------------------------------------------------------------------------------
+class _GatherSlices(torch.autograd.Function):
+    """Slice-sharded [Tl_r, …] -> replicated [T, …] (ranks may own one slice more or less: shards
+    are padded to the largest).  Each rank goes on to compute something different from the
+    gathered tensor (its own rows of M ×₁ ·), so the adjoint is a reduce-scatter."""
+
+    @staticmethod
+    def forward(ctx, x, shard):
+        ctx.shard = shard
+        G, Tmax = shard.G, shard.Tmax
+        tail = tuple(x.shape[1:])
+        pad = x.new_zeros((Tmax,) + tail)
+        pad[:x.shape[0]] = x
+        out = x.new_empty((G * Tmax,) + tail)
+        dist.all_gather_into_tensor(out, pad, group=shard.group)
+        out = out.view((G, Tmax) + tail)
+        return torch.cat([out[r, :b - a] for r, (a, b) in enumerate(shard.bounds)], dim=0)
+
+    @staticmethod
+    def backward(ctx, d):
+        shard = ctx.shard
+        G, Tmax = shard.G, shard.Tmax
+        tail = tuple(d.shape[1:])
+        pad = d.new_zeros((G, Tmax) + tail)
+        for r, (a, b) in enumerate(shard.bounds):
+            pad[r, :b - a] = d[a:b]
+        out = d.new_empty((Tmax,) + tail)
+        dist.reduce_scatter_tensor(out, pad.view((G * Tmax,) + tail), op=dist.ReduceOp.SUM, group=shard.group)
+        return out[:shard.Tl].contiguous(), None
+
+
+class _GatherRows(torch.autograd.Function):
+    """Per-rank rows (the logits of the edges a rank owns) -> the full [E, C] result in the caller's
+    edge order, on every rank.  Every rank then evaluates the SAME loss on it, so the gradient of
+    the local rows is simply their rows of the upstream gradient (no sum over ranks: the loss is
+    one replicated scalar, not G different ones)."""
+
+    @staticmethod
+    def forward(ctx, local, shard, counts, gather_index, mine):
+        ctx.mine = mine
+        G, Emax = shard.G, max(max(counts), 1)
+        tail = tuple(local.shape[1:])
+        pad = local.new_zeros((Emax,) + tail)
+        pad[:local.shape[0]] = local
+        out = local.new_empty((G * Emax,) + tail)
+        dist.all_gather_into_tensor(out, pad, group=shard.group)
+        return out[gather_index]
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[ctx.mine].contiguous(), None, None, None, None
+
+
+class SliceShard:
+    """Slice ownership of one rank inside `group`, and the three collectives a slice-sharded
+    drop-in model needs (all autograd-aware):
+      * m_transform  — the ONE exchange of a layer that mixes slices (apply_M_twice / use_Minv
+                       branches, ehf:224, 332, 341-346): all-gather of the slice-sharded activation,
+                       then only this rank's rows of M (or M⁻¹);
+      * shared       — replicated parameters: gradients summed over the ranks (all-reduce);
+      * gather_rows  — per-rank edge logits -> the full [E, C] tensor in the caller's edge order.
+    The reference's as-run models (default layer-2 branch) need no activation exchange at all."""
+
+    def __init__(self, group, T: int):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("group= needs an initialised torch.distributed process group")
+        self.group = group
+        self.rank, self.G = dist.get_rank(group), dist.get_world_size(group)
+        self.T = int(T)
+        self.bounds = even_bounds(self.T, self.G)
+        self.k0, self.k1 = self.bounds[self.rank]
+        self.Tl = self.k1 - self.k0
+        self.Tmax = max(b - a for a, b in self.bounds)
+
+    def local(self, seq):
+        """This rank's slices of a per-slice sequence (list of adjacency slices, or a [T, …] tensor)."""
+        return seq[self.k0:self.k1]
+
+    def gather_slices(self, x_local: torch.Tensor) -> torch.Tensor:
+        return _GatherSlices.apply(x_local.contiguous(), self)
+
+    def m_transform(self, x_local: torch.Tensor, op: "ops.MOperator") -> torch.Tensor:
+        full = self.gather_slices(x_local)
+        return ops.m_transform(full, op, row_off=self.k0, col_off=0, T_out=self.Tl)
+
+    def shared(self, w: torch.Tensor) -> torch.Tensor:
+        return _SharedWeight.apply(w, self.group)
+
+    def edge_index(self, edges: torch.Tensor, N: int, device):
+        """(EdgeIndex of the edges whose slice this rank owns — slice numbers re-based to the shard —,
+        per-rank counts, gather_index [E] into the rank-major padded gather, positions of this rank's edges)."""
+        e = edges.detach()
+        ops.EdgeIndex(e, N, "cpu" if e.device.type == "cpu" else e.device, T=self.T)     # validate the full set once
+        t = e[0]
+        owner = torch.zeros_like(t)
+        for r, (a, b) in enumerate(self.bounds):
+            owner[(t >= a) & (t < b)] = r
+        counts = [int((owner == r).sum()) for r in range(self.G)]
+        Emax = max(max(counts), 1)
+        within = torch.zeros_like(t)
+        for r in range(self.G):
+            m = owner == r
+            within[m] = torch.arange(counts[r], dtype=t.dtype, device=t.device)
+        gather_index = (owner * Emax + within).to(device)
+        mine = torch.nonzero(owner == self.rank).reshape(-1)
+        e_loc = e[:, mine].clone()
+        e_loc[0] -= self.k0
+        return ops.EdgeIndex(e_loc, N, device, T=max(self.Tl, 1)), counts, gather_index, mine.to(device)
+
+    def gather_rows(self, local: torch.Tensor, counts, gather_index, mine) -> torch.Tensor:
+        return _GatherRows.apply(local.contiguous(), self, counts, gather_index, mine)

@@ -89,6 +89,69 @@ class _Deliver:
         return out
 
 
+class _Sharding:
+    """Mixin: optional slice sharding of a drop-in model over a torch.distributed process group.
+
+    ``group=None`` (default): the whole model on this process's device, as in the reference.
+    ``group=<ProcessGroup>`` (e.g. ``dist.group.WORLD``): every rank is handed the same inputs (as a
+    script run under torchrun would do) and keeps only its contiguous range of frontal slices —
+    its block of the adjacency, its slices of the cached ``AtXt`` and of every activation, the
+    labelled edges of its slices.  Parameters stay replicated (same seeded draws on every rank;
+    gradients summed over the ranks).  Collectives: one all-gather of the activation in front of
+    each M / M⁻¹ product that follows the first propagation (``apply_M_twice``,
+    ``apply_M_three_times``, ``use_Minv`` — the as-run default layer-2 branch needs none), the
+    all-gather of the per-rank logits into the caller's [E, C] order, and the all-reduce of the
+    parameter gradients.  X is the constant layer-1 input and is kept whole."""
+
+    _shard = None
+
+    def _init_shard(self, group):
+        if group is not None:
+            from .dist import SliceShard
+            self._shard = SliceShard(group, self.T)
+            if self._shard.Tl == 0:
+                raise RuntimeError(f"T={self.T} slices cannot be sharded over {self._shard.G} ranks")
+
+    def _own(self, seq):
+        """This rank's slices of a list of adjacency slices / a BatchedCSR / a [T,…] tensor."""
+        if self._shard is None:
+            return seq
+        if isinstance(seq, BatchedCSR):
+            return seq.slices(self._shard.k0, min(self._shard.k1, seq.T))
+        return seq[self._shard.k0:self._shard.k1]
+
+    def _mt_input(self, X: torch.Tensor, op) -> torch.Tensor:
+        """P1 of the constant input (kept whole on every rank): only this rank's output slices."""
+        if self._shard is None:
+            return ops.m_transform(X, op)
+        return ops.m_transform(X, op, row_off=self._shard.k0, col_off=0, T_out=self._shard.Tl)
+
+    def _mt(self, Y: torch.Tensor, op) -> torch.Tensor:
+        """M (or M⁻¹) applied to a slice-sharded activation: the one exchange of that layer."""
+        return ops.m_transform(Y, op) if self._shard is None else self._shard.m_transform(Y, op)
+
+    def _p(self, param: torch.Tensor, per_slice: bool = False) -> torch.Tensor:
+        """A parameter as the kernels take it: fp32, gradient summed over the ranks when sharded,
+        and — for one-weight-per-slice parameters — this rank's slices."""
+        w = _w(param)
+        if self._shard is not None:
+            w = self._shard.shared(w)
+            if per_slice:
+                w = w[self._shard.k0:self._shard.k1].contiguous()
+        return w
+
+    def _edge_index(self, edges, dev):
+        if self._shard is None:
+            return _EdgeIndex(edges, self.N, dev, T=self.T)
+        return self._shard.edge_index(edges, self.N, dev)
+
+    def _head(self, Z: torch.Tensor, eidx, U: torch.Tensor) -> torch.Tensor:
+        if self._shard is None:
+            return _edge_head(Z, eidx, U)
+        local_idx, counts, gather_index, mine = eidx
+        return self._shard.gather_rows(_edge_head(Z, local_idx, U), counts, gather_index, mine)
+
+
 def _param(t: torch.Tensor, dev, dtype) -> nn.Parameter:
     """A parameter drawn on the CPU generator (reference order/values), stored on the device in
     `dtype` (fp32, or bf16 for the "bf16 weights" config)."""
@@ -101,16 +164,18 @@ def _w(p: torch.Tensor) -> torch.Tensor:
     return p if p.dtype == torch.float32 else p.float()
 
 
-class EmbeddingGCN(_Deliver, nn.Module):
-    """1-layer TM-GCN (ehf:156-234)."""
+class EmbeddingGCN(_Deliver, _Sharding, nn.Module):
+    """1-layer TM-GCN (ehf:156-234).  ``group``: slice-shard the model over a process group (_Sharding)."""
 
     def __init__(self, At: AdjLike, X: torch.Tensor, edges: torch.Tensor, M: torch.Tensor,
                  hidden_feat=[2, 2], condensed_W=False, use_Minv=True, device=None,
-                 param_dtype=torch.float32):
+                 param_dtype=torch.float32, group=None):
         super().__init__()
         dev = torch.device(device) if device is not None else _default_device()
         self.use_Minv = use_Minv
+        self.condensed_W = condensed_W
         self.T, self.N = int(X.shape[0]), int(X.shape[1])
+        self._init_shard(group)
         self.F = [int(X.shape[-1])] + list(hidden_feat)
         self.Mop = ops.MOperator(M, dev)
         if self.Mop.T != self.T:
@@ -120,24 +185,24 @@ class EmbeddingGCN(_Deliver, nn.Module):
         w_shape = (self.F[0], self.F[1]) if condensed_W else (self.T, self.F[0], self.F[1])
         self.W = _param(torch.randn(*w_shape), dev, param_dtype)                      # ehf:189/191
         self.U = _param(torch.randn(2 * self.F[1], self.F[2]), dev, param_dtype)     # ehf:192
-        self.AtXt = self.compute_AtXt(_adj(At, self.N, dev), _feat(X, dev))   # ehf:195
-        self._edges = _EdgeIndex(edges, self.N, dev, T=self.T)
+        self.AtXt = self.compute_AtXt(_adj(self._own(At), self.N, dev), _feat(X, dev))   # ehf:195
+        self._edges = self._edge_index(edges, dev)
         self.dev = dev
 
     def compute_AtXt(self, At: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
-        """ehf:203-208 — P1 then P2."""
-        return ops.spmm(At, ops.m_transform(X, self.Mop))
+        """ehf:203-208 — P1 then P2 (sharded: this rank's slices of both)."""
+        return ops.spmm(At, self._mt_input(X, self.Mop))
 
     def forward(self, At=None, X=None, edges=None):
         if _is_recompute_call(At, X, edges):
-            AtXt = self.compute_AtXt(_adj(At, self.N, self.dev), _feat(X, self.dev))
-            eidx = _EdgeIndex(edges, self.N, self.dev, T=self.T)
+            AtXt = self.compute_AtXt(_adj(self._own(At), self.N, self.dev), _feat(X, self.dev))
+            eidx = self._edge_index(edges, self.dev)
         else:
             AtXt, eidx = self.AtXt, self._edges
-        Y = ops.feature_gemm(AtXt, _w(self.W))                               # ehf:222
+        Y = ops.feature_gemm(AtXt, self._p(self.W, per_slice=not self.condensed_W))   # ehf:222
         if self.use_Minv:
-            Y = ops.m_transform(Y, self.Minv)                                # ehf:224
-        return self._deliver(_edge_head(Y, eidx, _w(self.U)))
+            Y = self._mt(Y, self.Minv)                                       # ehf:224
+        return self._deliver(self._head(Y, eidx, self._p(self.U)))
 
 
 class EmbeddingGCN_reg(_Deliver, nn.Module):
@@ -170,12 +235,12 @@ class EmbeddingGCN_reg(_Deliver, nn.Module):
         return self._deliver(self.lin1(Y).squeeze(2))                        # ehf:421-423
 
 
-class EmbeddingGCN2(_Deliver, nn.Module):
-    """2-layer TM-GCN (ehf:236-357)."""
+class EmbeddingGCN2(_Deliver, _Sharding, nn.Module):
+    """2-layer TM-GCN (ehf:236-357).  ``group``: slice-shard the model over a process group (_Sharding)."""
 
     def __init__(self, At: AdjLike, X: torch.Tensor, edges: torch.Tensor, M: torch.Tensor,
                  hidden_feat=[2, 2, 2], condensed_W=False, use_Minv=True, apply_M_twice=False,
-                 apply_M_three_times=False, nonlin2="relu", device=None, param_dtype=torch.float32):
+                 apply_M_three_times=False, nonlin2="relu", device=None, param_dtype=torch.float32, group=None):
         super().__init__()
         dev = torch.device(device) if device is not None else _default_device()
         if nonlin2 not in _NONLIN:
@@ -184,7 +249,9 @@ class EmbeddingGCN2(_Deliver, nn.Module):
         self.apply_M_twice = apply_M_twice
         self.apply_M_three_times = apply_M_three_times
         self.nonlin2 = nonlin2
+        self.condensed_W = condensed_W
         self.T, self.N = int(X.shape[0]), int(X.shape[1])
+        self._init_shard(group)
         self.F = [int(X.shape[-1])] + list(hidden_feat)
         self.Mop = ops.MOperator(M, dev)
         if self.Mop.T != self.T:
@@ -195,9 +262,9 @@ class EmbeddingGCN2(_Deliver, nn.Module):
         self.W1 = _param(torch.randn(*lead, self.F[0], self.F[1]), dev, param_dtype)  # ehf:278/281
         self.W2 = _param(torch.randn(*lead, self.F[1], self.F[2]), dev, param_dtype)  # ehf:279/282
         self.U = _param(torch.randn(self.F[2] * 2, self.F[3]), dev, param_dtype)      # ehf:283
-        self.At = _adj(At, self.N, dev)                                            # ehf:267
+        self.At = _adj(self._own(At), self.N, dev)                                 # ehf:267 (sharded: this rank's slices)
         self.AtXt = self.compute_AtXt(self.At, _feat(X, dev))                      # ehf:293
-        self._edges = _EdgeIndex(edges, self.N, dev, T=self.T)
+        self._edges = self._edge_index(edges, dev)
         self.dev = dev
 
     def compute_AX(self, A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
@@ -205,38 +272,41 @@ class EmbeddingGCN2(_Deliver, nn.Module):
         return ops.spmm(A, X)
 
     def compute_AtXt(self, At: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
-        """ehf:307-312 — P1 then P2."""
-        return ops.spmm(At, ops.m_transform(X, self.Mop))
+        """ehf:307-312 — P1 then P2 (sharded: this rank's slices of both; X is the whole constant input)."""
+        return ops.spmm(At, self._mt_input(X, self.Mop))
 
     def forward(self, At=None, X=None, edges=None):
         if _is_recompute_call(At, X, edges):
-            AtXt = self.compute_AtXt(_adj(At, self.N, self.dev), _feat(X, self.dev))
-            eidx = _EdgeIndex(edges, self.N, self.dev, T=self.T)
+            AtXt = self.compute_AtXt(_adj(self._own(At), self.N, self.dev), _feat(X, self.dev))
+            eidx = self._edge_index(edges, self.dev)
         else:
             AtXt, eidx = self.AtXt, self._edges
-        W1, W2, U = _w(self.W1), _w(self.W2), _w(self.U)
+        ps = not self.condensed_W
+        W1, W2, U = self._p(self.W1, ps), self._p(self.W2, ps), self._p(self.U)
         # first layer (ehf:330-335)
         if self.use_Minv:
-            Y = ops.activation(ops.m_transform(ops.feature_gemm(AtXt, W1), self.Minv), self.nonlin2)
+            Y = ops.activation(self._mt(ops.feature_gemm(AtXt, W1), self.Minv), self.nonlin2)
         else:
             Y = ops.feature_gemm(AtXt, W1, act=self.nonlin2)
-        # second layer — always the training adjacency self.At (ehf:339, 343, 348)
+        # second layer — always the training adjacency self.At (ehf:339, 343, 348); sharded, the
+        # M / M⁻¹ products below are the only steps that exchange activations between ranks
         if self.use_Minv:
-            Z = ops.m_transform(ops.spmm_feature_gemm(self.At, ops.m_transform(Y, self.Mop), W2), self.Minv)
+            Z = self._mt(ops.spmm_feature_gemm(self.At, self._mt(Y, self.Mop), W2), self.Minv)
         elif self.apply_M_twice:
-            Z = ops.spmm_feature_gemm(self.At, ops.m_transform(Y, self.Mop), W2)
+            Z = ops.spmm_feature_gemm(self.At, self._mt(Y, self.Mop), W2)
             if self.apply_M_three_times:
-                Z = ops.m_transform(Z, self.Mop)                                   # ehf:346
+                Z = self._mt(Z, self.Mop)                                          # ehf:346
         else:
             Z = ops.spmm_feature_gemm(self.At, Y, W2)                              # ehf:348-349
-        return self._deliver(_edge_head(Z, eidx, U))
+        return self._deliver(self._head(Z, eidx, U))
 
 
-class EmbeddingKWGCN(_Deliver, nn.Module):
-    """Baseline GCN without the M-product, 1 or 2 layers (ehf:425-497)."""
+class EmbeddingKWGCN(_Deliver, _Sharding, nn.Module):
+    """Baseline GCN without the M-product, 1 or 2 layers (ehf:425-497).  ``group``: slice-shard the
+    model over a process group (_Sharding) — no M, so no activation exchange in any configuration."""
 
     def __init__(self, A: AdjLike, X: torch.Tensor, edges: torch.Tensor, hidden_feat=[2, 2],
-                 nonlin2="relu", device=None, param_dtype=torch.float32):
+                 nonlin2="relu", device=None, param_dtype=torch.float32, group=None):
         super().__init__()
         dev = torch.device(device) if device is not None else _default_device()
         if nonlin2 not in _NONLIN:
@@ -244,40 +314,52 @@ class EmbeddingKWGCN(_Deliver, nn.Module):
         self.no_layers = len(hidden_feat) - 1
         self.nonlin2 = nonlin2
         self.T, self.N = int(X.shape[0]), int(X.shape[1])
+        self._init_shard(group)
         self.F = [int(X.shape[-1])] + list(hidden_feat)
         if self.no_layers == 2:
             self.W2 = _param(torch.randn(self.F[1], self.F[2]), dev, param_dtype)     # ehf:452 (drawn first)
         self.W1 = _param(torch.randn(self.F[0], self.F[1]), dev, param_dtype)         # ehf:453
         self.U = _param(torch.randn(self.F[-2] * 2, self.F[-1]), dev, param_dtype)    # ehf:454
-        self.A = _adj(A, self.N, dev)
-        if self.A.T != self.T:
-            raise RuntimeError(f"adjacency has {self.A.T} slices but X has T={self.T}")
-        self._edges = _EdgeIndex(edges, self.N, dev, T=self.T)
-        self.AX = self.compute_AX(self.A, _feat(X, dev))                           # ehf:464
+        n_slices = A.T if isinstance(A, BatchedCSR) else len(A)
+        if n_slices != self.T:
+            raise RuntimeError(f"adjacency has {n_slices} slices but X has T={self.T}")
+        self.A = _adj(self._own(A), self.N, dev)
+        self._edges = self._edge_index(edges, dev)
+        self.AX = self.compute_AX(self.A, self._own(_feat(X, dev)))                # ehf:464
         self.dev = dev
 
     def compute_AX(self, A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
         """ehf:469-473 — a [self.T, N, F] buffer whose first len(A) slices are Â_k·X_k and whose
         remaining slices stay zero: the baseline scripts validate on fewer slices than they train
         on (25 vs 150), and layer 2 then runs over all T slices of the training adjacency."""
-        if A.T > self.T:
+        T_mine = self.T if self._shard is None else self._shard.Tl      # A and X are this rank's slices already
+        if A.T > T_mine:
             raise RuntimeError(f"adjacency has {A.T} slices but the model was built for T={self.T} (ehf:470-472)")
         if X.shape[0] < A.T:
             raise RuntimeError(f"X has {X.shape[0]} slices but the adjacency has {A.T}")
+        if A.T == 0:
+            return X.new_zeros(T_mine, self.N, X.shape[-1])
         AX = ops.spmm(A, X if X.shape[0] == A.T else X[:A.T].contiguous())
-        if A.T < self.T:
-            AX = torch.cat((AX, AX.new_zeros(self.T - A.T, self.N, AX.shape[-1])), dim=0)
+        if A.T < T_mine:
+            AX = torch.cat((AX, AX.new_zeros(T_mine - A.T, self.N, AX.shape[-1])), dim=0)
         return AX
 
     def forward(self, A=None, X=None, edges=None):
         if _is_recompute_call(A, X, edges):
-            AX = self.compute_AX(_adj(A, self.N, self.dev), _feat(X, self.dev))
-            eidx = _EdgeIndex(edges, self.N, self.dev, T=self.T)
+            n_call = A.T if isinstance(A, BatchedCSR) else len(A)
+            if n_call > self.T:
+                raise RuntimeError(f"adjacency has {n_call} slices but the model was built for T={self.T} (ehf:470-472)")
+            A_mine = self._own(A)
+            A_csr = _adj(A_mine, self.N, self.dev) if (A_mine.T if isinstance(A_mine, BatchedCSR) else len(A_mine)) else \
+                BatchedCSR(torch.zeros(1, dtype=torch.int64, device=self.dev), torch.zeros(0, dtype=torch.int32, device=self.dev),
+                           torch.zeros(0, dtype=torch.float32, device=self.dev), 0, self.N)
+            AX = self.compute_AX(A_csr, self._own(_feat(X, self.dev)))
+            eidx = self._edge_index(edges, self.dev)
         else:
             AX, eidx = self.AX, self._edges
         if self.no_layers == 2:
-            Y = ops.feature_gemm(AX, _w(self.W1), act=self.nonlin2)                # ehf:486
-            Z = ops.spmm_feature_gemm(self.A, Y, _w(self.W2))                      # ehf:487
+            Y = ops.feature_gemm(AX, self._p(self.W1), act=self.nonlin2)           # ehf:486
+            Z = ops.spmm_feature_gemm(self.A, Y, self._p(self.W2))                 # ehf:487
         else:
-            Z = ops.feature_gemm(AX, _w(self.W1))                                  # ehf:489
-        return self._deliver(_edge_head(Z, eidx, _w(self.U)))
+            Z = ops.feature_gemm(AX, self._p(self.W1))                             # ehf:489
+        return self._deliver(self._head(Z, eidx, self._p(self.U)))
