@@ -50,6 +50,13 @@ enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SE
 int tmgcn_abi_version(void);
 const char* tmgcn_last_error(void);
 
+/* algorithm of tmgcn_gemm_f32 (instruction choice only; both fp32-accurate and reproducible) */
+enum {
+  TMGCN_GEMM_AUTO = 0,    /* bf16 matrix cores after an exact 3-way split of the fp32 operands where the shapes
+                             allow (K a multiple of 4 in [16, 128], 16-byte aligned A), else exact f32 */
+  TMGCN_GEMM_F32MFMA = 1  /* always the exact-f32 MFMA kernel: bitwise an fmaf chain in k order */
+};
+
 /* algorithm of tmgcn_gemm_dw_f32 (performance / instruction choice only; both are fp32-accurate,
  * atomic-free and bitwise reproducible) */
 enum {
@@ -128,10 +135,11 @@ int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* 
  *   (one shared weight, ehf:189); rows_per_batch = N gives one weight per slice (ehf:191).
  *   trans_w=1 is the backward  dA = dY · Wᵀ.
  *   pre_act (optional, may be NULL): when act != NONE also store the pre-activation sum.
+ *   algo: TMGCN_GEMM_AUTO / TMGCN_GEMM_F32MFMA (per call).
  */
 int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* pre_act,
                    int64_t R, int32_t K, int32_t Nf, int32_t trans_w,
-                   int64_t rows_per_batch, int64_t w_batch_stride, int32_t act, void* stream);
+                   int64_t rows_per_batch, int64_t w_batch_stride, int32_t act, int32_t algo, void* stream);
 
 /* Backward of P3 with respect to the weight (autograd of ehf:222 etc.):
  *   dW_b[k][n] = sum_{r in batch b} A[r][k] * dY[r][n]

@@ -184,7 +184,7 @@ int main(void) {
   /* forward */
   ABI(tmgcn_mtransform_f32(dM, T, T, 0, 0, 0, T, T, BAND - 1, 0, dX_in, dXt, (int64_t)N * F, 0, 0, st));
   ABI(tmgcn_spmm_csr_batched_f32(d_rowptr, d_col, d_val, dXt, dAX, R, N, F, st));
-  ABI(tmgcn_gemm_f32(dAX, dWt, dYo, NULL, R, F, NF, 0, 0, 0, TMGCN_ACT_NONE, st));
+  ABI(tmgcn_gemm_f32(dAX, dWt, dYo, NULL, R, F, NF, 0, 0, 0, TMGCN_ACT_NONE, TMGCN_GEMM_AUTO, st));
   if (!tmgcn_spmm_gemm_supported(F, NF)) {
     fprintf(stderr, "fused kernel should support K=%d Nf=%d\n", F, NF);
     return 1;
@@ -192,7 +192,7 @@ int main(void) {
   ABI(tmgcn_spmm_gemm_f32(d_rowptr, d_col, d_val, dXt, R, N, F, dWt, NF, 0, 0, 0, TMGCN_ACT_NONE, dYf, dAXf, NULL, 0, st));
   /* backward */
   ABI(tmgcn_gemm_dw_f32(dAX, d_dY, d_dW, R, F, NF, 0, TMGCN_DW_AUTO, ws, ws_bytes, st));
-  ABI(tmgcn_gemm_f32(d_dY, dWt, d_dA, NULL, R, NF, F, 1, 0, 0, TMGCN_ACT_NONE, st));
+  ABI(tmgcn_gemm_f32(d_dY, dWt, d_dA, NULL, R, NF, F, 1, 0, 0, TMGCN_ACT_NONE, TMGCN_GEMM_AUTO, st));
   ABI(tmgcn_spmm_csr_batched_f32(d_trowptr, d_tcol, d_tval, d_dA, d_dXt, R, N, F, st));
   ABI(tmgcn_mtransform_f32(dM, T, T, 1, 0, 0, T, T, 0, BAND - 1, d_dXt, d_dX, (int64_t)N * F, 0, 0, st));
   /* the backward pair as ONE fused launch: A^T (dY W^T) = (A^T dY) W^T */

@@ -190,7 +190,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                    'int main(void) {\n'
                    '  if (tmgcn_abi_version() != 2) return 1;\n'
                    '  if (tmgcn_spmm_gemm_supported(128, 128) != 1) return 2;\n'
-                   '  if (tmgcn_gemm_f32(0, 0, 0, 0, 10, 0, 4, 0, 0, 0, 0, 0) != TMGCN_ERR_INVALID) return 3;\n'
+                   '  if (tmgcn_gemm_f32(0, 0, 0, 0, 10, 0, 4, 0, 0, 0, 0, 0, 0) != TMGCN_ERR_INVALID) return 3;\n'
                    '  printf("%s\\n", tmgcn_last_error());\n  return 0;\n}\n')
     exe = tmp_path / "abi"
     lib_dir = os.path.dirname(_lib.LIB_PATH)

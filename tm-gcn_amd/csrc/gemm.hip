@@ -3,7 +3,9 @@
 // Replaces  t.matmul(AtXt, Wt)  (embedding_help_functions.py:222, 330, 340, 344, 349, 415,
 // 486-489) and autograd's  dA = dY·Wᵀ,  dW = Σ_r A[r]ᵀ dY[r].
 //
-//   gemm_mfma      Y[R][Nf] = act(A[R][K] · Wop): exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//   gemm_bf16x3    Y[R][Nf] = act(A[R][K] · Wop) on the bf16 matrix cores after an exact 3-way split of
+//                  the fp32 operands (fp32-accurate; the default for K a multiple of 4 in [16, 128]).
+//   gemm_mfma      the same product as exact-f32 MFMA (v_mfma_f32_32x32x2_f32): every other shape, and on request.
 //                  A 64-row tile is staged through LDS with full-line loads; each wave
 //                  keeps its 32-column strip of W in registers (B fragments) for the whole
 //                  persistent loop, so W is read once per block.  The k index inside a
@@ -150,6 +152,209 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
       }
     }
     __syncthreads();  // everyone has read s_tile and the LDS tile before the next draw
+  }
+}
+
+// ---- P3 on the bf16 matrix cores at fp32 accuracy ---------------------------------------------
+// Y = act(A·Wop) with every fp32 operand split exactly into three bf16 planes (x = hi + mid + lo,
+// split3 below) and the six plane products that matter per term, as in gemm_dw_bf16x3: 6 bf16 MFMAs
+// (32 cycles each) do the work of 8 f32 MFMAs (64 cycles each), which moves the F = 128 GEMM from
+// MFMA-bound (0.45 of the f32 peak in the kernel above) to its 2·R·128·4 B stream.
+//   tile = 64 rows.  Thread (row group t>>5, quad t&31) loads rows (t>>5)+8i, i = 0..7, as coalesced
+//   float4s (4 consecutive k), splits them and writes 8 bytes per plane into the LDS image
+//   [plane][row: 272 B][k: 2 B]; the 16-byte row pad makes the ds_read_b128 A-fragment reads
+//   (lane = row, 8 consecutive k) conflict-free.  The wave's 32-column strip of Wop lives in
+//   registers as pre-split B fragments (8 k-steps x 3 planes x 4 VGPRs) for the whole persistent
+//   loop.  The next tile's rows are requested before this tile's MFMAs (register staging), tiles
+//   are drawn from the device counter one ahead.  The reduction is over K <= 128 only (48 MFMA
+//   accumulations per output): the truncating bf16-MFMA accumulator (see X3_FLUSH) costs < 0.1 ulp here.
+typedef __bf16 gx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gx_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned gx_pack(float a, float b) {  // bf16(a) | bf16(b) << 16, RNE
+  gx_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gx_bf16x2));
+}
+__device__ __forceinline__ void gx_split3(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  h = gx_pack(a, b);
+  a -= __uint_as_float(h << 16);
+  b -= __uint_as_float(h & 0xffff0000u);
+  m = gx_pack(a, b);
+  a -= __uint_as_float(m << 16);
+  b -= __uint_as_float(m & 0xffff0000u);
+  l = gx_pack(a, b);
+}
+
+constexpr int GX_PITCH = 272;             // bytes per row of a plane image: 128 k x 2 B + 16 pad
+constexpr int GX_PLANE = BM * GX_PITCH;   // 64 rows
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[3 * GX_PLANE];
+  __shared__ unsigned int s_tile[2];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int n0 = blockIdx.y * 128 + wave * 32;  // this wave's column strip
+  const bool strip = n0 < a.Nf;
+  const int64_t batch_rows = a.rows_per_batch ? a.rows_per_batch : a.R;
+  const int nks = (a.K + 15) / 16;  // k-steps of 16
+
+  // staging role: quad q (k = 4q .. 4q+3) of rows rg + 8 i
+  const int q = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const bool okq = 4 * q < a.K;             // K % 4 == 0: a quad is inside or outside as a whole
+  const float zq = okq ? 1.f : 0.f;
+  const int qcol = okq ? 4 * q : 0;         // outside quads read column 0 (a valid address) and are zeroed
+  unsigned char* wr = sm + rg * GX_PITCH + q * 8;
+  const unsigned char* rd = sm + li * GX_PITCH + lh * 16;
+
+  unsigned bw[8][3][4];  // B fragments of Wop: [k-step][plane][8 bf16]
+  // Wop[k][n] = W[k*sk + n*sn]; this lane's column n0+li, clamped (columns / rows outside are zeroed by
+  // the mask, so the 64 loads are unconditional: no exec-mask branches)
+  const int ncol = n0 + li < a.Nf ? n0 + li : a.Nf - 1;
+  const int sk = a.trans_w ? 1 : a.Nf, sn = a.trans_w ? a.K : 1;
+  const float zn = n0 + li < a.Nf ? 1.f : 0.f;
+  auto load_w = [&](const float* Wb) {
+    int koff = 8 * lh;
+    // opaque to the optimiser: otherwise the 64 loop-invariant element offsets are hoisted out of
+    // the tile loop into 64 VGPRs (and spilled) for a routine that runs once per weight
+    asm volatile("" : "+v"(koff));
+    const float* wl = Wb + (int64_t)ncol * sn;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = koff + 16 * ks + 2 * j;
+        const int k0c = k < a.K ? k : a.K - 1, k1c = k + 1 < a.K ? k + 1 : a.K - 1;
+        const float w0 = wl[(int64_t)k0c * sk] * (k < a.K ? zn : 0.f);
+        const float w1 = wl[(int64_t)k1c * sk] * (k + 1 < a.K ? zn : 0.f);
+        gx_split3(w0, w1, bw[ks][0][j], bw[ks][1][j], bw[ks][2][j]);
+      }
+  };
+
+  float4 st[8];
+  struct TileRows {
+    int64_t row0, row_end, batch;
+  };
+  auto tile_rows = [&](unsigned tile) {  // tile ids fit 31 bits (checked by the launcher): 32-bit scalar arithmetic
+    const unsigned tpb = (unsigned)a.tiles_per_batch;
+    const unsigned b = tile / tpb;
+    TileRows t;
+    t.batch = b;
+    t.row0 = (int64_t)b * batch_rows + (int64_t)(tile - b * tpb) * BM;
+    t.row_end = (int64_t)(b + 1) * batch_rows;
+    if (t.row_end > a.R) t.row_end = a.R;
+    return t;
+  };
+  auto fetch = [&](const TileRows& t) {  // no conditional load: rows past the end re-read the last row and are zeroed at the split
+    const float* base = a.A + qcol;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int64_t r = t.row0 + rg + 8 * i;
+      if (r >= t.row_end) r = t.row_end - 1;
+      st[i] = *reinterpret_cast<const float4*>(base + r * a.K);
+    }
+  };
+  auto split_store = [&](const TileRows& t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float z = (t.row0 + rg + 8 * i < t.row_end) ? zq : 0.f;
+      unsigned h0, m0, l0, h1, m1, l1;
+      gx_split3(st[i].x * z, st[i].y * z, h0, m0, l0);
+      gx_split3(st[i].z * z, st[i].w * z, h1, m1, l1);
+      unsigned char* w = wr + i * 8 * GX_PITCH;
+      *reinterpret_cast<uint2*>(w) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(w + GX_PLANE) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(w + 2 * GX_PLANE) = make_uint2(l0, l1);
+    }
+  };
+
+  if (threadIdx.x == 0) s_tile[0] = atomicAdd(a.tile_counter + blockIdx.y, 1u);
+  __syncthreads();
+  unsigned cur = s_tile[0];
+  int64_t cur_batch = -1;
+  int par = 1;
+  const unsigned n_tiles = (unsigned)a.n_tiles;
+  TileRows tc = tile_rows(cur < n_tiles ? cur : 0);
+  if (cur < n_tiles) fetch(tc);
+  while (cur < n_tiles) {
+    if (threadIdx.x == 0) s_tile[par] = atomicAdd(a.tile_counter + blockIdx.y, 1u);
+    __syncthreads();  // the previous tile's fragment reads are done; the next draw is visible
+    split_store(tc);
+    const unsigned nxt = s_tile[par];
+    par ^= 1;
+    const TileRows tn = tile_rows(nxt < n_tiles ? nxt : 0);
+    if (nxt < n_tiles) fetch(tn);  // in flight during this tile's MFMAs and stores
+    __syncthreads();
+
+    if (tc.batch != cur_batch) {
+      load_w(a.W + (a.rows_per_batch ? tc.batch * a.w_batch_stride : 0));
+      cur_batch = tc.batch;
+    }
+    if (strip) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks < nks) {
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            const unsigned char* p = rd + mb * 32 * GX_PITCH + ks * 32;
+            const gx_bf16x8 ah = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p));
+            const gx_bf16x8 am = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + GX_PLANE));
+            const gx_bf16x8 al = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + 2 * GX_PLANE));
+            const gx_bf16x8 bh = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
+            const gx_bf16x8 bm = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
+            const gx_bf16x8 bl = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][2][0], bw[ks][2][1], bw[ks][2][2], bw[ks][2][3]));
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);  // small terms first
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mb], 0, 0, 0);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+          }
+        }
+      }
+      // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5).
+      // One 64-bit base per wave-lane and 32-bit row offsets (32 x 2 address pairs would not fit
+      // beside the B strip); whole tiles take the branch-free path.
+      const int n = n0 + li;
+      if (n < a.Nf) {
+        const int64_t base = (tc.row0 + 4 * lh) * a.Nf + n;
+        float* yb = a.Y + base;
+        float* pb = a.pre ? a.pre + base : nullptr;
+        const int rows_left = (int)((tc.row_end - tc.row0 - 4 * lh) < 64 ? (tc.row_end - tc.row0 - 4 * lh) : 64);
+        if (tc.row0 + BM <= tc.row_end) {
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int off = (mb * 32 + (i & 3) + 8 * (i >> 2)) * a.Nf;
+              const float sv = acc[mb][i];
+              if (pb) pb[off] = sv;
+              yb[off] = act_apply(sv, a.act);
+            }
+        } else {
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int rr = mb * 32 + (i & 3) + 8 * (i >> 2);
+              if (rr < rows_left) {
+                const float sv = acc[mb][i];
+                if (pb) pb[rr * a.Nf] = sv;
+                yb[rr * a.Nf] = act_apply(sv, a.act);
+              }
+            }
+        }
+      }
+    }
+    cur = nxt;
+    tc = tn;
   }
 }
 
@@ -367,7 +572,18 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& h, unsigned& 
 #define X3_DEPTH 1
 #endif
 #ifndef X3_OCC
-#define X3_OCC 3
+#define X3_OCC 2
+#endif
+// v_mfma_f32_32x32x16_bf16 does not round its accumulation to nearest: the sum of the 16 products and
+// the C input is TRUNCATED toward -infinity a few (~9-10) bits below the ulp of the largest addend
+// (measured, tools/dw_bias.py: mean signed error of all 128x128 outputs < 0 for every operand
+// distribution, growing like R·ulp(|acc|), while the f32 MFMA — an RNE fmaf chain — shows none).
+// At the bench size (R = 33.5 M rows, 21.8 k rows per block) that bias reached 1.2e-5 of max|dW|,
+// above the stated 1e-5 tolerance.  So the MFMA accumulator is kept SMALL: every X3_FLUSH steps
+// (X3_FLUSH*32 rows) it is added into a second register set with v_add_f32 (round to nearest even)
+// and cleared; the truncation then happens at ulp(|acc| <~ 8) instead of ulp(~100).
+#ifndef X3_FLUSH
+#define X3_FLUSH 4
 #endif
 constexpr int X3_ROWS = 32;
 constexpr int X3_PITCH = 272;             // bytes per feature quad (4 x 64 + 16)
@@ -433,11 +649,22 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
     pb += (int64_t)X3_ROWS * a.Nf;
   };
 
-  f32x16 acc[4];
+  f32x16 acc[4], sum[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[t][i] = sum[t][i] = 0.f;
+  int since_flush = 0;
+  auto flush = [&]() {  // RNE add of the short MFMA chain into the running sum (see X3_FLUSH)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sum[t][i] += acc[t][i];
+        acc[t][i] = 0.f;
+      }
+    since_flush = 0;
+  };
 
   unsigned char* wrA = sm + fq * X3_PITCH + kg * 8;
   unsigned char* wrB = wrA + X3_OPERAND;
@@ -481,6 +708,7 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
       }
     }
+    if (++since_flush == X3_FLUSH) flush();
   };
 
   int64_t r = r0;
@@ -514,6 +742,7 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
     __syncthreads();
     multiply();
   }
+  flush();
   float* P = a.part + ((int64_t)blockIdx.x) * a.K * a.Nf;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -522,7 +751,7 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int kk = kbase + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-        if (kk < a.K) P[(int64_t)kk * a.Nf + n] = acc[t][i];
+        if (kk < a.K) P[(int64_t)kk * a.Nf + n] = sum[t][i];
       }
     }
   }
@@ -625,7 +854,7 @@ static void dw_plan(int64_t R, int64_t rows_per_batch, int64_t* n_batch, int* ch
   const int64_t br = rows_per_batch ? rows_per_batch : R;
   const int64_t nb = br ? (R + br - 1) / br : 1;
   int64_t c = (br + 511) / 512;  // >= 512 rows per chunk
-  int64_t cmax = 1536 / (nb > 0 ? nb : 1);  // two rounds of the 768 blocks (3 per CU) the bf16x3 kernel keeps resident
+  int64_t cmax = 1536 / (nb > 0 ? nb : 1);  // three rounds of the 512 blocks (2 per CU) the bf16x3 kernel keeps resident
   if (cmax < 1) cmax = 1;
   if (c > cmax) c = cmax;
   if (c < 1) c = 1;
@@ -644,8 +873,9 @@ using namespace tmgcn;
 
 extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* pre_act, int64_t R,
                                int32_t K, int32_t Nf, int32_t trans_w, int64_t rows_per_batch,
-                               int64_t w_batch_stride, int32_t act, void* stream) {
+                               int64_t w_batch_stride, int32_t act, int32_t algo, void* stream) {
   TMGCN_REQUIRE(R >= 0 && K > 0 && Nf > 0, "gemm: bad shape R=%lld K=%d Nf=%d", (long long)R, K, Nf);
+  TMGCN_REQUIRE(algo == TMGCN_GEMM_AUTO || algo == TMGCN_GEMM_F32MFMA, "gemm: unknown algo %d", algo);
   TMGCN_REQUIRE(rows_per_batch >= 0, "gemm: negative rows_per_batch");
   TMGCN_REQUIRE(act >= TMGCN_ACT_NONE && act <= TMGCN_ACT_SELU, "gemm: unknown activation %d", act);
   if (R == 0) return TMGCN_OK;
@@ -672,6 +902,14 @@ extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* p
   // gy consecutive counters of the pool (acquire zeroes one; take gy of them in a row)
   a.tile_counter = acquire_tile_counters(st, (int)gy);
   TMGCN_REQUIRE(a.tile_counter, "gemm: cannot set up the tile counters");
+  const bool x3 = algo == TMGCN_GEMM_AUTO && K % 4 == 0 && K >= 16 && K <= 128 &&
+                  reinterpret_cast<uintptr_t>(A) % 16 == 0;
+  if (x3) {
+    int64_t gx = persistent_grid(gemm_bf16x3_kernel, 256);
+    if (gx > a.n_tiles) gx = a.n_tiles;
+    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
+    return check_launch("gemm_bf16x3");
+  }
   int64_t gx = persistent_grid(gemm_mfma_kernel, 256);
   if (gx > a.n_tiles) gx = a.n_tiles;
   hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);

@@ -168,7 +168,8 @@ void spmm_gemm_out(const Tensor& rowptr, const Tensor& col, const Tensor& val, c
   spmm_gemm_launch(rowptr, col, val, X, N, W, trans_w, act, Y, ax, pr, grid_reserve);
 }
 
-std::tuple<Tensor, Tensor> bgemm(const Tensor& A, const Tensor& W, bool trans_w, int64_t act, bool want_pre) {
+std::tuple<Tensor, Tensor> bgemm(const Tensor& A, const Tensor& W, bool trans_w, int64_t act, bool want_pre,
+                                 int64_t algo) {
   want(A, "gemm A");
   want(W, "gemm W");
   TORCH_CHECK(A.dim() == 3, "gemm: A must be [T,N,K]");
@@ -179,7 +180,7 @@ std::tuple<Tensor, Tensor> bgemm(const Tensor& A, const Tensor& W, bool trans_w,
   Tensor pre = (want_pre && act != TMGCN_ACT_NONE) ? at::empty_like(Y) : Tensor();
   ok(tmgcn_gemm_f32((const float*)ptr(A), (const float*)ptr(W), (float*)ptr(Y), (float*)ptr(pre), T * N,
                     (int32_t)K, (int32_t)s.wn, trans_w ? 1 : 0, s.per_slice ? N : 0, s.stride, (int32_t)act,
-                    stream_of(A)),
+                    (int32_t)algo, stream_of(A)),
      "tmgcn_gemm_f32");
   return {Y, pre.defined() ? pre : none_like(A)};
 }
@@ -355,7 +356,7 @@ struct SpmmFn : public torch::autograd::Function<SpmmFn> {
 struct FeatureGemmFn : public torch::autograd::Function<FeatureGemmFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& A, const Tensor& W, int64_t act) {
     at::AutoDispatchBelowADInplaceOrView guard;
-    auto [Y, pre] = bgemm(A, W, false, act, act != TMGCN_ACT_NONE);
+    auto [Y, pre] = bgemm(A, W, false, act, act != TMGCN_ACT_NONE, TMGCN_GEMM_AUTO);
     ctx->saved_data["act"] = act;
     ctx->save_for_backward({A, W, pre});
     return Y;
@@ -368,7 +369,7 @@ struct FeatureGemmFn : public torch::autograd::Function<FeatureGemmFn> {
     Tensor dY = grads[0].contiguous();
     if (act != TMGCN_ACT_NONE) dY = act_bwd(pre, dY, act);
     Tensor dA, dW;
-    if (ctx->needs_input_grad(0)) dA = std::get<0>(bgemm(dY, W, true, TMGCN_ACT_NONE, false));
+    if (ctx->needs_input_grad(0)) dA = std::get<0>(bgemm(dY, W, true, TMGCN_ACT_NONE, false, TMGCN_GEMM_AUTO));
     if (ctx->needs_input_grad(1)) dW = bgemm_dW(A, dY, W.dim() == 3, TMGCN_DW_AUTO);
     return {dA, dW, Tensor()};
   }
@@ -406,7 +407,7 @@ struct SpmmFeatureGemmFn : public torch::autograd::Function<SpmmFeatureGemmFn> {
         dX = std::get<0>(spmm_gemm(sv[3], sv[4], sv[5], dY, N, W, true, TMGCN_ACT_NONE, false, false,
                                    ctx->saved_data["reserve"].toInt()));
       else  // the transposed widths have no fused kernel: dA = dY·Wᵀ, then Âᵀ·dA
-        dX = spmm_csr_batched(sv[3], sv[4], sv[5], std::get<0>(bgemm(dY, W, true, TMGCN_ACT_NONE, false)), N,
+        dX = spmm_csr_batched(sv[3], sv[4], sv[5], std::get<0>(bgemm(dY, W, true, TMGCN_ACT_NONE, false, TMGCN_GEMM_AUTO)), N,
                               ctx->saved_data["avg"].toDouble());
     }
     if (ctx->needs_input_grad(1)) dW = bgemm_dW(AX, dY, W.dim() == 3, TMGCN_DW_AUTO);
@@ -505,7 +506,7 @@ TORCH_LIBRARY(tmgcn, m) {
         "bool want_ax, bool want_pre, int grid_reserve) -> (Tensor, Tensor, Tensor)");
   m.def("spmm_gemm_out(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, Tensor W, bool trans_w, int act, "
         "Tensor(a!) Y, Tensor(b!)? AX, Tensor(c!)? pre, int grid_reserve) -> ()");
-  m.def("bgemm(Tensor A, Tensor W, bool trans_w, int act, bool want_pre) -> (Tensor, Tensor)");
+  m.def("bgemm(Tensor A, Tensor W, bool trans_w, int act, bool want_pre, int algo) -> (Tensor, Tensor)");
   m.def("bgemm_dW(Tensor A, Tensor dY, bool per_slice, int algo) -> Tensor");
   m.def("edge_head_fwd(Tensor Z2, Tensor src, Tensor dst, Tensor U) -> Tensor");
   m.def("edge_head_bwd(Tensor Z2, Tensor src, Tensor dst, Tensor U, Tensor dout, Tensor eptr, Tensor eidx, "

@@ -202,10 +202,12 @@ class HipKernels:
         return Y, (AX if AX.numel() else None), (pre if pre.numel() else None)
 
     # P3 ---------------------------------------------------------------------------------
-    def gemm(self, A: torch.Tensor, W: torch.Tensor, trans_w=False, act=None, want_pre=False):
-        """A [T,N,K] · W ([K,Nf] shared or [T,K,Nf] per slice; transposed if trans_w)."""
+    def gemm(self, A: torch.Tensor, W: torch.Tensor, trans_w=False, act=None, want_pre=False, algo=None):
+        """A [T,N,K] · W ([K,Nf] shared or [T,K,Nf] per slice; transposed if trans_w).
+        algo: None / "auto" (bf16x3 split on the bf16 matrix cores for K a multiple of 4 in [16,128])
+        or "f32mfma" (exact-f32 MFMA: bitwise an fmaf chain) — per call."""
         Y, pre = self._run("gemm_dA" if trans_w else "gemm", A.device, lambda: self.ops.bgemm(
-            A, W, bool(trans_w), _lib.ACT_IDS[act], bool(want_pre)))
+            A, W, bool(trans_w), _lib.ACT_IDS[act], bool(want_pre), _lib.GEMM_ALGOS[algo]))
         return (Y, pre if pre.numel() else None) if want_pre else Y
 
     def gemm_dw(self, A: torch.Tensor, dY: torch.Tensor, per_slice: bool, algo=None) -> torch.Tensor:

@@ -15,13 +15,14 @@ p, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
 
 def load(path):
     lib = C.CDLL(path)
-    lib.tmgcn_gemm_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i64, i64, i32, p]
+    lib.tmgcn_gemm_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i64, i64, i32, i32, p]
     lib.tmgcn_gemm_dw_f32.argtypes = [p, p, p, i64, i32, i32, i64, i32, p, i64, p]
     lib.tmgcn_gemm_dw_workspace_bytes.restype = i64
     lib.tmgcn_gemm_dw_workspace_bytes.argtypes = [i64, i32, i32, i64]
     return lib
 
 
+ALGO = int(os.environ.get("TMGCN_AB_GEMM_ALGO", "0"))   # 0 = auto (bf16x3), 1 = exact-f32 MFMA
 names = sys.argv[1:] or sorted(os.path.basename(os.path.dirname(f)) for f in glob.glob(root + "/build/variants/*/libtmgcn_hip.so"))
 libs = {"default": load(root + "/tm-gcn_amd/libtmgcn_hip.so")}
 for n in names:
@@ -39,9 +40,9 @@ ptr = lambda t: C.c_void_p(t.data_ptr())
 
 def run(lib, which):
     if which == "gemm":
-        return lib.tmgcn_gemm_f32(ptr(A), ptr(W), ptr(Y), None, R, K, Nf, 0, 0, 0, 0, st)
+        return lib.tmgcn_gemm_f32(ptr(A), ptr(W), ptr(Y), None, R, K, Nf, 0, 0, 0, 0, ALGO, st)
     if which == "gemm_dA":
-        return lib.tmgcn_gemm_f32(ptr(dY), ptr(W), ptr(Y), None, R, Nf, K, 1, 0, 0, 0, st)
+        return lib.tmgcn_gemm_f32(ptr(dY), ptr(W), ptr(Y), None, R, Nf, K, 1, 0, 0, 0, ALGO, st)
     return lib.tmgcn_gemm_dw_f32(ptr(A), ptr(dY), ptr(dW), R, K, Nf, 0, 0, ptr(ws), ws.numel(), st)
 
 
