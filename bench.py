@@ -329,17 +329,19 @@ def epochs_block(args, configs=("S1", "S2", "S3"), modes=("eager", "graph", "fus
             first, sec = gpu_epochs(g, spec, args.epoch_reps, mode)
             rec[f"gpu_ms_{mode}"] = round(sec * 1e3, 4)
             loss_gpu = first if loss_gpu is None else loss_gpu
-        cpu = {}
-        loss_cpu = None
-        for th in sorted({min(8, ncpu), min(32, ncpu)}):   # all 256 threads is pathological on these small ops
-            loss_cpu, cpu[th] = cpu_epochs(g, spec, args.cpu_epoch_reps, th)
-        th_best = min(cpu, key=cpu.get)
-        rec.update({"cpu_ms": round(cpu[th_best] * 1e3, 2), "cpu_threads": th_best,
-                    "cpu_ms_by_threads": {str(k): round(v * 1e3, 2) for k, v in cpu.items()},
-                    "first_loss_gpu": loss_gpu, "first_loss_cpu": loss_cpu})
-        best = min(rec[f"gpu_ms_{m}"] for m in modes)
-        rec["speedup_script_mode"] = round(rec["cpu_ms"] / rec["gpu_ms_script"], 1) if "script" in modes else None
-        rec["speedup_best_mode"] = round(rec["cpu_ms"] / best, 1)
+        rec["first_loss_gpu"] = loss_gpu
+        if args.cpu_epoch_reps > 0:
+            cpu = {}
+            loss_cpu = None
+            for th in sorted({min(8, ncpu), min(32, ncpu)}):   # all 256 threads is pathological on these small ops
+                loss_cpu, cpu[th] = cpu_epochs(g, spec, args.cpu_epoch_reps, th)
+            th_best = min(cpu, key=cpu.get)
+            rec.update({"cpu_ms": round(cpu[th_best] * 1e3, 2), "cpu_threads": th_best,
+                        "cpu_ms_by_threads": {str(k): round(v * 1e3, 2) for k, v in cpu.items()},
+                        "first_loss_cpu": loss_cpu})
+            best = min(rec[f"gpu_ms_{m}"] for m in modes)
+            rec["speedup_script_mode"] = round(rec["cpu_ms"] / rec["gpu_ms_script"], 1) if "script" in modes else None
+            rec["speedup_best_mode"] = round(rec["cpu_ms"] / best, 1)
         out[name] = rec
         gc.collect()
     out["note"] = ("epoch = zero_grad, gcn(), class-weighted CE, backward, SGD step (experiment_reddit_our_link_prediction.py:75-81); "
@@ -500,26 +502,44 @@ def worker(args):
         # side by side.  The all-gather materialises [T,N,F] (forward) and again for the reduce-scatter
         # input (backward) on every GPU, so at S4 size it only fits for small G: the pair is always
         # measured at a reduced N, and at full N wherever it fits (decided collectively).
-        compare = {"reduced_n": {"nodes": min(N, args.compare_nodes)}}
+        def fits(ex, n_nodes):
+            """Collective decision: does one more layer in mode `ex` at n_nodes fit on every rank?
+            The all-gather materialises [T,N,F] forward and again as the reduce-scatter input."""
+            slab = Tl * n_nodes * F * 4
+            nnz_b = Tl * n_nodes * (args.deg + 1) * 8
+            need = ((2 * world + 8) if ex == "allgather" else 10) * slab + 2 * nnz_b + (2 << 30)
+            free_b, _total = torch.cuda.mem_get_info(dev)
+            if args.single_device:
+                free_b //= world                     # every rank of the emulation allocates on the same device
+            ok = torch.tensor([1 if free_b > 1.15 * need else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            return bool(int(ok.item())), need
+
+        n_cmp = min(N, args.compare_nodes)
+        compare = {"reduced_n": {"nodes": n_cmp}}
         for ex in ("a2a", "allgather"):
-            r = run_layer(args, dist, dev, rank, world, ex, min(N, args.compare_nodes), 3, 1, want_timer=False)
-            compare["reduced_n"][ex + "_ms_per_step"] = round(r["elapsed"] / 3 * 1e3, 3)
-            free_device_memory()
-        slab = Tl * N * F * 4
-        need = (2 * world + 8) * slab + 2 * res["nnz_rank"] * 8 + (2 << 30)
-        free_b, _total = torch.cuda.mem_get_info(dev)
-        ok = torch.tensor([1 if free_b > 1.1 * need else 0], device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            ok, need = fits(ex, n_cmp)
+            if ok:
+                r = run_layer(args, dist, dev, rank, world, ex, n_cmp, 3, 1, want_timer=False)
+                compare["reduced_n"][ex + "_ms_per_step"] = round(r["elapsed"] / 3 * 1e3, 3)
+                free_device_memory()
+            else:
+                compare["reduced_n"][ex + "_ms_per_step"] = None
+                compare["reduced_n"][ex + "_note"] = f"needs about {need / 1e9:.0f} GB per rank: does not fit here"
         other = "allgather" if args.exchange == "a2a" else "a2a"
+        ok, need = fits(other, N)
         compare["full_n"] = {"nodes": N, args.exchange + "_ms_per_step": round(res["elapsed"] / args.steps * 1e3, 3),
-                             "allgather_needs_gb_per_gpu": round(need / 1e9, 1)}
-        if int(ok.item()) or other == "a2a":
+                             other + "_needs_gb_per_gpu": round(need / 1e9, 1)}
+        if ok and N != n_cmp:
             r = run_layer(args, dist, dev, rank, world, other, N, 3, 1, want_timer=False)
             compare["full_n"][other + "_ms_per_step"] = round(r["elapsed"] / 3 * 1e3, 3)
             free_device_memory()
+        elif N == n_cmp:
+            compare["full_n"][other + "_ms_per_step"] = compare["reduced_n"].get(other + "_ms_per_step")
         else:
             compare["full_n"][other + "_ms_per_step"] = None
-            compare["full_n"]["note"] = "all-gather of [T,N,F] (+ its reduce-scatter input) does not fit beside the layer at this world size"
+            compare["full_n"]["note"] = ("all-gather of [T,N,F] (+ its reduce-scatter input) does not fit beside the layer "
+                                         "at this world size")
 
     out = None
     if rank == 0:

@@ -115,6 +115,52 @@ def test_mtransform_dense_and_inverse_roundtrip(T):
     assert_close(back, X, 1e-4, "band Minv∘M = I")
 
 
+@pytest.mark.parametrize("T,N,F,transpose", [(128, 301, 4, False), (128, 301, 4, True), (100, 77, 8, False),
+                                             (37, 1000, 4, True), (128, 16, 4, False), (17, 5, 4, False)])
+def test_mtransform_dense_bf16_split_kernel(T, N, F, transpose):
+    """Dense operators with T <= 128 run on the bf16 matrix cores after an exact 3-way split of both
+    operands: fp32 accuracy against the fp64 oracle on operands spanning six orders of magnitude,
+    tail column tiles (C not a multiple of 64), tail rows (T not a multiple of 16 / 32), Mᵀ, and
+    bit-reproducible."""
+    g = torch.Generator().manual_seed(T * 7 + N)
+    M = (torch.randn(T, T, generator=g, dtype=torch.float64) * torch.exp(torch.randn(T, 1, generator=g, dtype=torch.float64) * 2)).contiguous()
+    op = ops.MOperator(M, DEV)
+    assert op.band_lo + op.band_hi + 1 > 20                      # not the band kernel
+    X = (torch.randn(T, N, F, generator=g) * torch.exp(torch.randn(1, N, 1, generator=g) * 3)).contiguous()
+    Y = ops.kernels.mtransform(op, X.to(DEV), transpose=transpose)
+    ref = ref_mt(M, X, transpose)
+    # per-column scale: every column's error against that column's own magnitude
+    err = ((Y.cpu().double() - ref.double()).abs().amax(0) / ref.double().abs().amax(0).clamp_min(1e-30)).max()
+    assert float(err) <= REL_TOL, float(err)
+    assert torch.equal(Y, ops.kernels.mtransform(op, X.to(DEV), transpose=transpose))
+
+
+def test_mtransform_dense_bf16_split_windows_and_grouped_rows():
+    """The dense bf16-split kernel with operator windows (a rank's own output slices of the gathered
+    tensor, and the adjoint) and with the group-interleaved row storage of the all-to-all layouts."""
+    T, N, F, tl = 96, 50, 4, 8
+    g = torch.Generator().manual_seed(5)
+    M = (torch.randn(T, T, generator=g, dtype=torch.float64) / T ** 0.5 + torch.eye(T, dtype=torch.float64)).contiguous()
+    op = ops.MOperator(M, DEV)
+    X = torch.randn(T, N, F, generator=g)
+    full = ref_mt(M, X)
+    part = ops.kernels.mtransform(op, X.to(DEV), row_off=24, col_off=0, T_out=24)
+    assert_close(part, full[24:48], REL_TOL, "dense row window")
+    dY = torch.randn(24, N, F, generator=g)
+    pad = torch.zeros(T, N, F)
+    pad[24:48] = dY
+    dX = ops.kernels.mtransform(op, dY.to(DEV), transpose=True, row_off=0, col_off=24, T_out=T)
+    assert_close(dX, ref_mt(M, pad, True), REL_TOL, "dense adjoint window")
+    # group-interleaved storage: logical row k lives at (k % tl) * (T / tl) + k // tl
+    pos = torch.tensor([(k % tl) * (T // tl) + k // tl for k in range(T)])
+    Yg = ops.kernels.mtransform(op, X.to(DEV), y_group_rows=tl)
+    assert_close(Yg.cpu()[pos], full, REL_TOL, "dense, grouped output rows")
+    Xg = torch.empty_like(X)
+    Xg[pos] = X
+    Yx = ops.kernels.mtransform(op, Xg.to(DEV), x_group_rows=tl)
+    assert_close(Yx, full, REL_TOL, "dense, grouped input rows")
+
+
 def test_mtransform_windowed_rows():
     """row/col offsets: a rank computing only its own slices from the full X, and the adjoint."""
     T, N, F = 24, 40, 4

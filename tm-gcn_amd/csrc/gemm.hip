@@ -188,10 +188,47 @@ __device__ __forceinline__ void gx_split3(float a, float b, unsigned& h, unsigne
 
 constexpr int GX_PITCH = 272;             // bytes per row of a plane image: 128 k x 2 B + 16 pad
 constexpr int GX_PLANE = BM * GX_PITCH;   // 64 rows
+typedef float gx_f32x4 __attribute__((ext_vector_type(4)));
+
+struct GxTile {
+  int64_t row0;
+  int rows, batch;  // rows of the tile inside its batch (1..64)
+};
+
+// activation + stores of one 64-row tile.  C/D map of the 32x32 MFMA: col = lane&31,
+// row = (i&3) + 8*(i>>2) + 4*(lane>>5).  One 64-bit base per lane and 32-bit row offsets; whole
+// tiles take the branch-free path.
+template <int ACT>
+__device__ __forceinline__ void gx_store_rows(const f32x16 (&acc)[2], float* yb, float* pb, int Nf, int tile_rows,
+                                              int rows_left) {
+  if (tile_rows == BM) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int off = (mb * 32 + (i & 3) + 8 * (i >> 2)) * Nf;
+        const float sv = acc[mb][i];
+        if (pb) pb[off] = sv;
+        yb[off] = act_apply(sv, ACT);
+      }
+  } else {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rr = mb * 32 + (i & 3) + 8 * (i >> 2);
+        if (rr < rows_left) {
+          const float sv = acc[mb][i];
+          if (pb) pb[rr * Nf] = sv;
+          yb[rr * Nf] = act_apply(sv, ACT);
+        }
+      }
+  }
+}
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[3 * GX_PLANE];
-  __shared__ unsigned int s_tile[2];
+  __shared__ unsigned int s_tile[3];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 31;
@@ -233,33 +270,51 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
       }
   };
 
-  float4 st[8];
-  struct TileRows {
-    int64_t row0, row_end, batch;
-  };
+  // Two staging register sets, filled by inline-asm loads that the compiler's wait-count pass does
+  // not see: the rows of tile i+2 are requested as soon as tile i has been split and are waited for
+  // with a COUNTED s_waitcnt one tile later (vmcnt(8): everything but the 8 loads requested since),
+  // so ~2 x 32 KB per block stay in flight across the barriers.  With compiler-visible loads hipcc
+  // drains the queue (vmcnt(0)) at the first use after the branches of the epilogue, which degrades
+  // a two-deep ring to the one-deep one (measured in round 1 on the dW kernel).
+  gx_f32x4 sa[8], sb[8];
   auto tile_rows = [&](unsigned tile) {  // tile ids fit 31 bits (checked by the launcher): 32-bit scalar arithmetic
     const unsigned tpb = (unsigned)a.tiles_per_batch;
     const unsigned b = tile / tpb;
-    TileRows t;
-    t.batch = b;
+    GxTile t;
+    t.batch = (int)b;
     t.row0 = (int64_t)b * batch_rows + (int64_t)(tile - b * tpb) * BM;
-    t.row_end = (int64_t)(b + 1) * batch_rows;
-    if (t.row_end > a.R) t.row_end = a.R;
+    int64_t row_end = (int64_t)(b + 1) * batch_rows;
+    if (row_end > a.R) row_end = a.R;
+    const int64_t left = row_end - t.row0;
+    t.rows = left < BM ? (int)left : BM;
     return t;
   };
-  auto fetch = [&](const TileRows& t) {  // no conditional load: rows past the end re-read the last row and are zeroed at the split
-    const float* base = a.A + qcol;
+  // scalar base of the tile + a 32-bit per-lane offset: no 64-bit address pairs held in VGPRs.
+  // No conditional load: rows past the end re-read the tile's last row and are zeroed at the split.
+  auto fetch = [&](gx_f32x4 (&st)[8], const GxTile& t) {
+    const float* tbase = a.A + t.row0 * a.K;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      int64_t r = t.row0 + rg + 8 * i;
-      if (r >= t.row_end) r = t.row_end - 1;
-      st[i] = *reinterpret_cast<const float4*>(base + r * a.K);
+      int rr = rg + 8 * i;
+      if (rr >= t.rows) rr = t.rows - 1;
+      const unsigned voff = (unsigned)(rr * a.K + qcol) * 4u;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(st[i]) : "v"(voff), "s"(tbase) : "memory");
     }
   };
-  auto split_store = [&](const TileRows& t) {
+  // the set's loads have landed: counted wait, then pin every later use of the set behind it
+  auto landed = [&](gx_f32x4 (&st)[8], bool newer_in_flight) {
+    if (newer_in_flight)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(st[i]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto split_store = [&](const gx_f32x4 (&st)[8], const GxTile& t) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float z = (t.row0 + rg + 8 * i < t.row_end) ? zq : 0.f;
+      const float z = (rg + 8 * i < t.rows) ? zq : 0.f;
       unsigned h0, m0, l0, h1, m1, l1;
       gx_split3(st[i].x * z, st[i].y * z, h0, m0, l0);
       gx_split3(st[i].z * z, st[i].w * z, h1, m1, l1);
@@ -270,91 +325,120 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
     }
   };
 
-  if (threadIdx.x == 0) s_tile[0] = atomicAdd(a.tile_counter + blockIdx.y, 1u);
-  __syncthreads();
-  unsigned cur = s_tile[0];
-  int64_t cur_batch = -1;
-  int par = 1;
-  const unsigned n_tiles = (unsigned)a.n_tiles;
-  TileRows tc = tile_rows(cur < n_tiles ? cur : 0);
-  if (cur < n_tiles) fetch(tc);
-  while (cur < n_tiles) {
-    if (threadIdx.x == 0) s_tile[par] = atomicAdd(a.tile_counter + blockIdx.y, 1u);
-    __syncthreads();  // the previous tile's fragment reads are done; the next draw is visible
-    split_store(tc);
-    const unsigned nxt = s_tile[par];
-    par ^= 1;
-    const TileRows tn = tile_rows(nxt < n_tiles ? nxt : 0);
-    if (nxt < n_tiles) fetch(tn);  // in flight during this tile's MFMAs and stores
-    __syncthreads();
-
+  // the tile whose planes are in LDS: multiply() runs the MFMAs, store_tile() applies the activation
+  // and stores; the counted wait for the other staging set sits between the two
+  int cur_batch = -1;
+  f32x16 acc[2];
+  auto multiply = [&](const GxTile& tc) {
     if (tc.batch != cur_batch) {
-      load_w(a.W + (a.rows_per_batch ? tc.batch * a.w_batch_stride : 0));
+      load_w(a.W + (a.rows_per_batch ? (int64_t)tc.batch * a.w_batch_stride : 0));
       cur_batch = tc.batch;
     }
-    if (strip) {
-      f32x16 acc[2];
+    if (!strip) return;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        if (ks < nks) {
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks < nks) {
 #pragma unroll
-          for (int mb = 0; mb < 2; ++mb) {
-            const unsigned char* p = rd + mb * 32 * GX_PITCH + ks * 32;
-            const gx_bf16x8 ah = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p));
-            const gx_bf16x8 am = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + GX_PLANE));
-            const gx_bf16x8 al = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + 2 * GX_PLANE));
-            const gx_bf16x8 bh = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
-            const gx_bf16x8 bm = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
-            const gx_bf16x8 bl = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][2][0], bw[ks][2][1], bw[ks][2][2], bw[ks][2][3]));
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);  // small terms first
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
-          }
-        }
-      }
-      // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5).
-      // One 64-bit base per wave-lane and 32-bit row offsets (32 x 2 address pairs would not fit
-      // beside the B strip); whole tiles take the branch-free path.
-      const int n = n0 + li;
-      if (n < a.Nf) {
-        const int64_t base = (tc.row0 + 4 * lh) * a.Nf + n;
-        float* yb = a.Y + base;
-        float* pb = a.pre ? a.pre + base : nullptr;
-        const int rows_left = (int)((tc.row_end - tc.row0 - 4 * lh) < 64 ? (tc.row_end - tc.row0 - 4 * lh) : 64);
-        if (tc.row0 + BM <= tc.row_end) {
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const int off = (mb * 32 + (i & 3) + 8 * (i >> 2)) * a.Nf;
-              const float sv = acc[mb][i];
-              if (pb) pb[off] = sv;
-              yb[off] = act_apply(sv, a.act);
-            }
-        } else {
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const int rr = mb * 32 + (i & 3) + 8 * (i >> 2);
-              if (rr < rows_left) {
-                const float sv = acc[mb][i];
-                if (pb) pb[rr * a.Nf] = sv;
-                yb[rr * a.Nf] = act_apply(sv, a.act);
-              }
-            }
+        for (int mb = 0; mb < 2; ++mb) {
+          const unsigned char* p = rd + mb * 32 * GX_PITCH + ks * 32;
+          const gx_bf16x8 ah = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p));
+          const gx_bf16x8 am = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + GX_PLANE));
+          const gx_bf16x8 al = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + 2 * GX_PLANE));
+          const gx_bf16x8 bh = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
+          const gx_bf16x8 bm = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
+          const gx_bf16x8 bl = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][2][0], bw[ks][2][1], bw[ks][2][2], bw[ks][2][3]));
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);  // small terms first
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
         }
       }
     }
-    cur = nxt;
-    tc = tn;
+  };
+  auto store_tile = [&](const GxTile& tc) {
+    const int n = n0 + li;
+    if (!strip || n >= a.Nf) return;
+    const int64_t base = (tc.row0 + 4 * lh) * a.Nf + n;
+    float* yb = a.Y + base;
+    float* pb = a.pre ? a.pre + base : nullptr;
+    const int rows_left = tc.rows - 4 * lh;
+    switch (a.act) {  // chosen once per tile, not once per element
+      case TMGCN_ACT_RELU: gx_store_rows<TMGCN_ACT_RELU>(acc, yb, pb, a.Nf, tc.rows, rows_left); break;
+      case TMGCN_ACT_LEAKY: gx_store_rows<TMGCN_ACT_LEAKY>(acc, yb, pb, a.Nf, tc.rows, rows_left); break;
+      case TMGCN_ACT_SELU: gx_store_rows<TMGCN_ACT_SELU>(acc, yb, pb, a.Nf, tc.rows, rows_left); break;
+      default: gx_store_rows<TMGCN_ACT_NONE>(acc, yb, pb, a.Nf, tc.rows, rows_left);
+    }
+  };
+
+  // Tile ids are drawn three ahead (two in registers, one in flight): the returning atomic of
+  // thread 0 is an inline-asm operation OLDER than the 8 loads of its phase, so the same counted
+  // wait covers it; a compiler-visible atomic would be waited for with vmcnt(0).
+  const unsigned n_tiles = (unsigned)a.n_tiles;
+  unsigned int* ctr = a.tile_counter + blockIdx.y;
+  if (threadIdx.x == 0) {
+    s_tile[0] = atomicAdd(ctr, 1u);
+    s_tile[1] = atomicAdd(ctr, 1u);
+    s_tile[2] = atomicAdd(ctr, 1u);
+  }
+  __syncthreads();
+  unsigned t0 = s_tile[0], t1 = s_tile[1], t2 = s_tile[2];
+  __syncthreads();
+  GxTile ta = tile_rows(t0 < n_tiles ? t0 : 0), tb = tile_rows(t1 < n_tiles ? t1 : 0);
+  if (t0 < n_tiles) fetch(sa, ta);
+  if (t1 < n_tiles) fetch(sb, tb);
+  landed(sa, t1 < n_tiles);
+  unsigned drawn = 0;
+  const unsigned one = 1u, zero_off = 0u;
+  auto draw = [&]() {  // thread 0: request the id three tiles ahead (valid after the next counted wait)
+    if (threadIdx.x == 0)
+      asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(drawn) : "v"(zero_off), "v"(one), "s"(ctr) : "memory");
+  };
+  auto publish = [&](int slot) {  // after the counted wait: hand the drawn id to the block
+    if (threadIdx.x == 0) {
+      asm volatile("" : "+v"(drawn));
+      s_tile[slot] = drawn;
+    }
+  };
+  while (t0 < n_tiles) {
+    // ---- tile t0 (set a): split, request t2 into set a, multiply, wait for set b, store
+    __syncthreads();  // the previous tile's fragment reads are done
+    split_store(sa, ta);
+    draw();
+    const GxTile tc2 = tile_rows(t2 < n_tiles ? t2 : 0);
+    const bool f2 = t2 < n_tiles;
+    if (f2) fetch(sa, tc2);
+    __syncthreads();
+    multiply(ta);
+    landed(sb, f2);
+    publish(0);
+    store_tile(ta);
+    if (t1 >= n_tiles) break;
+    // ---- tile t1 (set b)
+    __syncthreads();  // also publishes s_tile[0]
+    const unsigned t3 = s_tile[0];
+    split_store(sb, tb);
+    draw();
+    const GxTile tc3 = tile_rows(t3 < n_tiles ? t3 : 0);
+    const bool f3 = t3 < n_tiles;
+    if (f3) fetch(sb, tc3);
+    __syncthreads();
+    multiply(tb);
+    landed(sa, f3);
+    publish(1);
+    store_tile(tb);
+    __syncthreads();  // publishes s_tile[1]
+    const unsigned t4 = s_tile[1];
+    t0 = t2;
+    ta = tc2;
+    t1 = t3;
+    tb = tc3;
+    t2 = t4;
   }
 }
 

@@ -12,7 +12,9 @@
 //                       upper-banded).  Each lane keeps a W-row sliding window of its four
 //                       columns in registers, so X is read once and Y written once:
 //                       8 B/element of HBM traffic, 2W flop/element -> HBM-bound.
-//   mtransform_dense    any operator (e.g. Minv): register-blocked 16 rows x float4 per lane.
+//   mtransform_bf16x3   any operator with T_in <= 128 (Minv, bands wider than 20): bf16 matrix cores after
+//                       an exact 3-way split of both operands (fp32-accurate), a stream over X and Y.
+//   mtransform_dense_mfma / mtransform_dense   exact-f32 MFMA (T_in <= 256) / register-blocked FMA fallbacks.
 #include "common.h"
 
 namespace tmgcn {
@@ -307,6 +309,252 @@ __global__ __launch_bounds__(256) void mtransform_dense_mfma_kernel(MtArgs a) {
   }
 }
 
+// ---- dense operators on the bf16 matrix cores at fp32 accuracy (T_in <= 128) -------------------
+// Minv (ehf:184, 224) and bands wider than 20 diagonals are dense T x T products against the
+// [T][C] tensor: 2·T²·C flops on 8·T·C bytes — at T = 128 that is MFMA-bound on the exact-f32
+// matrix instruction (kernel above).  Here both operands are split exactly into three bf16 planes
+// (x = hi + mid + lo) and the six plane products that matter are formed with
+// v_mfma_f32_32x32x16_bf16 (16x the f32 rate): the transform becomes a stream over X and Y.
+//   tile = 64 columns x all T_in rows.  Thread (column quad t&15, row group t>>4) loads two 4x4
+//   blocks (4 consecutive rows j x 4 consecutive columns: coalesced float4s along C), splits them and
+//   writes, per column, the 4 j-slots it owns as one 8-byte store: the transpose to "8 consecutive j
+//   per lane" (the MFMA B operand, lane = column) happens in the split pass.  LDS image
+//   [plane][j/32][column quad: 272 B][column: 64 B][j%32: 2 B] — the 16-byte pad per quad makes the
+//   ds_read_b128 fragment reads conflict-free.  Wave w owns output rows 32w..32w+31 of the block's
+//   128-row slab; its rows of Mop live in registers as pre-split A fragments, and j-steps outside
+//   the band of those rows are skipped (a triangular operator costs half the MFMAs).  Output
+//   D[k][c]: lane = column, so every store instruction writes two full 128-B row segments.
+//   Reduction length T_in <= 128: 48 MFMA accumulations per output, so the truncating bf16-MFMA
+//   accumulator (gemm.hip, X3_FLUSH) costs < 0.1 ulp here.
+typedef __bf16 mx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mx_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned mx_pack(float a, float b) {  // bf16(a) | bf16(b) << 16, RNE
+  mx_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mx_bf16x2));
+}
+__device__ __forceinline__ void mx_split3(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  h = mx_pack(a, b);
+  a -= __uint_as_float(h << 16);
+  b -= __uint_as_float(h & 0xffff0000u);
+  m = mx_pack(a, b);
+  a -= __uint_as_float(m << 16);
+  b -= __uint_as_float(m & 0xffff0000u);
+  l = mx_pack(a, b);
+}
+__device__ __forceinline__ float mx_comp(const float4& v, int c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+constexpr int MX_COLS = 64;
+constexpr int MX_QPITCH = 272;                        // bytes per column quad: 4 x 64 + 16
+constexpr int MX_JB = (MX_COLS / 4) * MX_QPITCH;      // one block of 32 rows j
+constexpr int MX_PLANE = 4 * MX_JB;                   // T_in <= 128
+
+__global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[3 * MX_PLANE];
+  __shared__ unsigned int s_tile[3];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int k0 = (blockIdx.y * 4 + wave) * 32;  // this wave's output rows
+  const bool wave_live = k0 < a.T_out;
+  const int d_lo = (a.row_off - a.col_off) - a.band_lo;
+  const int d_hi = (a.row_off - a.col_off) + a.band_hi;
+  // j-steps (16 rows each) that this wave's 32 output rows can touch
+  int j_lo = k0 + d_lo, j_hi = k0 + 31 + d_hi;
+  if (j_lo < 0) j_lo = 0;
+  if (j_hi > a.T_in - 1) j_hi = a.T_in - 1;
+  const int js_lo = j_lo / 16, js_hi = (wave_live && j_hi >= j_lo) ? j_hi / 16 + 1 : 0;
+
+  // A fragments: lane (row k0+li, j = 16 js + 8 lh + e), pre-split; zero outside the operator / the band
+  unsigned am[8][3][4];
+  {
+    const int k = k0 + li;
+    const int kc = k < a.T_out ? k : a.T_out - 1;
+#pragma unroll
+    for (int js = 0; js < 8; ++js)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = 16 * js + 8 * lh + 2 * e + u;
+          const int jc = j < a.T_in ? j : a.T_in - 1;
+          const bool in = k < a.T_out && j < a.T_in && j >= k + d_lo && j <= k + d_hi;
+          v[u] = mop(a, kc, jc) * (in ? 1.f : 0.f);
+        }
+        mx_split3(v[0], v[1], am[js][0][e], am[js][1][e], am[js][2][e]);
+      }
+  }
+
+  // staging role: column quad cq, row blocks 4(jg + 16 b) .. +3, b = 0, 1
+  const int cq = threadIdx.x & 15, jg = threadIdx.x >> 4;
+  unsigned char* wr0 = sm + (jg >> 3) * MX_JB + cq * MX_QPITCH + (jg & 7) * 8;  // block b adds 2 j-blocks
+  const unsigned char* rd = sm + (li >> 2) * MX_QPITCH + (li & 3) * 64 + lh * 16;
+
+  // Two staging register sets filled by inline-asm loads (invisible to the compiler's wait-count
+  // pass, which would otherwise drain the queue at the first use after the epilogue's branches):
+  // the columns of tile i+2 are requested as soon as tile i has been split and are waited for with a
+  // counted s_waitcnt one tile later (vmcnt(8): all but the 8 loads requested since) — ~2 x 32 KB
+  // per block stay in flight across the barriers.  Same scheme as gemm_bf16x3_kernel (gemm.hip).
+  typedef float mx_f32x4 __attribute__((ext_vector_type(4)));
+  mx_f32x4 sa[8], sb[8];
+  const int64_t last_quad = a.C - 4;  // C % 4 == 0 (checked by the launcher)
+  // Row positions are recomputed per tile from an opaque copy of jg: hoisted out of the tile loop
+  // they would pin 16 VGPRs of 64-bit offsets (plus 32 more for the stores below) beside the
+  // 96-VGPR operator strip.
+  auto fetch = [&](mx_f32x4 (&st)[8], unsigned tile) {  // no conditional load: columns past C re-read the last quad, rows past T_in the last row; zeroed at the split
+    int64_t c = (int64_t)tile * MX_COLS + 4 * cq;
+    if (c > last_quad) c = last_quad;
+    const float* base = a.X + c;
+    int jq = jg;
+    asm volatile("" : "+v"(jq));
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 4 * (jq + 16 * b) + i;
+        const float* ptr = base + row_pos(j < a.T_in ? j : a.T_in - 1, a.T_in, a.x_tl) * a.C;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st[4 * b + i]) : "v"(ptr) : "memory");
+      }
+  };
+  auto landed = [&](mx_f32x4 (&st)[8], bool newer_in_flight) {  // counted wait, then pin every later use of the set behind it
+    if (newer_in_flight)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(st[i]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto split_store = [&](const mx_f32x4 (&st)[8], unsigned tile) {
+    const float zc = ((int64_t)tile * MX_COLS + 4 * cq < a.C) ? 1.f : 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float z[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) z[i] = (4 * (jg + 16 * b) + i < a.T_in) ? zc : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        mx_split3(st[4 * b + 0][e] * z[0], st[4 * b + 1][e] * z[1], h0, m0, l0);
+        mx_split3(st[4 * b + 2][e] * z[2], st[4 * b + 3][e] * z[3], h1, m1, l1);
+        unsigned char* w = wr0 + b * 2 * MX_JB + e * 64;
+        *reinterpret_cast<uint2*>(w) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(w + MX_PLANE) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(w + 2 * MX_PLANE) = make_uint2(l0, l1);
+      }
+    }
+  };
+
+  f32x16 acc[2];
+  auto multiply = [&]() {
+    if (!wave_live) return;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+#pragma unroll
+    for (int js = 0; js < 8; ++js) {
+      if (js >= js_lo && js < js_hi) {
+        const mx_bf16x8 ah = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][0][0], am[js][0][1], am[js][0][2], am[js][0][3]));
+        const mx_bf16x8 amid = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][1][0], am[js][1][1], am[js][1][2], am[js][1][3]));
+        const mx_bf16x8 al = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][2][0], am[js][2][1], am[js][2][2], am[js][2][3]));
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const unsigned char* p = rd + (js >> 1) * MX_JB + cb * 8 * MX_QPITCH + (js & 1) * 32;
+          const mx_bf16x8 bh = __builtin_bit_cast(mx_bf16x8, *reinterpret_cast<const uint4*>(p));
+          const mx_bf16x8 bm = __builtin_bit_cast(mx_bf16x8, *reinterpret_cast<const uint4*>(p + MX_PLANE));
+          const mx_bf16x8 bl = __builtin_bit_cast(mx_bf16x8, *reinterpret_cast<const uint4*>(p + 2 * MX_PLANE));
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[cb], 0, 0, 0);  // small terms first
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid, bm, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid, bh, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[cb], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto store_tile = [&](unsigned tile) {  // D[k][c]: column = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+    if (!wave_live) return;
+    const int64_t c0 = (int64_t)tile * MX_COLS;
+    int kb = k0 + 4 * lh;
+    asm volatile("" : "+v"(kb));  // see fetch(): keep the 16 row offsets out of the loop-invariant set
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int64_t c = c0 + cb * 32 + li;
+      if (c < a.C) {
+        float* yc = a.Y + c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = kb + (i & 3) + 8 * (i >> 2);
+          if (k < a.T_out) yc[row_pos(k, a.T_out, a.y_tl) * a.C] = acc[cb][i];
+        }
+      }
+    }
+  };
+
+  // tile ids are drawn three ahead; thread 0's returning atomic is an inline-asm operation older than
+  // the 8 loads of its phase, so the same counted wait covers it (gemm.hip has the long version)
+  const unsigned n_tiles = (unsigned)((a.C + MX_COLS - 1) / MX_COLS);
+  unsigned int* ctr = a.tile_counter + blockIdx.y;
+  if (threadIdx.x == 0) {
+    s_tile[0] = atomicAdd(ctr, 1u);
+    s_tile[1] = atomicAdd(ctr, 1u);
+    s_tile[2] = atomicAdd(ctr, 1u);
+  }
+  __syncthreads();
+  unsigned t0 = s_tile[0], t1 = s_tile[1], t2 = s_tile[2];
+  __syncthreads();
+  if (t0 < n_tiles) fetch(sa, t0);
+  if (t1 < n_tiles) fetch(sb, t1);
+  landed(sa, t1 < n_tiles);
+  unsigned drawn = 0;
+  const unsigned one = 1u, zero_off = 0u;
+  auto draw = [&]() {
+    if (threadIdx.x == 0)
+      asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(drawn) : "v"(zero_off), "v"(one), "s"(ctr) : "memory");
+  };
+  auto publish = [&](int slot) {
+    if (threadIdx.x == 0) {
+      asm volatile("" : "+v"(drawn));
+      s_tile[slot] = drawn;
+    }
+  };
+  while (t0 < n_tiles) {
+    // ---- tile t0 (set a): split, request t2 into set a, multiply, wait for set b, store
+    __syncthreads();  // the previous tile's fragment reads are done
+    split_store(sa, t0);
+    draw();
+    const bool f2 = t2 < n_tiles;
+    if (f2) fetch(sa, t2);
+    __syncthreads();
+    multiply();
+    landed(sb, f2);
+    publish(0);
+    store_tile(t0);
+    if (t1 >= n_tiles) break;
+    // ---- tile t1 (set b)
+    __syncthreads();  // also publishes s_tile[0]
+    const unsigned t3 = s_tile[0];
+    split_store(sb, t1);
+    draw();
+    const bool f3 = t3 < n_tiles;
+    if (f3) fetch(sb, t3);
+    __syncthreads();
+    multiply();
+    landed(sa, f3);
+    publish(1);
+    store_tile(t1);
+    __syncthreads();  // publishes s_tile[1]
+    const unsigned t4 = s_tile[1];
+    t0 = t2;
+    t1 = t3;
+    t2 = t4;
+  }
+}
+
 template <int WIDTH, int VEC>
 static void launch_band(const MtArgs& a, dim3 grid, hipStream_t st) {
   constexpr int PF = 4;  // rows in flight per lane
@@ -345,7 +593,24 @@ static int dispatch(MtArgs a, hipStream_t st) {
     else launch_band<20, VEC>(a, grid, st);
     return check_launch("mtransform_band");
   }
-  if (a.T_in <= 256) {  // matrix-core path
+  if (a.T_in <= 128 && VEC == 4) {  // bf16 matrix cores, exact 3-way split (fp32-accurate): a stream over X and Y
+    const unsigned gy = (unsigned)((a.T_out + 127) / 128);
+    const int64_t n_tiles = (a.C + MX_COLS - 1) / MX_COLS;
+    if (gy > 64 || n_tiles >= (int64_t)0x7fffffff) {
+      set_error("mtransform: shape too large for the dense tile scheduler");
+      return TMGCN_ERR_INVALID;
+    }
+    a.tile_counter = acquire_tile_counters(st, (int)gy);
+    if (!a.tile_counter) {
+      set_error("mtransform: cannot set up the tile counters");
+      return TMGCN_ERR_LAUNCH;
+    }
+    int64_t gx = persistent_grid(mtransform_bf16x3_kernel, 256);
+    if (gx > n_tiles) gx = n_tiles;
+    hipLaunchKernelGGL(mtransform_bf16x3_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
+    return check_launch("mtransform_bf16x3");
+  }
+  if (a.T_in <= 256) {  // exact-f32 matrix-core path (129 <= T_in <= 256, or unaligned / C % 4 != 0)
     const size_t smem = (size_t)a.T_in * kDenseCols * sizeof(float);
     const unsigned gy = (unsigned)((a.T_out + 127) / 128);
     const int64_t n_tiles = (a.C + kDenseCols - 1) / kDenseCols;
