@@ -213,3 +213,15 @@ def test_edge_index_validation_on_the_host():
         with pytest.raises(IndexError):
             ops.EdgeIndex(torch.tensor(bad), 10, "cpu", T=2)
     ops.EdgeIndex(torch.zeros(3, 0, dtype=torch.int64), 10, "cpu", T=2)      # empty edge set is fine
+
+
+def test_reserved_register_zone_is_untouched_by_compiler_code():
+    """The stream kernels park in-flight global loads in fixed registers at the top of the register
+    file (csrc/async_stage.h).  That is only sound if no compiler-generated instruction uses that
+    zone: compile the kernels to gfx950 assembly and check every instruction outside inline asm."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_reserved_vgprs.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(": OK") == 2, r.stdout

@@ -20,7 +20,9 @@
 //                  block through LDS (full-line loads) and read back with conflict-free
 //                  ds_read_b32; row-chunk partial slabs are reduced in a fixed order by a
 //                  second kernel (no float atomics: reproducible).
+#include <type_traits>
 #include "common.h"
+#include "async_stage.h"
 
 namespace tmgcn {
 
@@ -228,7 +230,6 @@ __device__ __forceinline__ void gx_store_rows(const f32x16 (&acc)[2], float* yb,
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[3 * GX_PLANE];
-  __shared__ unsigned int s_tile[3];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 31;
@@ -270,13 +271,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
       }
   };
 
-  // Two staging register sets, filled by inline-asm loads that the compiler's wait-count pass does
-  // not see: the rows of tile i+2 are requested as soon as tile i has been split and are waited for
-  // with a COUNTED s_waitcnt one tile later (vmcnt(8): everything but the 8 loads requested since),
-  // so ~2 x 32 KB per block stay in flight across the barriers.  With compiler-visible loads hipcc
-  // drains the queue (vmcnt(0)) at the first use after the branches of the epilogue, which degrades
-  // a two-deep ring to the one-deep one (measured in round 1 on the dW kernel).
-  gx_f32x4 sa[8], sb[8];
+  // Two staging sets of 8 float4s in RESERVED registers (v192..v255, async_stage.h), filled by
+  // inline-asm loads that the compiler's wait-count pass does not see: the rows of tile i+2 are
+  // requested as soon as tile i has been split and are waited for with a COUNTED s_waitcnt one tile
+  // later (vmcnt(8): everything but the 8 loads requested since), so ~2 x 32 KB per block stay in
+  // flight across the barriers.  With compiler-visible loads hipcc drains the queue (vmcnt(0)) at
+  // the first use after the branches of the epilogue, which degrades a two-deep ring to a one-deep
+  // one (measured in round 1 on the dW kernel).
   auto tile_rows = [&](unsigned tile) {  // tile ids fit 31 bits (checked by the launcher): 32-bit scalar arithmetic
     const unsigned tpb = (unsigned)a.tiles_per_batch;
     const unsigned b = tile / tpb;
@@ -291,39 +292,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   };
   // scalar base of the tile + a 32-bit per-lane offset: no 64-bit address pairs held in VGPRs.
   // No conditional load: rows past the end re-read the tile's last row and are zeroed at the split.
-  auto fetch = [&](gx_f32x4 (&st)[8], const GxTile& t) {
+  auto fetch = [&](auto set, const GxTile& t) {
+    constexpr int SET = decltype(set)::value;
     const float* tbase = a.A + t.row0 * a.K;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    auto voff = [&](int i) {
       int rr = rg + 8 * i;
       if (rr >= t.rows) rr = t.rows - 1;
-      const unsigned voff = (unsigned)(rr * a.K + qcol) * 4u;
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(st[i]) : "v"(voff), "s"(tbase) : "memory");
-    }
+      return (unsigned)(rr * a.K + qcol) * 4u;
+    };
+    stage8_load_s<SET, 0>(voff(0), tbase);
+    stage8_load_s<SET, 1>(voff(1), tbase);
+    stage8_load_s<SET, 2>(voff(2), tbase);
+    stage8_load_s<SET, 3>(voff(3), tbase);
+    stage8_load_s<SET, 4>(voff(4), tbase);
+    stage8_load_s<SET, 5>(voff(5), tbase);
+    stage8_load_s<SET, 6>(voff(6), tbase);
+    stage8_load_s<SET, 7>(voff(7), tbase);
   };
-  // the set's loads have landed: counted wait, then pin every later use of the set behind it
-  auto landed = [&](gx_f32x4 (&st)[8], bool newer_in_flight) {
+  auto landed = [&](bool newer_in_flight) {  // the OLDER set's 8 loads are complete
     if (newer_in_flight)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      TMGCN_WAIT_VM(8);
     else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(st[i]));
-    __builtin_amdgcn_sched_barrier(0);
+      TMGCN_WAIT_VM(0);
   };
-  auto split_store = [&](const gx_f32x4 (&st)[8], const GxTile& t) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float z = (rg + 8 * i < t.rows) ? zq : 0.f;
-      unsigned h0, m0, l0, h1, m1, l1;
-      gx_split3(st[i].x * z, st[i].y * z, h0, m0, l0);
-      gx_split3(st[i].z * z, st[i].w * z, h1, m1, l1);
-      unsigned char* w = wr + i * 8 * GX_PITCH;
-      *reinterpret_cast<uint2*>(w) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(w + GX_PLANE) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2*>(w + 2 * GX_PLANE) = make_uint2(l0, l1);
-    }
+  auto split_one = [&](const stage_f32x4& v, int i, const GxTile& t) {
+    const float z = (rg + 8 * i < t.rows) ? zq : 0.f;
+    unsigned h0, m0, l0, h1, m1, l1;
+    gx_split3(v[0] * z, v[1] * z, h0, m0, l0);
+    gx_split3(v[2] * z, v[3] * z, h1, m1, l1);
+    unsigned char* w = wr + i * 8 * GX_PITCH;
+    *reinterpret_cast<uint2*>(w) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(w + GX_PLANE) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(w + 2 * GX_PLANE) = make_uint2(l0, l1);
   };
+  auto split_store = [&](auto set, const GxTile& t) {
+    constexpr int SET = decltype(set)::value;
+    split_one(stage8_read<SET, 0>(), 0, t);
+    split_one(stage8_read<SET, 1>(), 1, t);
+    split_one(stage8_read<SET, 2>(), 2, t);
+    split_one(stage8_read<SET, 3>(), 3, t);
+    split_one(stage8_read<SET, 4>(), 4, t);
+    split_one(stage8_read<SET, 5>(), 5, t);
+    split_one(stage8_read<SET, 6>(), 6, t);
+    split_one(stage8_read<SET, 7>(), 7, t);
+  };
+  const std::integral_constant<int, 0> SA;
+  const std::integral_constant<int, 1> SB;
 
   // the tile whose planes are in LDS: multiply() runs the MFMAs, store_tile() applies the activation
   // and stores; the counted wait for the other staging set sits between the two
@@ -376,69 +390,43 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
     }
   };
 
-  // Tile ids are drawn three ahead (two in registers, one in flight): the returning atomic of
-  // thread 0 is an inline-asm operation OLDER than the 8 loads of its phase, so the same counted
-  // wait covers it; a compiler-visible atomic would be waited for with vmcnt(0).
-  const unsigned n_tiles = (unsigned)a.n_tiles;
-  unsigned int* ctr = a.tile_counter + blockIdx.y;
-  if (threadIdx.x == 0) {
-    s_tile[0] = atomicAdd(ctr, 1u);
-    s_tile[1] = atomicAdd(ctr, 1u);
-    s_tile[2] = atomicAdd(ctr, 1u);
-  }
-  __syncthreads();
-  unsigned t0 = s_tile[0], t1 = s_tile[1], t2 = s_tile[2];
-  __syncthreads();
+  // Static persistent schedule: block b takes tiles b, b + G, b + 2G, ... (uniform tiles: nothing to
+  // balance, and a returning atomic would be one more asynchronous result to park in a reserved
+  // register).  Tiles alternate between the two staging sets, so the loop body is written for two.
+  const unsigned n_tiles = (unsigned)a.n_tiles, stride = gridDim.x;
+  unsigned t0 = blockIdx.x, t1 = blockIdx.x + stride;
   GxTile ta = tile_rows(t0 < n_tiles ? t0 : 0), tb = tile_rows(t1 < n_tiles ? t1 : 0);
-  if (t0 < n_tiles) fetch(sa, ta);
-  if (t1 < n_tiles) fetch(sb, tb);
-  landed(sa, t1 < n_tiles);
-  unsigned drawn = 0;
-  const unsigned one = 1u, zero_off = 0u;
-  auto draw = [&]() {  // thread 0: request the id three tiles ahead (valid after the next counted wait)
-    if (threadIdx.x == 0)
-      asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(drawn) : "v"(zero_off), "v"(one), "s"(ctr) : "memory");
-  };
-  auto publish = [&](int slot) {  // after the counted wait: hand the drawn id to the block
-    if (threadIdx.x == 0) {
-      asm volatile("" : "+v"(drawn));
-      s_tile[slot] = drawn;
-    }
-  };
+  if (t0 < n_tiles) fetch(SA, ta);
+  if (t1 < n_tiles) fetch(SB, tb);
+  landed(t1 < n_tiles);  // set A
   while (t0 < n_tiles) {
-    // ---- tile t0 (set a): split, request t2 into set a, multiply, wait for set b, store
+    // ---- tile t0 (set A): split, request t0 + 2G into set A, multiply, wait for set B, store
     __syncthreads();  // the previous tile's fragment reads are done
-    split_store(sa, ta);
-    draw();
-    const GxTile tc2 = tile_rows(t2 < n_tiles ? t2 : 0);
+    split_store(SA, ta);
+    const unsigned t2 = t0 + 2 * stride;
     const bool f2 = t2 < n_tiles;
-    if (f2) fetch(sa, tc2);
+    const GxTile tc2 = tile_rows(f2 ? t2 : 0);
+    if (f2) fetch(SA, tc2);
     __syncthreads();
     multiply(ta);
-    landed(sb, f2);
-    publish(0);
+    landed(f2);  // set B
     store_tile(ta);
     if (t1 >= n_tiles) break;
-    // ---- tile t1 (set b)
-    __syncthreads();  // also publishes s_tile[0]
-    const unsigned t3 = s_tile[0];
-    split_store(sb, tb);
-    draw();
-    const GxTile tc3 = tile_rows(t3 < n_tiles ? t3 : 0);
+    // ---- tile t1 (set B)
+    __syncthreads();
+    split_store(SB, tb);
+    const unsigned t3 = t1 + 2 * stride;
     const bool f3 = t3 < n_tiles;
-    if (f3) fetch(sb, tc3);
+    const GxTile tc3 = tile_rows(f3 ? t3 : 0);
+    if (f3) fetch(SB, tc3);
     __syncthreads();
     multiply(tb);
-    landed(sa, f3);
-    publish(1);
+    landed(f3);  // set A
     store_tile(tb);
-    __syncthreads();  // publishes s_tile[1]
-    const unsigned t4 = s_tile[1];
     t0 = t2;
     ta = tc2;
     t1 = t3;
     tb = tc3;
-    t2 = t4;
   }
 }
 
@@ -841,6 +829,17 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
   }
 }
 
+// A second form of this kernel was built and measured in round 2 and is NOT kept: one 512-thread
+// block per CU, double-buffered plane images (one barrier per step), waves 0-3 splitting while waves
+// 4-7 multiply (stagger), and a two-deep load ring in reserved registers (async_stage.h).  It ran
+// 2.17 ms against 1.89 ms for the kernel above at R = 8 M rows (2.20 ms without the stagger,
+// 2.02 ms without the RNE flush; profiles/r02k_ab_dw_forms.txt).  The PMC pass of
+// profiles/r02l_pmc_sq_gemm_dw.json says why more prefetch does not help either form: the matrix
+// pipes are busy 47-48 % of the cycles and the waves wait on instruction ISSUE (MFMA pipe / VALU)
+// for 48 % of their life, on memory or barriers for only 26 %, at a shader clock of ~1.6 GHz — the
+// six plane products plus ~200 VALU instructions of splitting per step are co-limiting with the
+// 32.8 GB stream, they are not hidden under it.
+
 // small dW: rows staged through LDS in tiles of DW_ROWS.  With few outputs (K*Nf <= 128, the
 // reference's 2x6 / 6x6) the 256 threads form 256/(K*Nf) row groups that each take every g-th row
 // of the tile, so all lanes work; with more outputs each thread owns up to 4 output elements.
@@ -983,17 +982,17 @@ extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* p
   a.n_tiles = nb * a.tiles_per_batch;
   const unsigned gy = (unsigned)((Nf + 127) / 128);
   TMGCN_REQUIRE(a.n_tiles < (int64_t)0x7fffffff && gy <= 64, "gemm: shape too large for the tile scheduler");
-  // gy consecutive counters of the pool (acquire zeroes one; take gy of them in a row)
-  a.tile_counter = acquire_tile_counters(st, (int)gy);
-  TMGCN_REQUIRE(a.tile_counter, "gemm: cannot set up the tile counters");
   const bool x3 = algo == TMGCN_GEMM_AUTO && K % 4 == 0 && K >= 16 && K <= 128 &&
                   reinterpret_cast<uintptr_t>(A) % 16 == 0;
-  if (x3) {
+  if (x3) {  // static persistent schedule: no tile counter
     int64_t gx = persistent_grid(gemm_bf16x3_kernel, 256);
     if (gx > a.n_tiles) gx = a.n_tiles;
     hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
     return check_launch("gemm_bf16x3");
   }
+  // gy consecutive counters of the pool (acquire zeroes one; take gy of them in a row)
+  a.tile_counter = acquire_tile_counters(st, (int)gy);
+  TMGCN_REQUIRE(a.tile_counter, "gemm: cannot set up the tile counters");
   int64_t gx = persistent_grid(gemm_mfma_kernel, 256);
   if (gx > a.n_tiles) gx = a.n_tiles;
   hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);

@@ -15,7 +15,9 @@
 //   mtransform_bf16x3   any operator with T_in <= 128 (Minv, bands wider than 20): bf16 matrix cores after
 //                       an exact 3-way split of both operands (fp32-accurate), a stream over X and Y.
 //   mtransform_dense_mfma / mtransform_dense   exact-f32 MFMA (T_in <= 256) / register-blocked FMA fallbacks.
+#include <type_traits>
 #include "common.h"
+#include "async_stage.h"
 
 namespace tmgcn {
 
@@ -352,7 +354,6 @@ constexpr int MX_PLANE = 4 * MX_JB;                   // T_in <= 128
 
 __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[3 * MX_PLANE];
-  __shared__ unsigned int s_tile[3];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -392,60 +393,65 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
   unsigned char* wr0 = sm + (jg >> 3) * MX_JB + cq * MX_QPITCH + (jg & 7) * 8;  // block b adds 2 j-blocks
   const unsigned char* rd = sm + (li >> 2) * MX_QPITCH + (li & 3) * 64 + lh * 16;
 
-  // Two staging register sets filled by inline-asm loads (invisible to the compiler's wait-count
-  // pass, which would otherwise drain the queue at the first use after the epilogue's branches):
-  // the columns of tile i+2 are requested as soon as tile i has been split and are waited for with a
-  // counted s_waitcnt one tile later (vmcnt(8): all but the 8 loads requested since) — ~2 x 32 KB
-  // per block stay in flight across the barriers.  Same scheme as gemm_bf16x3_kernel (gemm.hip).
-  typedef float mx_f32x4 __attribute__((ext_vector_type(4)));
-  mx_f32x4 sa[8], sb[8];
+  // Two staging sets of 8 float4s in RESERVED registers (v192..v255; async_stage.h explains why they
+  // must not be ordinary asm outputs), filled by inline-asm loads that the compiler's wait-count pass
+  // does not see: the columns of tile i+2 are requested as soon as tile i has been split and are
+  // waited for with a counted s_waitcnt one tile later (vmcnt(8): all but the 8 loads requested
+  // since) — ~2 x 32 KB per block stay in flight across the barriers.  Same scheme as gemm_bf16x3_kernel.
   const int64_t last_quad = a.C - 4;  // C % 4 == 0 (checked by the launcher)
   // Row positions are recomputed per tile from an opaque copy of jg: hoisted out of the tile loop
   // they would pin 16 VGPRs of 64-bit offsets (plus 32 more for the stores below) beside the
   // 96-VGPR operator strip.
-  auto fetch = [&](mx_f32x4 (&st)[8], unsigned tile) {  // no conditional load: columns past C re-read the last quad, rows past T_in the last row; zeroed at the split
+  auto fetch = [&](auto set, unsigned tile) {  // no conditional load: columns past C re-read the last quad, rows past T_in the last row; zeroed at the split
+    constexpr int SET = decltype(set)::value;
     int64_t c = (int64_t)tile * MX_COLS + 4 * cq;
     if (c > last_quad) c = last_quad;
     const float* base = a.X + c;
     int jq = jg;
     asm volatile("" : "+v"(jq));
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 4 * (jq + 16 * b) + i;
-        const float* ptr = base + row_pos(j < a.T_in ? j : a.T_in - 1, a.T_in, a.x_tl) * a.C;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st[4 * b + i]) : "v"(ptr) : "memory");
-      }
+    auto rowp = [&](int b, int i) {
+      const int j = 4 * (jq + 16 * b) + i;
+      return base + row_pos(j < a.T_in ? j : a.T_in - 1, a.T_in, a.x_tl) * a.C;
+    };
+    stage8_load<SET, 0>(rowp(0, 0));
+    stage8_load<SET, 1>(rowp(0, 1));
+    stage8_load<SET, 2>(rowp(0, 2));
+    stage8_load<SET, 3>(rowp(0, 3));
+    stage8_load<SET, 4>(rowp(1, 0));
+    stage8_load<SET, 5>(rowp(1, 1));
+    stage8_load<SET, 6>(rowp(1, 2));
+    stage8_load<SET, 7>(rowp(1, 3));
   };
-  auto landed = [&](mx_f32x4 (&st)[8], bool newer_in_flight) {  // counted wait, then pin every later use of the set behind it
+  auto landed = [&](bool newer_in_flight) {  // the OLDER set's 8 loads are complete
     if (newer_in_flight)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      TMGCN_WAIT_VM(8);
     else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(st[i]));
-    __builtin_amdgcn_sched_barrier(0);
+      TMGCN_WAIT_VM(0);
   };
-  auto split_store = [&](const mx_f32x4 (&st)[8], unsigned tile) {
-    const float zc = ((int64_t)tile * MX_COLS + 4 * cq < a.C) ? 1.f : 0.f;
+  auto split_block = [&](const stage_f32x4& s0, const stage_f32x4& s1, const stage_f32x4& s2, const stage_f32x4& s3,
+                         int b, float zc) {
+    float z[4];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      float z[4];
+    for (int i = 0; i < 4; ++i) z[i] = (4 * (jg + 16 * b) + i < a.T_in) ? zc : 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) z[i] = (4 * (jg + 16 * b) + i < a.T_in) ? zc : 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        mx_split3(st[4 * b + 0][e] * z[0], st[4 * b + 1][e] * z[1], h0, m0, l0);
-        mx_split3(st[4 * b + 2][e] * z[2], st[4 * b + 3][e] * z[3], h1, m1, l1);
-        unsigned char* w = wr0 + b * 2 * MX_JB + e * 64;
-        *reinterpret_cast<uint2*>(w) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(w + MX_PLANE) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(w + 2 * MX_PLANE) = make_uint2(l0, l1);
-      }
+    for (int e = 0; e < 4; ++e) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      mx_split3(s0[e] * z[0], s1[e] * z[1], h0, m0, l0);
+      mx_split3(s2[e] * z[2], s3[e] * z[3], h1, m1, l1);
+      unsigned char* w = wr0 + b * 2 * MX_JB + e * 64;
+      *reinterpret_cast<uint2*>(w) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(w + MX_PLANE) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(w + 2 * MX_PLANE) = make_uint2(l0, l1);
     }
   };
+  auto split_store = [&](auto set, unsigned tile) {
+    constexpr int SET = decltype(set)::value;
+    const float zc = ((int64_t)tile * MX_COLS + 4 * cq < a.C) ? 1.f : 0.f;
+    split_block(stage8_read<SET, 0>(), stage8_read<SET, 1>(), stage8_read<SET, 2>(), stage8_read<SET, 3>(), 0, zc);
+    split_block(stage8_read<SET, 4>(), stage8_read<SET, 5>(), stage8_read<SET, 6>(), stage8_read<SET, 7>(), 1, zc);
+  };
+  const std::integral_constant<int, 0> SA;
+  const std::integral_constant<int, 1> SB;
 
   f32x16 acc[2];
   auto multiply = [&]() {
@@ -495,63 +501,37 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
     }
   };
 
-  // tile ids are drawn three ahead; thread 0's returning atomic is an inline-asm operation older than
-  // the 8 loads of its phase, so the same counted wait covers it (gemm.hip has the long version)
-  const unsigned n_tiles = (unsigned)((a.C + MX_COLS - 1) / MX_COLS);
-  unsigned int* ctr = a.tile_counter + blockIdx.y;
-  if (threadIdx.x == 0) {
-    s_tile[0] = atomicAdd(ctr, 1u);
-    s_tile[1] = atomicAdd(ctr, 1u);
-    s_tile[2] = atomicAdd(ctr, 1u);
-  }
-  __syncthreads();
-  unsigned t0 = s_tile[0], t1 = s_tile[1], t2 = s_tile[2];
-  __syncthreads();
-  if (t0 < n_tiles) fetch(sa, t0);
-  if (t1 < n_tiles) fetch(sb, t1);
-  landed(sa, t1 < n_tiles);
-  unsigned drawn = 0;
-  const unsigned one = 1u, zero_off = 0u;
-  auto draw = [&]() {
-    if (threadIdx.x == 0)
-      asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(drawn) : "v"(zero_off), "v"(one), "s"(ctr) : "memory");
-  };
-  auto publish = [&](int slot) {
-    if (threadIdx.x == 0) {
-      asm volatile("" : "+v"(drawn));
-      s_tile[slot] = drawn;
-    }
-  };
+  // static persistent schedule: block b takes column tiles b, b + G, b + 2G, ... (uniform tiles);
+  // tiles alternate between the two staging sets, so the loop body is written for two
+  const unsigned n_tiles = (unsigned)((a.C + MX_COLS - 1) / MX_COLS), stride = gridDim.x;
+  unsigned t0 = blockIdx.x, t1 = blockIdx.x + stride;
+  if (t0 < n_tiles) fetch(SA, t0);
+  if (t1 < n_tiles) fetch(SB, t1);
+  landed(t1 < n_tiles);  // set A
   while (t0 < n_tiles) {
-    // ---- tile t0 (set a): split, request t2 into set a, multiply, wait for set b, store
+    // ---- tile t0 (set A): split, request t0 + 2G into set A, multiply, wait for set B, store
     __syncthreads();  // the previous tile's fragment reads are done
-    split_store(sa, t0);
-    draw();
+    split_store(SA, t0);
+    const unsigned t2 = t0 + 2 * stride;
     const bool f2 = t2 < n_tiles;
-    if (f2) fetch(sa, t2);
+    if (f2) fetch(SA, t2);
     __syncthreads();
     multiply();
-    landed(sb, f2);
-    publish(0);
+    landed(f2);  // set B
     store_tile(t0);
     if (t1 >= n_tiles) break;
-    // ---- tile t1 (set b)
-    __syncthreads();  // also publishes s_tile[0]
-    const unsigned t3 = s_tile[0];
-    split_store(sb, t1);
-    draw();
+    // ---- tile t1 (set B)
+    __syncthreads();
+    split_store(SB, t1);
+    const unsigned t3 = t1 + 2 * stride;
     const bool f3 = t3 < n_tiles;
-    if (f3) fetch(sb, t3);
+    if (f3) fetch(SB, t3);
     __syncthreads();
     multiply();
-    landed(sa, f3);
-    publish(1);
+    landed(f3);  // set A
     store_tile(t1);
-    __syncthreads();  // publishes s_tile[1]
-    const unsigned t4 = s_tile[1];
     t0 = t2;
     t1 = t3;
-    t2 = t4;
   }
 }
 
@@ -600,12 +580,7 @@ static int dispatch(MtArgs a, hipStream_t st) {
       set_error("mtransform: shape too large for the dense tile scheduler");
       return TMGCN_ERR_INVALID;
     }
-    a.tile_counter = acquire_tile_counters(st, (int)gy);
-    if (!a.tile_counter) {
-      set_error("mtransform: cannot set up the tile counters");
-      return TMGCN_ERR_LAUNCH;
-    }
-    int64_t gx = persistent_grid(mtransform_bf16x3_kernel, 256);
+    int64_t gx = persistent_grid(mtransform_bf16x3_kernel, 256);  // static persistent schedule: no tile counter
     if (gx > n_tiles) gx = n_tiles;
     hipLaunchKernelGGL(mtransform_bf16x3_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
     return check_launch("mtransform_bf16x3");
