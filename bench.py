@@ -55,6 +55,10 @@ def parse(argv=None):
     p.add_argument("--no-epochs", action="store_true", help="skip the S1-S3 training-epoch block (N = 1 only)")
     p.add_argument("--no-compare-exchange", action="store_true",
                    help="skip the a2a / allgather side-by-side leg of multi-rank runs")
+    p.add_argument("--compare-full", action="store_true",
+                   help="also run the OTHER exchange mode at full N where it fits (the all-gather materialises [T,N,F] "
+                        "twice per GPU: only G = 2 at the S4 size); off by default so that a scaling run never risks its "
+                        "headline measurement on a 200 GB side experiment")
     p.add_argument("--no-fuse", action="store_true", help="run P2 and P3 as separate kernels")
     p.add_argument("--no-pipeline", action="store_true", help="exchange all slices before computing")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
@@ -530,7 +534,10 @@ def worker(args):
         ok, need = fits(other, N)
         compare["full_n"] = {"nodes": N, args.exchange + "_ms_per_step": round(res["elapsed"] / args.steps * 1e3, 3),
                              other + "_needs_gb_per_gpu": round(need / 1e9, 1)}
-        if ok and N != n_cmp:
+        if not args.compare_full and N != n_cmp:
+            compare["full_n"][other + "_ms_per_step"] = None
+            compare["full_n"]["note"] = "not run (pass --compare-full); " + ("it would fit" if ok else "it would not fit at this world size")
+        elif ok and N != n_cmp:
             r = run_layer(args, dist, dev, rank, world, other, N, 3, 1, want_timer=False)
             compare["full_n"][other + "_ms_per_step"] = round(r["elapsed"] / 3 * 1e3, 3)
             free_device_memory()

@@ -343,6 +343,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   // and stores; the counted wait for the other staging set sits between the two
   int cur_batch = -1;
   f32x16 acc[2];
+  auto k_step = [&](int ks) {  // 2 row blocks x 6 plane products of one 16-deep k-step
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const unsigned char* p = rd + mb * 32 * GX_PITCH + ks * 32;
+      const gx_bf16x8 ah = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p));
+      const gx_bf16x8 am = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + GX_PLANE));
+      const gx_bf16x8 al = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + 2 * GX_PLANE));
+      const gx_bf16x8 bh = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
+      const gx_bf16x8 bm = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
+      const gx_bf16x8 bl = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][2][0], bw[ks][2][1], bw[ks][2][2], bw[ks][2][3]));
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);  // small terms first
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+    }
+  };
   auto multiply = [&](const GxTile& tc) {
     if (tc.batch != cur_batch) {
       load_w(a.W + (a.rows_per_batch ? (int64_t)tc.batch * a.w_batch_stride : 0));
@@ -353,26 +371,47 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
+    if (nks == 8) {
+      // K = 128: 16 groups (k-step, row block) of 3 fragment reads + 6 MFMAs, software-pipelined by
+      // hand: the reads of group g+1 are issued in front of the MFMAs of group g (sched_barrier pins
+      // the order), so a read has 192 cycles of matrix-pipe time to land.  Left alone, hipcc issues
+      // each read right in front of its MFMA and waits out the LDS latency ~50 times per tile.
+      struct Frag3 {
+        uint4 h, m, l;
+      };
+      auto read_group = [&](int g) {
+        const unsigned char* p = rd + (g & 1) * 32 * GX_PITCH + (g >> 1) * 32;
+        Frag3 f;
+        f.h = *reinterpret_cast<const uint4*>(p);
+        f.m = *reinterpret_cast<const uint4*>(p + GX_PLANE);
+        f.l = *reinterpret_cast<const uint4*>(p + 2 * GX_PLANE);
+        return f;
+      };
+      Frag3 cur = read_group(0);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      if (ks < nks) {
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-          const unsigned char* p = rd + mb * 32 * GX_PITCH + ks * 32;
-          const gx_bf16x8 ah = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p));
-          const gx_bf16x8 am = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + GX_PLANE));
-          const gx_bf16x8 al = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + 2 * GX_PLANE));
-          const gx_bf16x8 bh = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
-          const gx_bf16x8 bm = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
-          const gx_bf16x8 bl = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][2][0], bw[ks][2][1], bw[ks][2][2], bw[ks][2][3]));
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);  // small terms first
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
-        }
+      for (int g = 0; g < 16; ++g) {
+        const int ks = g >> 1, mb = g & 1;
+        Frag3 nxt = cur;
+        if (g + 1 < 16) nxt = read_group(g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const gx_bf16x8 ah = __builtin_bit_cast(gx_bf16x8, cur.h), am = __builtin_bit_cast(gx_bf16x8, cur.m),
+                        al = __builtin_bit_cast(gx_bf16x8, cur.l);
+        const gx_bf16x8 bh = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
+        const gx_bf16x8 bm = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
+        const gx_bf16x8 bl = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][2][0], bw[ks][2][1], bw[ks][2][2], bw[ks][2][3]));
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);  // small terms first
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
       }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        if (ks < nks) k_step(ks);
     }
   };
   auto store_tile = [&](const GxTile& tc) {
@@ -657,6 +696,9 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& h, unsigned& 
 #ifndef X3_FLUSH
 #define X3_FLUSH 4
 #endif
+#ifndef X3_SCHED
+#define X3_SCHED 1
+#endif
 constexpr int X3_ROWS = 32;
 constexpr int X3_PITCH = 272;             // bytes per feature quad (4 x 64 + 16)
 constexpr int X3_PLANE = 32 * X3_PITCH;   // 128 features
@@ -780,6 +822,26 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
       }
     }
+#if X3_SCHED
+    // Software-pipeline the LDS fragment reads against the MFMAs (left to itself hipcc issues each
+    // group's ds_read_b128s right in front of the MFMA that needs them and waits out their latency,
+    // 8-10 times per step): A fragments of half 0 + B fragments of group 0 first, then every group of
+    // 6 MFMAs is preceded by the 3 reads of the NEXT group (the A fragments of half 1 ride along with
+    // group 2), so a read has 6 MFMAs = 192 cycles of matrix-pipe time to land.
+#define X3_SGB_READS(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define X3_SGB_MFMAS(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+    X3_SGB_READS(6);                   // A(half 0), B(group 0)
+    X3_SGB_READS(3); X3_SGB_MFMAS(6);  // B(1) | group 0
+    X3_SGB_READS(3); X3_SGB_MFMAS(6);  // B(2) | group 1
+    X3_SGB_READS(6); X3_SGB_MFMAS(6);  // B(3) + A(half 1) | group 2
+    X3_SGB_READS(3); X3_SGB_MFMAS(6);  // B(4) | group 3
+    X3_SGB_READS(3); X3_SGB_MFMAS(6);  // B(5) | group 4
+    X3_SGB_READS(3); X3_SGB_MFMAS(6);  // B(6) | group 5
+    X3_SGB_READS(3); X3_SGB_MFMAS(6);  // B(7) | group 6
+    X3_SGB_MFMAS(6);                   //        group 7
+#undef X3_SGB_READS
+#undef X3_SGB_MFMAS
+#endif
     if (++since_flush == X3_FLUSH) flush();
   };
 

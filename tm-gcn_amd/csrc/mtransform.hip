@@ -454,31 +454,71 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
   const std::integral_constant<int, 1> SB;
 
   f32x16 acc[2];
+  struct Frag3 {
+    uint4 h, m, l;
+  };
+  auto read_group = [&](int js, int cb) {  // X-plane fragments of j-step js, column block cb
+    const unsigned char* p = rd + (js >> 1) * MX_JB + cb * 8 * MX_QPITCH + (js & 1) * 32;
+    Frag3 f;
+    f.h = *reinterpret_cast<const uint4*>(p);
+    f.m = *reinterpret_cast<const uint4*>(p + MX_PLANE);
+    f.l = *reinterpret_cast<const uint4*>(p + 2 * MX_PLANE);
+    return f;
+  };
+  auto six = [&](int js, int cb, const Frag3& f) {  // the six plane products of one (j-step, column block)
+    const mx_bf16x8 ah = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][0][0], am[js][0][1], am[js][0][2], am[js][0][3]));
+    const mx_bf16x8 amid = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][1][0], am[js][1][1], am[js][1][2], am[js][1][3]));
+    const mx_bf16x8 al = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][2][0], am[js][2][1], am[js][2][2], am[js][2][3]));
+    const mx_bf16x8 bh = __builtin_bit_cast(mx_bf16x8, f.h), bm = __builtin_bit_cast(mx_bf16x8, f.m),
+                    bl = __builtin_bit_cast(mx_bf16x8, f.l);
+    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[cb], 0, 0, 0);  // small terms first
+    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[cb], 0, 0, 0);
+    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid, bm, acc[cb], 0, 0, 0);
+    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid, bh, acc[cb], 0, 0, 0);
+    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[cb], 0, 0, 0);
+    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[cb], 0, 0, 0);
+  };
+  // j-steps [LO, HI) known at compile time: groups (j-step, column block) software-pipelined by hand —
+  // the three fragment reads of group g+1 are issued in front of the six MFMAs of group g
+  // (sched_barrier pins the order), so a read has 192 cycles of matrix-pipe time to land instead of
+  // being waited for right in front of its MFMA.
+  auto pipelined = [&](auto lo_tag, auto hi_tag) {
+    constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value, NG = 2 * (HI - LO);
+    Frag3 cur = read_group(LO, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      Frag3 nxt = cur;
+      if (g + 1 < NG) nxt = read_group(LO + ((g + 1) >> 1), (g + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      six(LO + (g >> 1), g & 1, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+  };
   auto multiply = [&]() {
     if (!wave_live) return;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
+    using std::integral_constant;
+    // the ranges a dense / lower- / upper-triangular 128-row operator gives the four waves of a block
+    const int range = js_lo * 16 + js_hi;
+    switch (range) {
+      case 0 * 16 + 8: pipelined(integral_constant<int, 0>{}, integral_constant<int, 8>{}); return;
+      case 0 * 16 + 6: pipelined(integral_constant<int, 0>{}, integral_constant<int, 6>{}); return;
+      case 0 * 16 + 4: pipelined(integral_constant<int, 0>{}, integral_constant<int, 4>{}); return;
+      case 0 * 16 + 2: pipelined(integral_constant<int, 0>{}, integral_constant<int, 2>{}); return;
+      case 2 * 16 + 8: pipelined(integral_constant<int, 2>{}, integral_constant<int, 8>{}); return;
+      case 4 * 16 + 8: pipelined(integral_constant<int, 4>{}, integral_constant<int, 8>{}); return;
+      case 6 * 16 + 8: pipelined(integral_constant<int, 6>{}, integral_constant<int, 8>{}); return;
+      default: break;
+    }
 #pragma unroll
-    for (int js = 0; js < 8; ++js) {
+    for (int js = 0; js < 8; ++js) {  // any other band / size: not pipelined
       if (js >= js_lo && js < js_hi) {
-        const mx_bf16x8 ah = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][0][0], am[js][0][1], am[js][0][2], am[js][0][3]));
-        const mx_bf16x8 amid = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][1][0], am[js][1][1], am[js][1][2], am[js][1][3]));
-        const mx_bf16x8 al = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][2][0], am[js][2][1], am[js][2][2], am[js][2][3]));
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          const unsigned char* p = rd + (js >> 1) * MX_JB + cb * 8 * MX_QPITCH + (js & 1) * 32;
-          const mx_bf16x8 bh = __builtin_bit_cast(mx_bf16x8, *reinterpret_cast<const uint4*>(p));
-          const mx_bf16x8 bm = __builtin_bit_cast(mx_bf16x8, *reinterpret_cast<const uint4*>(p + MX_PLANE));
-          const mx_bf16x8 bl = __builtin_bit_cast(mx_bf16x8, *reinterpret_cast<const uint4*>(p + 2 * MX_PLANE));
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[cb], 0, 0, 0);  // small terms first
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[cb], 0, 0, 0);
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid, bm, acc[cb], 0, 0, 0);
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid, bh, acc[cb], 0, 0, 0);
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[cb], 0, 0, 0);
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[cb], 0, 0, 0);
-        }
+        for (int cb = 0; cb < 2; ++cb) six(js, cb, read_group(js, cb));
       }
     }
   };
