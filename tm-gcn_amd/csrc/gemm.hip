@@ -653,7 +653,8 @@ __global__ __launch_bounds__(256) void gemm_dw_lds_kernel(DwArgs a) {
 //   the 16-byte pad per quad makes the ds_read_b128 fragment reads conflict-free (2-way on the
 //   stores, which their issue cost hides).  k-slot = row inside the step for BOTH operands, so the
 //   MFMA's k order is consistent.  Staging registers are refilled for the next step before the MFMA
-//   phase; three blocks per CU overlap one block's split/store phase with another's MFMAs.
+//   phase; two blocks per CU (the RNE flush set below costs the third) overlap one block's split/store
+//   phase with the other's MFMAs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -676,7 +677,7 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& h, unsigned& 
   l = pack_bf16(a, b);
 }
 
-// Measured (33.5 M rows, 128x128): depth 1 at 3 blocks/CU 7.57 ms, depth 2 / 3 / 4 at 2 blocks/CU 7.68 /
+// Measured in round 1, before the flush set (33.5 M rows, 128x128): depth 1 at 3 blocks/CU 7.57 ms, depth 2 / 3 / 4 at 2 blocks/CU 7.68 /
 // 7.69 / 7.73 ms — hipcc drains every outstanding load at the ring loop's header (s_waitcnt vmcnt(0)),
 // so a deeper ring buys nothing today; the f32-MFMA kernel it replaces takes 10.9 ms.
 #ifndef X3_DEPTH
