@@ -319,3 +319,33 @@ def test_g8_gcn_reg(name):
     for n, p in m.named_parameters():
         assert_close(p.grad, d["d" + n.replace(".", "_")], TOL, name + " d" + n)
     assert torch.equal(m(i["At"], i["X"]), m())  # forward ignores its arguments (ehf:410-412)
+
+
+def test_registered_cpp_autograd_and_python_autograd_paths_are_bit_identical():
+    """ops.py reaches the kernels two ways: the registered C++ autograd operators of the torch
+    extension (torch.ops.tmgcn.*, the product default) and — when a per-launch KernelTimer is attached,
+    as bench.py's roofline leg does — Python autograd functions over the kernel-level operators.  Both
+    must launch the same kernels with the same arguments: outputs and every gradient bit for bit."""
+    from tmgcn_amd import ops
+    d = golden("g3_gcn2_three_selu_condensed1")
+    i = _inputs(d)
+
+    def run(timed):
+        torch.manual_seed(int(d["seed"]))
+        m = ehf.EmbeddingGCN2(i["At"], i["X"], i["edges"], i["M"], hidden_feat=[6, 6, 2], condensed_W=True,
+                              use_Minv=False, apply_M_twice=True, apply_M_three_times=True, nonlin2="selu")
+        ops.kernels.timer = ops.KernelTimer() if timed else None
+        try:
+            out, loss, g = _loss_grads(m, i["labels"])
+            tags = set(ops.kernels.timer.summary()) if timed else set()
+        finally:
+            ops.kernels.timer = None
+        return out, loss, g, tags
+
+    out_c, loss_c, g_c, _ = run(False)
+    out_p, loss_p, g_p, tags = run(True)
+    assert {"mtransform", "mtransform_T", "spmm_gemm", "spmm_gemm_T", "gemm", "gemm_dW", "edge_head", "edge_head_bwd"} <= tags, tags
+    assert torch.equal(out_c, out_p) and loss_c == loss_p
+    for n in g_c:
+        assert torch.equal(g_c[n], g_p[n]), n
+    assert_close(out_c, d["logits"], TOL, "logits")
