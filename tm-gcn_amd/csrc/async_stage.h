@@ -32,6 +32,12 @@
 #define TMGCN_Q_READ(a, b, c, d, dst)                                                                       \
   asm volatile("v_mov_b32 %0, v" #a "\n\tv_mov_b32 %1, v" #b "\n\tv_mov_b32 %2, v" #c "\n\tv_mov_b32 %3, v" #d \
                : "=v"((dst)[0]), "=v"((dst)[1]), "=v"((dst)[2]), "=v"((dst)[3]))
+// the same, multiplied by a per-lane mask/scale on the way out (one v_mul_f32 per element instead of
+// v_mov_b32 + a separate multiply: the stream kernels zero out-of-range rows / columns this way)
+#define TMGCN_Q_READ_MUL(a, b, c, d, dst, z)                                                                    \
+  asm volatile("v_mul_f32 %0, v" #a ", %4\n\tv_mul_f32 %1, v" #b ", %4\n\tv_mul_f32 %2, v" #c ", %4\n\tv_mul_f32 %3, v" #d ", %4" \
+               : "=&v"((dst)[0]), "=&v"((dst)[1]), "=&v"((dst)[2]), "=&v"((dst)[3])                                \
+               : "v"(z))
 // counted wait: everything but the n youngest vector-memory operations of this wave has completed
 #define TMGCN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
@@ -106,6 +112,30 @@ __device__ __forceinline__ stage_f32x4 stage8_read() {
   if constexpr (q == 13) TMGCN_Q_READ(244, 245, 246, 247, v);
   if constexpr (q == 14) TMGCN_Q_READ(248, 249, 250, 251, v);
   if constexpr (q == 15) TMGCN_Q_READ(252, 253, 254, 255, v);
+  return v;
+}
+
+template <int SET, int I>
+__device__ __forceinline__ stage_f32x4 stage8_read_mul(float z) {
+  static_assert(SET >= 0 && SET < 2 && I >= 0 && I < 8, "stage8: bad slot");
+  constexpr int q = SET * 8 + I;
+  stage_f32x4 v;
+  if constexpr (q == 0) TMGCN_Q_READ_MUL(192, 193, 194, 195, v, z);
+  if constexpr (q == 1) TMGCN_Q_READ_MUL(196, 197, 198, 199, v, z);
+  if constexpr (q == 2) TMGCN_Q_READ_MUL(200, 201, 202, 203, v, z);
+  if constexpr (q == 3) TMGCN_Q_READ_MUL(204, 205, 206, 207, v, z);
+  if constexpr (q == 4) TMGCN_Q_READ_MUL(208, 209, 210, 211, v, z);
+  if constexpr (q == 5) TMGCN_Q_READ_MUL(212, 213, 214, 215, v, z);
+  if constexpr (q == 6) TMGCN_Q_READ_MUL(216, 217, 218, 219, v, z);
+  if constexpr (q == 7) TMGCN_Q_READ_MUL(220, 221, 222, 223, v, z);
+  if constexpr (q == 8) TMGCN_Q_READ_MUL(224, 225, 226, 227, v, z);
+  if constexpr (q == 9) TMGCN_Q_READ_MUL(228, 229, 230, 231, v, z);
+  if constexpr (q == 10) TMGCN_Q_READ_MUL(232, 233, 234, 235, v, z);
+  if constexpr (q == 11) TMGCN_Q_READ_MUL(236, 237, 238, 239, v, z);
+  if constexpr (q == 12) TMGCN_Q_READ_MUL(240, 241, 242, 243, v, z);
+  if constexpr (q == 13) TMGCN_Q_READ_MUL(244, 245, 246, 247, v, z);
+  if constexpr (q == 14) TMGCN_Q_READ_MUL(248, 249, 250, 251, v, z);
+  if constexpr (q == 15) TMGCN_Q_READ_MUL(252, 253, 254, 255, v, z);
   return v;
 }
 

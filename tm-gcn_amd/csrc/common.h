@@ -72,6 +72,42 @@ inline int persistent_grid_reserved(K kernel, int block_threads, int reserve, si
   return g < 64 ? 64 : g;
 }
 
+// 4x4 transpose across a lane quad: on entry register k of lane j (j = lane & 3) holds M[k][j], on
+// exit it holds M[j][k].  The MFMA accumulator layout has the output COLUMN on the lane and four
+// consecutive ROWS in consecutive registers, so a plain epilogue stores one dword per lane per row
+// (two 128-B segments per wave-instruction) and is bound by store ISSUE, not by bandwidth
+// (MI355X_MICROARCH.md, "epilogue store tail"; cdna_hip_programming.md T21).  After this transpose
+// lane j of a quad owns row j and four consecutive columns: one 16-byte store per lane, eight full
+// 128-B lines per wave-instruction, a quarter of the store instructions.  Two butterfly stages of
+// quad-permute DPP moves (no LDS): 12 VALU instructions per 4x4 block.
+__device__ __forceinline__ void quad_transpose4(float (&v)[4], int j) {
+  const bool odd = j & 1, hi = j & 2;
+  {  // stage 1: lanes j ^ 1, register pairs (0,1) and (2,3)
+    const float s0 = odd ? v[0] : v[1], s1 = odd ? v[2] : v[3];
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+    if (odd) {
+      v[0] = r0;
+      v[2] = r1;
+    } else {
+      v[1] = r0;
+      v[3] = r1;
+    }
+  }
+  {  // stage 2: lanes j ^ 2, register pairs (0,2) and (1,3)
+    const float s0 = hi ? v[0] : v[2], s1 = hi ? v[1] : v[3];
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
+    if (hi) {
+      v[0] = r0;
+      v[1] = r1;
+    } else {
+      v[2] = r0;
+      v[3] = r1;
+    }
+  }
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
   // torch.nn.ReLU / LeakyReLU(0.01) / SELU constants (ehf:284-289)
   switch (act) {

@@ -228,6 +228,34 @@ __device__ __forceinline__ void gx_store_rows(const f32x16 (&acc)[2], float* yb,
   }
 }
 
+// The same tile through 16-byte stores: each 4x4 block (4 rows in registers x 4 columns on a lane
+// quad) is transposed in registers (quad_transpose4), after which lane j of a quad owns row j and
+// columns 4q..4q+3.  y0 / p0 point at (tile row 0, this wave's column strip); needs Nf % 4 == 0 and
+// 16-byte aligned outputs (checked by the caller).  Rows past the tile's end are predicated off.
+template <int ACT>
+__device__ __forceinline__ void gx_store_rows_v4(const f32x16 (&acc)[2], float* y0, float* p0, int Nf, int rows,
+                                                 int li, int lh, bool cols_ok) {
+  // opaque copies: otherwise the eight row offsets and row tests are hoisted out of the tile loop as
+  // loop invariants and pinned in registers for the whole kernel, beside the 96-VGPR operator strip
+  asm volatile("" : "+v"(li), "+v"(lh));
+  const int j = li & 3, q = li >> 2;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v[4] = {acc[mb][4 * g], acc[mb][4 * g + 1], acc[mb][4 * g + 2], acc[mb][4 * g + 3]};
+      quad_transpose4(v, j);
+      const int rr = mb * 32 + 8 * g + 4 * lh + j;
+      if (rr < rows && cols_ok) {
+        const int off = rr * Nf + 4 * q;
+        if (p0) *reinterpret_cast<float4*>(p0 + off) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(y0 + off) =
+            make_float4(act_apply(v[0], ACT), act_apply(v[1], ACT), act_apply(v[2], ACT), act_apply(v[3], ACT));
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one 4x4 block in flight: the B strip leaves ~60 VGPRs for everything else
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[3 * GX_PLANE];
   const int lane = threadIdx.x & 63;
@@ -315,11 +343,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
     else
       TMGCN_WAIT_VM(0);
   };
-  auto split_one = [&](const stage_f32x4& v, int i, const GxTile& t) {
-    const float z = (rg + 8 * i < t.rows) ? zq : 0.f;
+  auto zrow = [&](int i, const GxTile& t) { return (rg + 8 * i < t.rows) ? zq : 0.f; };  // 0 for rows / k-quads outside
+  auto split_one = [&](const stage_f32x4& v, int i) {  // v arrives masked (stage8_read_mul)
     unsigned h0, m0, l0, h1, m1, l1;
-    gx_split3(v[0] * z, v[1] * z, h0, m0, l0);
-    gx_split3(v[2] * z, v[3] * z, h1, m1, l1);
+    gx_split3(v[0], v[1], h0, m0, l0);
+    gx_split3(v[2], v[3], h1, m1, l1);
     unsigned char* w = wr + i * 8 * GX_PITCH;
     *reinterpret_cast<uint2*>(w) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(w + GX_PLANE) = make_uint2(m0, m1);
@@ -327,14 +355,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   };
   auto split_store = [&](auto set, const GxTile& t) {
     constexpr int SET = decltype(set)::value;
-    split_one(stage8_read<SET, 0>(), 0, t);
-    split_one(stage8_read<SET, 1>(), 1, t);
-    split_one(stage8_read<SET, 2>(), 2, t);
-    split_one(stage8_read<SET, 3>(), 3, t);
-    split_one(stage8_read<SET, 4>(), 4, t);
-    split_one(stage8_read<SET, 5>(), 5, t);
-    split_one(stage8_read<SET, 6>(), 6, t);
-    split_one(stage8_read<SET, 7>(), 7, t);
+    split_one(stage8_read_mul<SET, 0>(zrow(0, t)), 0);
+    split_one(stage8_read_mul<SET, 1>(zrow(1, t)), 1);
+    split_one(stage8_read_mul<SET, 2>(zrow(2, t)), 2);
+    split_one(stage8_read_mul<SET, 3>(zrow(3, t)), 3);
+    split_one(stage8_read_mul<SET, 4>(zrow(4, t)), 4);
+    split_one(stage8_read_mul<SET, 5>(zrow(5, t)), 5);
+    split_one(stage8_read_mul<SET, 6>(zrow(6, t)), 6);
+    split_one(stage8_read_mul<SET, 7>(zrow(7, t)), 7);
   };
   const std::integral_constant<int, 0> SA;
   const std::integral_constant<int, 1> SB;
@@ -414,9 +442,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
         if (ks < nks) k_step(ks);
     }
   };
+  // 16-byte stores need whole column quads inside Nf and aligned rows
+  const bool v4 = (a.Nf % 4 == 0) && (reinterpret_cast<uintptr_t>(a.Y) % 16 == 0) &&
+                  (!a.pre || reinterpret_cast<uintptr_t>(a.pre) % 16 == 0);
   auto store_tile = [&](const GxTile& tc) {
+    if (!strip) return;
+    if (v4) {  // every lane takes part in the quad transposes; columns past Nf are predicated off
+      const int64_t base = tc.row0 * a.Nf + n0;
+      float* y0 = a.Y + base;
+      float* p0 = a.pre ? a.pre + base : nullptr;
+      const bool cols_ok = n0 + 4 * (li >> 2) < a.Nf;
+      switch (a.act) {
+        case TMGCN_ACT_RELU: gx_store_rows_v4<TMGCN_ACT_RELU>(acc, y0, p0, a.Nf, tc.rows, li, lh, cols_ok); break;
+        case TMGCN_ACT_LEAKY: gx_store_rows_v4<TMGCN_ACT_LEAKY>(acc, y0, p0, a.Nf, tc.rows, li, lh, cols_ok); break;
+        case TMGCN_ACT_SELU: gx_store_rows_v4<TMGCN_ACT_SELU>(acc, y0, p0, a.Nf, tc.rows, li, lh, cols_ok); break;
+        default: gx_store_rows_v4<TMGCN_ACT_NONE>(acc, y0, p0, a.Nf, tc.rows, li, lh, cols_ok);
+      }
+      return;
+    }
     const int n = n0 + li;
-    if (!strip || n >= a.Nf) return;
+    if (n >= a.Nf) return;
     const int64_t base = (tc.row0 + 4 * lh) * a.Nf + n;
     float* yb = a.Y + base;
     float* pb = a.pre ? a.pre + base : nullptr;

@@ -428,16 +428,14 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
     else
       TMGCN_WAIT_VM(0);
   };
+  auto zrow = [&](int b, int i, float zc) { return (4 * (jg + 16 * b) + i < a.T_in) ? zc : 0.f; };  // 0 outside T_in / C
   auto split_block = [&](const stage_f32x4& s0, const stage_f32x4& s1, const stage_f32x4& s2, const stage_f32x4& s3,
-                         int b, float zc) {
-    float z[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) z[i] = (4 * (jg + 16 * b) + i < a.T_in) ? zc : 0.f;
+                         int b) {  // the four rows arrive masked (stage8_read_mul)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       unsigned h0, m0, l0, h1, m1, l1;
-      mx_split3(s0[e] * z[0], s1[e] * z[1], h0, m0, l0);
-      mx_split3(s2[e] * z[2], s3[e] * z[3], h1, m1, l1);
+      mx_split3(s0[e], s1[e], h0, m0, l0);
+      mx_split3(s2[e], s3[e], h1, m1, l1);
       unsigned char* w = wr0 + b * 2 * MX_JB + e * 64;
       *reinterpret_cast<uint2*>(w) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(w + MX_PLANE) = make_uint2(m0, m1);
@@ -447,8 +445,10 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
   auto split_store = [&](auto set, unsigned tile) {
     constexpr int SET = decltype(set)::value;
     const float zc = ((int64_t)tile * MX_COLS + 4 * cq < a.C) ? 1.f : 0.f;
-    split_block(stage8_read<SET, 0>(), stage8_read<SET, 1>(), stage8_read<SET, 2>(), stage8_read<SET, 3>(), 0, zc);
-    split_block(stage8_read<SET, 4>(), stage8_read<SET, 5>(), stage8_read<SET, 6>(), stage8_read<SET, 7>(), 1, zc);
+    split_block(stage8_read_mul<SET, 0>(zrow(0, 0, zc)), stage8_read_mul<SET, 1>(zrow(0, 1, zc)),
+                stage8_read_mul<SET, 2>(zrow(0, 2, zc)), stage8_read_mul<SET, 3>(zrow(0, 3, zc)), 0);
+    split_block(stage8_read_mul<SET, 4>(zrow(1, 0, zc)), stage8_read_mul<SET, 5>(zrow(1, 1, zc)),
+                stage8_read_mul<SET, 6>(zrow(1, 2, zc)), stage8_read_mul<SET, 7>(zrow(1, 3, zc)), 1);
   };
   const std::integral_constant<int, 0> SA;
   const std::integral_constant<int, 1> SB;
@@ -522,21 +522,27 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
       }
     }
   };
-  auto store_tile = [&](unsigned tile) {  // D[k][c]: column = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+  // D[k][c]: column = lane & 31, row = (i&3) + 8*(i>>2) + 4*(lane>>5).  Each 4x4 block (4 rows in
+  // registers x 4 columns on a lane quad) is transposed in registers (quad_transpose4, common.h):
+  // lane j of a quad then owns row j and four consecutive columns — one 16-byte store per lane
+  // instead of four dword stores (the dword epilogue is bound by store issue, not bandwidth).
+  auto store_tile = [&](unsigned tile) {
     if (!wave_live) return;
     const int64_t c0 = (int64_t)tile * MX_COLS;
-    int kb = k0 + 4 * lh;
-    asm volatile("" : "+v"(kb));  // see fetch(): keep the 16 row offsets out of the loop-invariant set
+    int lq = li, kb = k0 + 4 * lh;
+    asm volatile("" : "+v"(lq), "+v"(kb));  // see fetch(): keep the row offsets out of the loop-invariant set
+    const int j = lq & 3, q = lq >> 2;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-      const int64_t c = c0 + cb * 32 + li;
-      if (c < a.C) {
-        float* yc = a.Y + c;
+      const int64_t c = c0 + cb * 32 + 4 * q;  // C % 4 == 0: a column quad is inside or outside as a whole
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int k = kb + (i & 3) + 8 * (i >> 2);
-          if (k < a.T_out) yc[row_pos(k, a.T_out, a.y_tl) * a.C] = acc[cb][i];
-        }
+      for (int g = 0; g < 4; ++g) {
+        float v[4] = {acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]};
+        quad_transpose4(v, j);
+        const int k = kb + 8 * g + j;
+        if (k < a.T_out && c < a.C)
+          *reinterpret_cast<float4*>(a.Y + row_pos(k, a.T_out, a.y_tl) * a.C + c) = make_float4(v[0], v[1], v[2], v[3]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
