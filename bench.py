@@ -78,6 +78,9 @@ def parse(argv=None):
     p.add_argument("--cpu-epoch-reps", type=int, default=5, help="CPU epochs timed per config and thread count")
     p.add_argument("--watchdog", type=int, default=600,
                    help="dump every thread's Python stack to stderr once after this many seconds (0 disables)")
+    p.add_argument("--selftest-stall", action="store_true",
+                   help="diagnostic (tests/test_bench_launcher.py): every rank stops making progress before it touches "
+                        "the GPU, so that the deadline path can be exercised on a CPU-only machine")
     p.add_argument("--deadline", type=int, default=1500,
                    help="hard limit: after this many seconds every rank dumps its stacks and exits non-zero (0 disables)")
     return p.parse_args(argv)
@@ -457,6 +460,10 @@ def worker(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.selftest_stall:
+        stage("selftest: stalling on purpose")
+        while True:
+            time.sleep(3600)
     stage("importing torch")
     import torch
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
