@@ -609,7 +609,9 @@ def worker(args):
                            "peak": 2500.0, "unit": "TFLOP/s", "frac": 6.0 * fp32_tf / 2500.0,
                            "dtype": "bf16 planes of an exact 3-way fp32 split (v_mfma_f32_32x32x16_bf16), fp32 accumulate",
                            "fp32_equivalent_tflops": fp32_tf, "f32_mfma_peak_tflops": 157.3,
-                           "hbm_gbs": res["rows_rank"] * 2 * F * 4 / t_dw / 1e9}
+                           "hbm_gbs": res["rows_rank"] * 2 * F * 4 / t_dw / 1e9,
+                           "bound_by": "board power: this kernel runs at the 1400 W cap with the shader clock pulled to "
+                                       "~1.9 GHz (profiles/r02t_power_probe.jsonl), neither the matrix pipes nor HBM are saturated"}
         if world == 1:  # the CPU legs are reported at N = 1 only
             if not args.no_epochs:
                 out["epochs"] = epochs_block(args)
