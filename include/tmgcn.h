@@ -141,6 +141,18 @@ int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* pre_act,
                    int64_t R, int32_t K, int32_t Nf, int32_t trans_w,
                    int64_t rows_per_batch, int64_t w_batch_stride, int32_t act, int32_t algo, void* stream);
 
+/* The same contraction with the weight STORED in bf16 (the "bf16 weights" configuration of the
+ * AMLSim experiment, SURVEY §8c/S3: the parameter of ehf:189/191 kept as torch.bfloat16): W_bf16
+ * holds bf16 bit patterns, w_batch_stride counts bf16 elements, everything else as above.  A, Y
+ * and the accumulation stay fp32.  A bf16 value is its own high plane, so the split kernel
+ * (K a multiple of 4 in [16,128]) needs three plane products per term instead of six; the result
+ * is bit-identical to tmgcn_gemm_f32 on the fp32-widened weight.
+ */
+int tmgcn_gemm_bf16w_f32(const float* A, const uint16_t* W_bf16, float* Y, float* pre_act,
+                         int64_t R, int32_t K, int32_t Nf, int32_t trans_w,
+                         int64_t rows_per_batch, int64_t w_batch_stride, int32_t act, int32_t algo,
+                         void* stream);
+
 /* Backward of P3 with respect to the weight (autograd of ehf:222 etc.):
  *   dW_b[k][n] = sum_{r in batch b} A[r][k] * dY[r][n]
  * workspace: tmgcn_gemm_dw_workspace_bytes() bytes of scratch on the device

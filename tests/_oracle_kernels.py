@@ -65,7 +65,7 @@ class OracleKernels:
         return Y, (AX if want_ax else None), (pre if want_pre else None)
 
     def gemm(self, A, W, trans_w=False, act=None, want_pre=False, algo=None):
-        Wd = W.double().transpose(-1, -2) if trans_w else W.double()
+        Wd = W.double().transpose(-1, -2) if trans_w else W.double()     # W may be stored in bf16
         pre = torch.matmul(A.double(), Wd).float()
         Y = orc.ACTS[act](pre) if act else pre
         return (Y, pre if act else None) if want_pre else Y

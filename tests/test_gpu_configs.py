@@ -120,6 +120,43 @@ def test_S3_amlsim_shaped_bf16_weights():
         assert_close(q.grad.float(), g32[n], 2e-2, "S3 d" + n)
 
 
+def test_S3_wide_features_bf16_weights_use_the_bf16_operand_kernel():
+    """The bf16-weights configuration at a feature width where P3 is a real GEMM (S3's graph, 64 random
+    input features -> 128 -> 2): the 1-layer model hands its bf16 W to tmgcn_gemm_bf16w_f32 as stored
+    (three plane products per term).  Forward at the fp32 tolerance against the oracle on the same
+    bf16-representable weights, gradients inside the bf16 tolerance, and the whole step bit-identical to
+    the same model with the weights widened to fp32 up front."""
+    from oracle import tmgcn_oracle as orc
+    g = synth.dynamic_graph(**synth.CONFIGS["S3"], seed=0)
+    At, M = g.At_list(), torch.from_numpy(g.M)
+    X = torch.rand(g.T, g.N, 64, generator=torch.Generator().manual_seed(3), dtype=torch.float64)   # the scripts hand fp64
+    edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels)
+    torch.manual_seed(1)
+    m = ehf.EmbeddingGCN(At, X, edges, M, hidden_feat=[128, 2], condensed_W=True, use_Minv=False,
+                         param_dtype=torch.bfloat16)
+    assert m.W.dtype == torch.bfloat16 and tuple(m.W.shape) == (64, 128)
+    out = m()
+    params = {n: q.detach().float().cpu() for n, q in m.named_parameters()}
+    ref32, g32, dlogits = _oracle(orc, "gcn", g, At, X, M, edges, labels, params, None, torch.float32)
+    ref64, g64, _ = _oracle(orc, "gcn", g, At, X, M, edges, labels, params, None, torch.float64, dlogits)
+    out.backward(dlogits.cuda())
+    _check(out, ref32, ref64, "S3-wide logits", strict=True)
+    for n, q in m.named_parameters():
+        assert q.grad.dtype == torch.bfloat16
+        assert_close(q.grad.float(), g32[n], 2e-2, "S3-wide d" + n)
+    # the same step with fp32 parameters holding the same values
+    torch.manual_seed(1)
+    w = ehf.EmbeddingGCN(At, X, edges, M, hidden_feat=[128, 2], condensed_W=True, use_Minv=False)
+    with torch.no_grad():
+        for q, qb in zip(w.parameters(), m.parameters()):
+            q.copy_(qb.float())
+    out_w = w()
+    out_w.backward(dlogits.cuda())
+    assert torch.equal(out_w, out), "bf16-operand kernel differs from the widened weight"
+    for (n, q), qb in zip(w.named_parameters(), m.parameters()):
+        assert torch.equal(q.grad.to(torch.bfloat16), qb.grad), n
+
+
 def test_S4_shaped_properties_large():
     T, N, F, deg = 2, 500_000, 128, 32
     dev = "cuda"

@@ -203,6 +203,45 @@ def test_gemm(K, Nf, per_slice, trans_w):
     assert_close(Y, ref_gemm(A, W, trans_w, per_slice), REL_TOL, f"gemm {K}x{Nf}")
 
 
+@pytest.mark.parametrize("K,Nf", [(2, 6), (6, 2), (16, 16), (128, 128), (128, 64), (64, 100), (100, 50), (36, 200),
+                                  (300, 40)])
+@pytest.mark.parametrize("per_slice", [False, True])
+@pytest.mark.parametrize("trans_w", [False, True])
+def test_gemm_bf16_stored_weight(K, Nf, per_slice, trans_w):
+    """tmgcn_gemm_bf16w_f32 (the "bf16 weights" configuration): W enters in bf16, A / Y / accumulation stay
+    fp32.  Against the C oracle on the widened weight at the fp32 tolerance, and bit-identical to the fp32
+    entry on the widened weight in every kernel (the split kernel only drops products with zero planes)."""
+    T, N = 3, 150
+    g = torch.Generator().manual_seed(K * 17 + Nf)
+    A = torch.randn(T, N, K, generator=g)
+    wshape = ((Nf, K) if trans_w else (K, Nf))
+    W = torch.randn(*((T,) + wshape if per_slice else wshape), generator=g).to(torch.bfloat16)
+    Y = ops.kernels.gemm(A.to(DEV), W.to(DEV), trans_w=trans_w)
+    assert Y.dtype == torch.float32
+    assert_close(Y, ref_gemm(A, W.float(), trans_w, per_slice), REL_TOL, f"bf16-W gemm {K}x{Nf}")
+    assert torch.equal(Y, ops.kernels.gemm(A.to(DEV), W.float().to(DEV), trans_w=trans_w)), "differs from the widened weight"
+
+
+def test_gemm_bf16_stored_weight_autograd_and_ragged_tiles():
+    """Gradients with a bf16-stored parameter: dA through the bf16-W kernel (Wᵀ), dW summed in fp32 and
+    rounded once to the parameter's dtype; fused activation; a row count that leaves a ragged last tile."""
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(2, 4099, 128, generator=g).to(DEV)
+    W = (torch.randn(128, 96, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    dY = torch.randn(2, 4099, 96, generator=g).to(DEV)
+    out = {}
+    for name, w in (("bf16", W), ("wide", W.float())):
+        a, w = A.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = ops.feature_gemm(a, w, act="leaky")
+        y.backward(dY)
+        out[name] = (y.detach(), a.grad, w.grad)
+    assert out["bf16"][2].dtype == torch.bfloat16
+    assert torch.equal(out["bf16"][0], out["wide"][0]) and torch.equal(out["bf16"][1], out["wide"][1])
+    assert torch.equal(out["bf16"][2], out["wide"][2].to(torch.bfloat16))
+    ref = torch.nn.functional.leaky_relu(A.double() @ W.double(), 0.01)
+    assert max_rel_err(out["bf16"][0], ref.float()) <= REL_TOL
+
+
 @pytest.mark.parametrize("act", ["relu", "leaky", "selu"])
 @pytest.mark.parametrize("K,Nf", [(2, 6), (128, 128)])
 def test_gemm_fused_activation(act, K, Nf):

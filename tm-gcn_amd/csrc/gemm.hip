@@ -46,11 +46,15 @@ struct GemmArgs {
   int64_t tiles_per_batch;
   int64_t n_tiles;
   unsigned int* tile_counter;  // dynamic tile scheduling (common.h); one counter per blockIdx.y strip
+  int32_t w_bf16;              // W holds bf16 elements (tmgcn_gemm_bf16w_f32): W points at uint16_t
 };
 
-__device__ __forceinline__ float wop(const GemmArgs& a, const float* Wb, int k, int n) {
+// element (k, n) of the operator at element offset woff (the batch's weight) of W, fp32 or bf16 storage
+__device__ __forceinline__ float wop(const GemmArgs& a, int64_t woff, int k, int n) {
   if (k >= a.K || n >= a.Nf) return 0.f;
-  return a.trans_w ? Wb[(int64_t)n * a.K + k] : Wb[(int64_t)k * a.Nf + n];
+  const int64_t i = woff + (a.trans_w ? (int64_t)n * a.K + k : (int64_t)k * a.Nf + n);
+  if (a.w_bf16) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(a.W)[i] << 16);
+  return a.W[i];
 }
 
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
     const int64_t row0 = batch * batch_rows + (tile % a.tiles_per_batch) * BM;
     int64_t row_end = (batch + 1) * batch_rows;
     if (row_end > a.R) row_end = a.R;
-    const float* Wb = a.W + (a.rows_per_batch ? batch * a.w_batch_stride : 0);
+    const int64_t Wb = a.rows_per_batch ? batch * a.w_batch_stride : 0;
 
     f32x16 acc[BM / 32];
 #pragma unroll
@@ -256,6 +260,11 @@ __device__ __forceinline__ void gx_store_rows_v4(const f32x16 (&acc)[2], float* 
     }
 }
 
+// WP = planes of the operator: 3 for an fp32 W (six plane products per term), 1 for a W stored in
+// bf16 (tmgcn_gemm_bf16w_f32: the weight IS its high plane, three products per term, a third of the
+// fragment registers) — the same sums in the same order, so bf16 W gives bit-identical results to
+// its fp32-widened copy at half the matrix-core work.
+template <int WP>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[3 * GX_PLANE];
   const int lane = threadIdx.x & 63;
@@ -275,28 +284,53 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   unsigned char* wr = sm + rg * GX_PITCH + q * 8;
   const unsigned char* rd = sm + li * GX_PITCH + lh * 16;
 
-  unsigned bw[8][3][4];  // B fragments of Wop: [k-step][plane][8 bf16]
+  unsigned bw[8][WP][4];  // B fragments of Wop: [k-step][plane][8 bf16]
   // Wop[k][n] = W[k*sk + n*sn]; this lane's column n0+li, clamped (columns / rows outside are zeroed by
   // the mask, so the 64 loads are unconditional: no exec-mask branches)
   const int ncol = n0 + li < a.Nf ? n0 + li : a.Nf - 1;
   const int sk = a.trans_w ? 1 : a.Nf, sn = a.trans_w ? a.K : 1;
   const float zn = n0 + li < a.Nf ? 1.f : 0.f;
-  auto load_w = [&](const float* Wb) {
+  auto load_w = [&](int64_t woff) {
     int koff = 8 * lh;
     // opaque to the optimiser: otherwise the 64 loop-invariant element offsets are hoisted out of
     // the tile loop into 64 VGPRs (and spilled) for a routine that runs once per weight
     asm volatile("" : "+v"(koff));
-    const float* wl = Wb + (int64_t)ncol * sn;
+    const int64_t wl = woff + (int64_t)ncol * sn;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k = koff + 16 * ks + 2 * j;
         const int k0c = k < a.K ? k : a.K - 1, k1c = k + 1 < a.K ? k + 1 : a.K - 1;
-        const float w0 = wl[(int64_t)k0c * sk] * (k < a.K ? zn : 0.f);
-        const float w1 = wl[(int64_t)k1c * sk] * (k + 1 < a.K ? zn : 0.f);
-        gx_split3(w0, w1, bw[ks][0][j], bw[ks][1][j], bw[ks][2][j]);
+        if constexpr (WP == 3) {
+          const float w0 = a.W[wl + (int64_t)k0c * sk] * (k < a.K ? zn : 0.f);
+          const float w1 = a.W[wl + (int64_t)k1c * sk] * (k + 1 < a.K ? zn : 0.f);
+          gx_split3(w0, w1, bw[ks][0][j], bw[ks][1][j], bw[ks][2][j]);
+        } else {
+          const unsigned short* wh = reinterpret_cast<const unsigned short*>(a.W);
+          const unsigned w0 = (k < a.K && zn != 0.f) ? wh[wl + (int64_t)k0c * sk] : 0u;
+          const unsigned w1 = (k + 1 < a.K && zn != 0.f) ? wh[wl + (int64_t)k1c * sk] : 0u;
+          bw[ks][0][j] = w0 | (w1 << 16);
+        }
       }
+  };
+  // the plane products of one (k-step, row block): small terms first
+  auto products = [&](f32x16& c, const gx_bf16x8 ah, const gx_bf16x8 am, const gx_bf16x8 al, int ks) {
+    const gx_bf16x8 bh = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
+    if constexpr (WP == 3) {
+      const gx_bf16x8 bm = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
+      const gx_bf16x8 bl = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][2][0], bw[ks][2][1], bw[ks][2][2], bw[ks][2][3]));
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    } else {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+    }
   };
 
   // Two staging sets of 8 float4s in RESERVED registers (v192..v255, async_stage.h), filled by
@@ -378,20 +412,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
       const gx_bf16x8 ah = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p));
       const gx_bf16x8 am = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + GX_PLANE));
       const gx_bf16x8 al = __builtin_bit_cast(gx_bf16x8, *reinterpret_cast<const uint4*>(p + 2 * GX_PLANE));
-      const gx_bf16x8 bh = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
-      const gx_bf16x8 bm = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
-      const gx_bf16x8 bl = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][2][0], bw[ks][2][1], bw[ks][2][2], bw[ks][2][3]));
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);  // small terms first
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+      products(acc[mb], ah, am, al, ks);
     }
   };
   auto multiply = [&](const GxTile& tc) {
     if (tc.batch != cur_batch) {
-      load_w(a.W + (a.rows_per_batch ? (int64_t)tc.batch * a.w_batch_stride : 0));
+      load_w(a.rows_per_batch ? (int64_t)tc.batch * a.w_batch_stride : 0);
       cur_batch = tc.batch;
     }
     if (!strip) return;
@@ -424,15 +450,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         const gx_bf16x8 ah = __builtin_bit_cast(gx_bf16x8, cur.h), am = __builtin_bit_cast(gx_bf16x8, cur.m),
                         al = __builtin_bit_cast(gx_bf16x8, cur.l);
-        const gx_bf16x8 bh = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
-        const gx_bf16x8 bm = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
-        const gx_bf16x8 bl = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][2][0], bw[ks][2][1], bw[ks][2][2], bw[ks][2][3]));
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);  // small terms first
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+        products(acc[mb], ah, am, al, ks);
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
       }
@@ -527,8 +545,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
   for (int t = threadIdx.x; t < n_w * a.K * Nfp; t += blockDim.x) {
     const int wb = t / (a.K * Nfp), rem = t % (a.K * Nfp);
     const int k = rem / Nfp, n = rem % Nfp;
-    const float* Wb = a.W + (a.rows_per_batch ? (b_first + wb) * a.w_batch_stride : 0);
-    Ws[t] = wop(a, Wb, k, n);
+    Ws[t] = wop(a, a.rows_per_batch ? (b_first + wb) * a.w_batch_stride : 0, k, n);
   }
   __syncthreads();
   const int64_t r = r_first + threadIdx.x;
@@ -1062,9 +1079,9 @@ static void dw_plan(int64_t R, int64_t rows_per_batch, int64_t* n_batch, int* ch
 
 using namespace tmgcn;
 
-extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* pre_act, int64_t R,
-                               int32_t K, int32_t Nf, int32_t trans_w, int64_t rows_per_batch,
-                               int64_t w_batch_stride, int32_t act, int32_t algo, void* stream) {
+static int gemm_launch(const float* A, const void* W, bool w_bf16, float* Y, float* pre_act, int64_t R,
+                       int32_t K, int32_t Nf, int32_t trans_w, int64_t rows_per_batch,
+                       int64_t w_batch_stride, int32_t act, int32_t algo, void* stream) {
   TMGCN_REQUIRE(R >= 0 && K > 0 && Nf > 0, "gemm: bad shape R=%lld K=%d Nf=%d", (long long)R, K, Nf);
   TMGCN_REQUIRE(algo == TMGCN_GEMM_AUTO || algo == TMGCN_GEMM_F32MFMA, "gemm: unknown algo %d", algo);
   TMGCN_REQUIRE(rows_per_batch >= 0, "gemm: negative rows_per_batch");
@@ -1072,7 +1089,8 @@ extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* p
   if (R == 0) return TMGCN_OK;
   TMGCN_REQUIRE(A && W && Y, "gemm: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  GemmArgs a{A, W, Y, pre_act, R, K, Nf, trans_w, rows_per_batch, w_batch_stride, act, 0, 0, nullptr};
+  GemmArgs a{A, static_cast<const float*>(W), Y, pre_act, R, K, Nf, trans_w, rows_per_batch, w_batch_stride,
+             act, 0, 0, nullptr, w_bf16 ? 1 : 0};
   if (use_small(K, Nf)) {
     const int Nfp = (Nf + 7) & ~7;
     const int64_t br = rows_per_batch ? rows_per_batch : R;
@@ -1093,9 +1111,12 @@ extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* p
   const bool x3 = algo == TMGCN_GEMM_AUTO && K % 4 == 0 && K >= 16 && K <= 128 &&
                   reinterpret_cast<uintptr_t>(A) % 16 == 0;
   if (x3) {  // static persistent schedule: no tile counter
-    int64_t gx = persistent_grid(gemm_bf16x3_kernel, 256);
+    int64_t gx = w_bf16 ? persistent_grid(gemm_bf16x3_kernel<1>, 256) : persistent_grid(gemm_bf16x3_kernel<3>, 256);
     if (gx > a.n_tiles) gx = a.n_tiles;
-    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
+    if (w_bf16)
+      hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(gemm_bf16x3_kernel<3>, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
     return check_launch("gemm_bf16x3");
   }
   // gy consecutive counters of the pool (acquire zeroes one; take gy of them in a row)
@@ -1105,6 +1126,19 @@ extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* p
   if (gx > a.n_tiles) gx = a.n_tiles;
   hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
   return check_launch("gemm_mfma");
+}
+
+extern "C" int tmgcn_gemm_f32(const float* A, const float* W, float* Y, float* pre_act, int64_t R,
+                               int32_t K, int32_t Nf, int32_t trans_w, int64_t rows_per_batch,
+                               int64_t w_batch_stride, int32_t act, int32_t algo, void* stream) {
+  return gemm_launch(A, W, false, Y, pre_act, R, K, Nf, trans_w, rows_per_batch, w_batch_stride, act, algo, stream);
+}
+
+extern "C" int tmgcn_gemm_bf16w_f32(const float* A, const uint16_t* W_bf16, float* Y, float* pre_act, int64_t R,
+                                     int32_t K, int32_t Nf, int32_t trans_w, int64_t rows_per_batch,
+                                     int64_t w_batch_stride, int32_t act, int32_t algo, void* stream) {
+  return gemm_launch(A, W_bf16, true, Y, pre_act, R, K, Nf, trans_w, rows_per_batch, w_batch_stride, act, algo,
+                     stream);
 }
 
 extern "C" int64_t tmgcn_gemm_dw_workspace_bytes(int64_t R, int32_t K, int32_t Nf,

@@ -171,17 +171,24 @@ void spmm_gemm_out(const Tensor& rowptr, const Tensor& col, const Tensor& val, c
 std::tuple<Tensor, Tensor> bgemm(const Tensor& A, const Tensor& W, bool trans_w, int64_t act, bool want_pre,
                                  int64_t algo) {
   want(A, "gemm A");
-  want(W, "gemm W");
+  const bool w_bf16 = W.defined() && W.scalar_type() == at::kBFloat16;  // a parameter stored in bf16
+  want(W, "gemm W", w_bf16 ? at::kBFloat16 : at::kFloat);
   TORCH_CHECK(A.dim() == 3, "gemm: A must be [T,N,K]");
   c10::DeviceGuard g(A.device());
   const int64_t T = A.size(0), N = A.size(1), K = A.size(2);
   const WShape s = w_shape(W, trans_w, T, K, "gemm");
   Tensor Y = at::empty({T, N, s.wn}, A.options());
   Tensor pre = (want_pre && act != TMGCN_ACT_NONE) ? at::empty_like(Y) : Tensor();
-  ok(tmgcn_gemm_f32((const float*)ptr(A), (const float*)ptr(W), (float*)ptr(Y), (float*)ptr(pre), T * N,
-                    (int32_t)K, (int32_t)s.wn, trans_w ? 1 : 0, s.per_slice ? N : 0, s.stride, (int32_t)act,
-                    (int32_t)algo, stream_of(A)),
-     "tmgcn_gemm_f32");
+  if (w_bf16)
+    ok(tmgcn_gemm_bf16w_f32((const float*)ptr(A), (const uint16_t*)ptr(W), (float*)ptr(Y), (float*)ptr(pre), T * N,
+                            (int32_t)K, (int32_t)s.wn, trans_w ? 1 : 0, s.per_slice ? N : 0, s.stride,
+                            (int32_t)act, (int32_t)algo, stream_of(A)),
+       "tmgcn_gemm_bf16w_f32");
+  else
+    ok(tmgcn_gemm_f32((const float*)ptr(A), (const float*)ptr(W), (float*)ptr(Y), (float*)ptr(pre), T * N,
+                      (int32_t)K, (int32_t)s.wn, trans_w ? 1 : 0, s.per_slice ? N : 0, s.stride, (int32_t)act,
+                      (int32_t)algo, stream_of(A)),
+       "tmgcn_gemm_f32");
   return {Y, pre.defined() ? pre : none_like(A)};
 }
 
@@ -370,7 +377,10 @@ struct FeatureGemmFn : public torch::autograd::Function<FeatureGemmFn> {
     if (act != TMGCN_ACT_NONE) dY = act_bwd(pre, dY, act);
     Tensor dA, dW;
     if (ctx->needs_input_grad(0)) dA = std::get<0>(bgemm(dY, W, true, TMGCN_ACT_NONE, false, TMGCN_GEMM_AUTO));
-    if (ctx->needs_input_grad(1)) dW = bgemm_dW(A, dY, W.dim() == 3, TMGCN_DW_AUTO);
+    if (ctx->needs_input_grad(1)) {
+      dW = bgemm_dW(A, dY, W.dim() == 3, TMGCN_DW_AUTO);  // summed in fp32, rounded once for a bf16 parameter
+      if (dW.scalar_type() != W.scalar_type()) dW = dW.to(W.scalar_type());
+    }
     return {dA, dW, Tensor()};
   }
 };

@@ -130,10 +130,13 @@ class _Sharding:
         """M (or M⁻¹) applied to a slice-sharded activation: the one exchange of that layer."""
         return ops.m_transform(Y, op) if self._shard is None else self._shard.m_transform(Y, op)
 
-    def _p(self, param: torch.Tensor, per_slice: bool = False) -> torch.Tensor:
+    def _p(self, param: torch.Tensor, per_slice: bool = False, gemm: bool = False) -> torch.Tensor:
         """A parameter as the kernels take it: fp32, gradient summed over the ranks when sharded,
-        and — for one-weight-per-slice parameters — this rank's slices."""
-        w = _w(param)
+        and — for one-weight-per-slice parameters — this rank's slices.  ``gemm``: the consumer is
+        the standalone P3 kernel, which takes a bf16-stored weight as it is (three plane products
+        instead of six, ops.HipKernels.gemm); the sharded model still widens, so that the gradient
+        is all-reduced in fp32 and rounded once."""
+        w = param if (gemm and self._shard is None and param.dtype == torch.bfloat16) else _w(param)
         if self._shard is not None:
             w = self._shard.shared(w)
             if per_slice:
@@ -199,7 +202,7 @@ class EmbeddingGCN(_Deliver, _Sharding, nn.Module):
             eidx = self._edge_index(edges, self.dev)
         else:
             AtXt, eidx = self.AtXt, self._edges
-        Y = ops.feature_gemm(AtXt, self._p(self.W, per_slice=not self.condensed_W))   # ehf:222
+        Y = ops.feature_gemm(AtXt, self._p(self.W, per_slice=not self.condensed_W, gemm=True))   # ehf:222
         if self.use_Minv:
             Y = self._mt(Y, self.Minv)                                       # ehf:224
         return self._deliver(self._head(Y, eidx, self._p(self.U)))
@@ -282,7 +285,7 @@ class EmbeddingGCN2(_Deliver, _Sharding, nn.Module):
         else:
             AtXt, eidx = self.AtXt, self._edges
         ps = not self.condensed_W
-        W1, W2, U = self._p(self.W1, ps), self._p(self.W2, ps), self._p(self.U)
+        W1, W2, U = self._p(self.W1, ps, gemm=True), self._p(self.W2, ps), self._p(self.U)
         # first layer (ehf:330-335)
         if self.use_Minv:
             Y = ops.activation(self._mt(ops.feature_gemm(AtXt, W1), self.Minv), self.nonlin2)
@@ -358,8 +361,8 @@ class EmbeddingKWGCN(_Deliver, _Sharding, nn.Module):
         else:
             AX, eidx = self.AX, self._edges
         if self.no_layers == 2:
-            Y = ops.feature_gemm(AX, self._p(self.W1), act=self.nonlin2)           # ehf:486
+            Y = ops.feature_gemm(AX, self._p(self.W1, gemm=True), act=self.nonlin2)  # ehf:486
             Z = ops.spmm_feature_gemm(self.A, Y, self._p(self.W2))                 # ehf:487
         else:
-            Z = ops.feature_gemm(AX, self._p(self.W1))                             # ehf:489
+            Z = ops.feature_gemm(AX, self._p(self.W1, gemm=True))                  # ehf:489
         return self._deliver(self._head(Z, eidx, self._p(self.U)))

@@ -203,7 +203,8 @@ class HipKernels:
 
     # P3 ---------------------------------------------------------------------------------
     def gemm(self, A: torch.Tensor, W: torch.Tensor, trans_w=False, act=None, want_pre=False, algo=None):
-        """A [T,N,K] · W ([K,Nf] shared or [T,K,Nf] per slice; transposed if trans_w).
+        """A [T,N,K] · W ([K,Nf] shared or [T,K,Nf] per slice; transposed if trans_w).  W may be stored
+        in bf16 (tmgcn_gemm_bf16w_f32: half the matrix-core work, same bits as its fp32-widened copy).
         algo: None / "auto" (bf16x3 split on the bf16 matrix cores for K a multiple of 4 in [16,128])
         or "f32mfma" (exact-f32 MFMA: bitwise an fmaf chain) — per call."""
         Y, pre = self._run("gemm_dA" if trans_w else "gemm", A.device, lambda: self.ops.bgemm(
@@ -291,6 +292,8 @@ class _FeatureGemm(torch.autograd.Function):
             A, W = ctx.saved_tensors
         dA = kernels.gemm(dY, W, trans_w=True) if ctx.needs_input_grad[0] else None
         dW = kernels.gemm_dw(A, dY, per_slice=W.dim() == 3) if ctx.needs_input_grad[1] else None
+        if dW is not None and dW.dtype != W.dtype:
+            dW = dW.to(W.dtype)              # a bf16-stored parameter: summed in fp32, rounded once
         return dA, dW, None
 
 

@@ -16,6 +16,8 @@ p, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
 def load(path):
     lib = C.CDLL(path)
     lib.tmgcn_gemm_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i64, i64, i32, i32, p]
+    if hasattr(lib, "tmgcn_gemm_bf16w_f32"):
+        lib.tmgcn_gemm_bf16w_f32.argtypes = [p, p, p, p, i64, i32, i32, i32, i64, i64, i32, i32, p]
     lib.tmgcn_gemm_dw_f32.argtypes = [p, p, p, i64, i32, i32, i64, i32, p, i64, p]
     lib.tmgcn_gemm_dw_workspace_bytes.restype = i64
     lib.tmgcn_gemm_dw_workspace_bytes.argtypes = [i64, i32, i32, i64]
@@ -30,6 +32,7 @@ for n in names:
 R, K, Nf = 8_000_000, 128, 128
 A = torch.rand(R, K, device="cuda")
 W = torch.randn(K, Nf, device="cuda")
+Wh = W.to(torch.bfloat16)
 dY = torch.rand(R, Nf, device="cuda")
 Y = torch.empty(R, Nf, device="cuda")
 dW = torch.empty(K, Nf, device="cuda")
@@ -43,11 +46,15 @@ def run(lib, which):
         return lib.tmgcn_gemm_f32(ptr(A), ptr(W), ptr(Y), None, R, K, Nf, 0, 0, 0, 0, ALGO, st)
     if which == "gemm_dA":
         return lib.tmgcn_gemm_f32(ptr(dY), ptr(W), ptr(Y), None, R, Nf, K, 1, 0, 0, 0, ALGO, st)
+    if which == "gemm_bf16w":      # weight stored in bf16: three plane products per term
+        if not hasattr(lib, "tmgcn_gemm_bf16w_f32"):
+            return 0
+        return lib.tmgcn_gemm_bf16w_f32(ptr(A), ptr(Wh), ptr(Y), None, R, K, Nf, 0, 0, 0, 0, ALGO, st)
     return lib.tmgcn_gemm_dw_f32(ptr(A), ptr(dY), ptr(dW), R, K, Nf, 0, 0, ptr(ws), ws.numel(), st)
 
 
 res = {}
-for which in ("gemm", "gemm_dA", "gemm_dW"):
+for which in ("gemm", "gemm_bf16w", "gemm_dA", "gemm_dW"):
     for lib in libs.values():
         assert run(lib, which) == 0
     torch.cuda.synchronize()
@@ -62,4 +69,4 @@ for which in ("gemm", "gemm_dA", "gemm_dW"):
 fl = 2.0 * R * K * Nf
 for (which, name), ms in res.items():
     med = statistics.median(ms)
-    print(f"{which:8s} {name:14s} median {med:6.2f} ms  {fl / med / 1e9:6.1f} TFLOP/s  {(R * (K + Nf) * 4) / med / 1e6:6.0f} GB/s")
+    print(f"{which:10s} {name:14s} median {med:6.2f} ms  {fl / med / 1e9:6.1f} TFLOP/s  {(R * (K + Nf) * 4) / med / 1e6:6.0f} GB/s")

@@ -19,6 +19,25 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.j
          "-mllvm", "-pragma-unroll-threshold=200000", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only"]
 
 
+def scan(body, first):
+    """(highest VGPR named, offending lines) of the compiler-generated instructions of one kernel body."""
+    inasm, top, hits = False, 0, []
+    for line in body.split("\n"):
+        if "ASMSTART" in line:
+            inasm = True
+        elif "ASMEND" in line:
+            inasm = False
+        elif not inasm:
+            regs = [int(x) for x in re.findall(r"\bv(\d+)\b", line)]
+            for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", line):
+                regs += [int(a), int(b)]
+            if regs:
+                top = max(top, max(regs))
+                if max(regs) >= first:
+                    hits.append(line.strip())
+    return top, hits
+
+
 def main():
     bad = 0
     for src, kernels in KERNELS.items():
@@ -27,28 +46,15 @@ def main():
             subprocess.check_call(["hipcc", *FLAGS, os.path.join(CSRC, src), "-o", out], stderr=subprocess.DEVNULL)
             text = open(out).read()
         for frag, first in kernels.items():
-            m = re.search(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)s_endpgm" % frag, text, re.S | re.M)
-            if not m:
+            found = list(re.finditer(r"^(_Z\w*%s\w*):[^\n]*\n(.*?)s_endpgm" % frag, text, re.S | re.M))
+            if not found:
                 print(f"{src}: kernel {frag} not found")
                 bad += 1
-                continue
-            inasm, top, hits = False, 0, []
-            for line in m.group(2).split("\n"):
-                if "ASMSTART" in line:
-                    inasm = True
-                elif "ASMEND" in line:
-                    inasm = False
-                elif not inasm:
-                    regs = [int(x) for x in re.findall(r"\bv(\d+)\b", line)]
-                    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", line):
-                        regs += [int(a), int(b)]
-                    if regs:
-                        top = max(top, max(regs))
-                        if max(regs) >= first:
-                            hits.append(line.strip())
-            print(f"{frag}: compiler code uses v0..v{top}, reserved zone starts at v{first}: "
-                  f"{'OK' if not hits else f'{len(hits)} VIOLATIONS, e.g. ' + hits[0]}")
-            bad += bool(hits)
+            for m in found:  # every instantiation of a templated kernel
+                top, hits = scan(m.group(2), first)
+                print(f"{m.group(1)}: compiler code uses v0..v{top}, reserved zone starts at v{first}: "
+                      f"{'OK' if not hits else f'{len(hits)} VIOLATIONS, e.g. ' + hits[0]}")
+                bad += bool(hits)
     return 1 if bad else 0
 
 
