@@ -219,8 +219,9 @@ EPOCH_MODELS = {  # the scripts' model per config
 
 
 def gpu_epochs(g, spec, epochs, mode):
-    """Seconds per training epoch (zero_grad, gcn(), weighted CE, backward, SGD step — the loop of
-    experiment_reddit_our_link_prediction.py:75-81) on the device.
+    """(first loss, median-pass and fastest-pass seconds per training epoch) — zero_grad, gcn(),
+    weighted CE, backward, SGD step: the loop of experiment_reddit_our_link_prediction.py:75-81 —
+    on the device; five timed passes of `epochs` epochs each.
     mode: "eager"   device targets + nn.CrossEntropyLoss on device logits
           "graph"   the same epoch captured into one hipGraph and replayed
           "fused"   eager with tmgcn_amd.WeightedCrossEntropy (the opt-in fused loss)
@@ -272,12 +273,20 @@ def gpu_epochs(g, spec, epochs, mode):
         run = step
     else:
         run = epoch
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(epochs):
-        run()
-    torch.cuda.synchronize()
-    return first, (time.perf_counter() - t0) / epochs
+    # sub-millisecond epochs: one pass of `epochs` epochs lasts 15-250 ms, short enough for a clock
+    # ramp or a host hiccup to double it (measured: the same mode 0.28 / 0.92 / 1.45 ms depending
+    # on what ran before it).  Time five passes after a pass of warm-up; report the median pass.
+    passes = []
+    for rep in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(epochs):
+            run()
+        torch.cuda.synchronize()
+        if rep:
+            passes.append((time.perf_counter() - t0) / epochs)
+    passes.sort()
+    return first, passes[len(passes) // 2], passes[0]
 
 
 def cpu_epochs(g, spec, epochs, threads):
@@ -329,12 +338,13 @@ def epochs_block(args, configs=("S1", "S2", "S3"), modes=("eager", "graph", "fus
         spec = EPOCH_MODELS[name]
         g = synth.dynamic_graph(**synth.CONFIGS[name], seed=0)
         rec = {"model": spec["kind"], "T": g.T, "N": g.N, "E": int(g.edges.shape[1]),
-               "nnz_At": int(sum(c.nnz for c in g.Ct)), "gpu_epochs_timed": args.epoch_reps,
+               "nnz_At": int(sum(c.nnz for c in g.Ct)), "gpu_epochs_timed": args.epoch_reps, "gpu_passes": 5,
                "cpu_epochs_timed": args.cpu_epoch_reps}
         loss_gpu = None
         for mode in modes:
-            first, sec = gpu_epochs(g, spec, args.epoch_reps, mode)
+            first, sec, sec_min = gpu_epochs(g, spec, args.epoch_reps, mode)
             rec[f"gpu_ms_{mode}"] = round(sec * 1e3, 4)
+            rec.setdefault("gpu_ms_min_pass", {})[mode] = round(sec_min * 1e3, 4)
             loss_gpu = first if loss_gpu is None else loss_gpu
         rec["first_loss_gpu"] = loss_gpu
         if args.cpu_epoch_reps > 0:

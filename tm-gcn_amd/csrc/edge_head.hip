@@ -69,6 +69,46 @@ __global__ __launch_bounds__(256) void edge_head_fwd_kernel(EdgeArgs a) {
   }
 }
 
+// Narrow heads (the reference's: F = 6 or 2, C = 2): one edge per lane with both widths known at
+// compile time — the 2·FT/2 row loads are 8-byte vectors all in flight at once, U is read through
+// uniform (scalar) loads into SGPRs, the CT logits leave as one vector store.  Needs an 8-byte
+// aligned Z (and out for CT = 2 / 4): checked by the launcher.
+template <int FT, int CT>
+__global__ __launch_bounds__(256) void edge_head_fwd_small_kernel(EdgeArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.E) return;
+  const float2* zs = reinterpret_cast<const float2*>(a.Z + a.src[e] * FT);
+  const float2* zd = reinterpret_cast<const float2*>(a.Z + a.dst[e] * FT);
+  float2 s[FT / 2], d[FT / 2];
+#pragma unroll
+  for (int i = 0; i < FT / 2; ++i) {
+    s[i] = zs[i];
+    d[i] = zd[i];
+  }
+  const float* __restrict__ U = a.U;
+  float acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int i = 0; i < FT / 2; ++i)  // same order of accumulation as the generic kernel: f ascending, src then dst
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = 2 * i + h;
+      const float sv = h ? s[i].y : s[i].x, dv = h ? d[i].y : d[i].x;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[c] = fmaf(dv, U[(FT + f) * CT + c], fmaf(sv, U[f * CT + c], acc[c]));
+    }
+  float* o = a.out + e * CT;
+  if constexpr (CT == 2) {
+    *reinterpret_cast<float2*>(o) = make_float2(acc[0], acc[1]);
+  } else if constexpr (CT == 4) {
+    *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) o[c] = acc[c];
+  }
+}
+
 struct EdgeBwdArgs {
   const float* Z;
   const int64_t* src;
@@ -86,7 +126,9 @@ struct EdgeBwdArgs {
   int32_t du_edges;      // edges per LDS tile of the dU kernel
 };
 
-// G lanes per row: every lane of the group sums the row's incident dout rows (broadcast loads),
+// G lanes per row: the lanes split the row's incident entries (lane gl takes entries gl, gl+G, ...:
+// G independent chains of dependent index -> dout loads instead of one), the partial sums are
+// combined with an xor butterfly — every lane ends with the same bits, in an order fixed by G —
 // then lane gl writes features gl, gl+G, ...
 template <int G>
 __global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
@@ -100,7 +142,8 @@ __global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
   double S[2][kMaxC];
 #pragma unroll
   for (int c = 0; c < kMaxC; ++c) S[0][c] = S[1][c] = 0.0;
-  for (int64_t p = a.eptr[r]; p < a.eptr[r + 1]; ++p) {
+  const int64_t p_end = a.eptr[r + 1];
+  for (int64_t p = a.eptr[r] + gl; p < p_end; p += G) {
     const int64_t x = a.eidx[p];
     const float* g = a.dout + (x >> 1) * a.C;
     const bool is_dst = x & 1;
@@ -110,6 +153,16 @@ __global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
         const double v = (double)g[c];
         if (is_dst) S[1][c] += v; else S[0][c] += v;
       }
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1)
+#pragma unroll
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < a.C) {
+          S[0][c] += __shfl_xor(S[0][c], o);
+          S[1][c] += __shfl_xor(S[1][c], o);
+        }
   }
   float s0[kMaxC], s1[kMaxC];
 #pragma unroll
@@ -195,23 +248,118 @@ __global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
   }
 }
 
-// one wave per output element: lanes stride over the chunk slabs, fixed butterfly
+// dU slabs for narrow heads (2·FT·CT <= 64 outputs): every lane keeps ALL outputs of its own edges
+// (edge e0 + t, e0 + t + 256, ... of the block's chunk) in fp64 registers — no LDS staging, no
+// barrier inside the edge loop, the row / dout loads of successive edges are independent — and the
+// block folds them once at the end: xor butterfly inside each wave, then the four waves in order.
+template <int FT, int CT>
+__global__ __launch_bounds__(256) void edge_head_du_small_kernel(EdgeBwdArgs a) {
+  constexpr int K = 2 * FT, NO = K * CT;
+  __shared__ double red[4][NO];
+  const int64_t e0 = (int64_t)blockIdx.x * a.edges_per_chunk;
+  int64_t e1 = e0 + a.edges_per_chunk;
+  if (e1 > a.E) e1 = a.E;
+  double acc[K][CT];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[k][c] = 0.0;
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+    const float2* zs = reinterpret_cast<const float2*>(a.Z + a.src[e] * FT);
+    const float2* zd = reinterpret_cast<const float2*>(a.Z + a.dst[e] * FT);
+    float z[K], g[CT];
+#pragma unroll
+    for (int i = 0; i < FT / 2; ++i) {
+      const float2 sv = zs[i], dv = zd[i];
+      z[2 * i] = sv.x;
+      z[2 * i + 1] = sv.y;
+      z[FT + 2 * i] = dv.x;
+      z[FT + 2 * i + 1] = dv.y;
+    }
+    if constexpr (CT == 2) {
+      const float2 gv = *reinterpret_cast<const float2*>(a.dout + e * CT);
+      g[0] = gv.x;
+      g[1] = gv.y;
+    } else {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) g[c] = a.dout[e * CT + c];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[k][c] = fma((double)z[k], (double)g[c], acc[k][c]);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      double v = acc[k][c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) red[wave][k * CT + c] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < NO)
+    a.part[(int64_t)blockIdx.x * NO + threadIdx.x] =
+        (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+}
+
+// one block per output element: the 256 threads stride over the chunk slabs, xor butterfly per wave,
+// the four waves in order (a fixed summation order)
 __global__ __launch_bounds__(256) void edge_head_du_reduce_kernel(const float* __restrict__ part,
                                                                    float* __restrict__ dU, int n_out, int chunks) {
-  const int lane = threadIdx.x & 63;
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (o >= n_out) return;  // whole wave
+  __shared__ double sh[4];
+  const int o = blockIdx.x;
   double s = 0.0;
-  for (int c = lane; c < chunks; c += kWave) s += (double)part[(int64_t)c * n_out + o];
+  for (int c = threadIdx.x; c < chunks; c += 256) s += (double)part[(int64_t)c * n_out + o];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) dU[o] = (float)s;
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dU[o] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
 static int lanes_per_item(int F) {  // G: 1 for the real (tiny) heads, up to 64 lanes for wide ones
   if (F <= 8) return 1;
   int g = 2;
   while (g < 64 && g * 4 < F) g <<= 1;
+  return g;
+}
+
+// narrow-head kernels: even F <= 8, C <= 4, 8-byte aligned operands
+static bool small_head(int F, int C, const void* Z, const void* io) {
+  return F >= 2 && F <= 8 && F % 2 == 0 && C >= 1 && C <= 4 && reinterpret_cast<uintptr_t>(Z) % 8 == 0 &&
+         reinterpret_cast<uintptr_t>(io) % 16 == 0;
+}
+#define TMGCN_HEAD_C(KERNEL, FT, ...)                                                           \
+  switch (C) {                                                                                  \
+    case 1: hipLaunchKernelGGL((KERNEL<FT, 1>), __VA_ARGS__); break;                            \
+    case 2: hipLaunchKernelGGL((KERNEL<FT, 2>), __VA_ARGS__); break;                            \
+    case 3: hipLaunchKernelGGL((KERNEL<FT, 3>), __VA_ARGS__); break;                            \
+    default: hipLaunchKernelGGL((KERNEL<FT, 4>), __VA_ARGS__);                                  \
+  }
+#define TMGCN_HEAD_FC(KERNEL, ...)                                                              \
+  switch (F) {                                                                                  \
+    case 2: TMGCN_HEAD_C(KERNEL, 2, __VA_ARGS__) break;                                         \
+    case 4: TMGCN_HEAD_C(KERNEL, 4, __VA_ARGS__) break;                                         \
+    case 6: TMGCN_HEAD_C(KERNEL, 6, __VA_ARGS__) break;                                         \
+    default: TMGCN_HEAD_C(KERNEL, 8, __VA_ARGS__)                                               \
+  }
+
+#ifndef TMGCN_DZ_CHAIN
+#define TMGCN_DZ_CHAIN 2   // entries per lane aimed at (A/B: tools/ab_edge_head.py, profiles/r02x_ab_edge_head.txt)
+#endif
+#ifndef TMGCN_DZ_MAXG
+#define TMGCN_DZ_MAXG 32
+#endif
+// lanes per row of the dZ kernel: at least the feature lanes, and enough to split a row's incident
+// entries (avg = 2E/R) into chains of about two
+static int dz_lanes(int F, int64_t E, int64_t R) {
+  int g = F <= 8 ? 1 : 2;
+  while (F > 8 && g < 64 && g * 4 < F) g <<= 1;
+  const int64_t avg = R > 0 ? (2 * E + R - 1) / R : 0;
+  while (g < TMGCN_DZ_MAXG && (int64_t)g * TMGCN_DZ_CHAIN < avg) g <<= 1;
   return g;
 }
 
@@ -256,6 +404,10 @@ extern "C" int tmgcn_edge_head_fwd_f32(const float* Z, const int64_t* src, const
   const int G = lanes_per_item(F);
   const unsigned grid = (unsigned)((E * G + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
+  if (small_head(F, C, Z, out)) {
+    TMGCN_HEAD_FC(edge_head_fwd_small_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, a)
+    return check_launch("edge_head_fwd_small");
+  }
   switch (G) {
     case 1: hipLaunchKernelGGL(edge_head_fwd_kernel<1>, dim3(grid), dim3(256), smem, st, a); break;
     case 2: hipLaunchKernelGGL(edge_head_fwd_kernel<2>, dim3(grid), dim3(256), smem, st, a); break;
@@ -291,7 +443,7 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
   if (dZ && R > 0) {
     TMGCN_REQUIRE(eptr && (E == 0 || (eidx && dout)) && U, "edge_head_bwd: null pointer (dZ)");
     const size_t smem = (size_t)2 * F * C * sizeof(float);
-    const int G = lanes_per_item(F);
+    const int G = dz_lanes(F, E, R);
     const unsigned grid = (unsigned)((R * G + 255) / 256);
     switch (G) {
       case 1: hipLaunchKernelGGL(edge_head_dz_kernel<1>, dim3(grid), dim3(256), smem, st, a); break;
@@ -316,12 +468,16 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
       set_error("edge_head_bwd: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
       return TMGCN_ERR_WORKSPACE;
     }
-    const size_t smem = (size_t)a.du_edges * (2 * F + C) * sizeof(float);
-    hipLaunchKernelGGL(edge_head_du_kernel, dim3((unsigned)chunks), dim3(256), smem, st, a);
+    if (small_head(F, C, Z, dout)) {
+      TMGCN_HEAD_FC(edge_head_du_small_kernel, dim3((unsigned)chunks), dim3(256), 0, st, a)
+    } else {
+      const size_t smem = (size_t)a.du_edges * (2 * F + C) * sizeof(float);
+      hipLaunchKernelGGL(edge_head_du_kernel, dim3((unsigned)chunks), dim3(256), smem, st, a);
+    }
     int rc = check_launch("edge_head_du");
     if (rc) return rc;
     const int n_out = 2 * F * C;
-    hipLaunchKernelGGL(edge_head_du_reduce_kernel, dim3((n_out + 3) / 4), dim3(256), 0, st,
+    hipLaunchKernelGGL(edge_head_du_reduce_kernel, dim3(n_out), dim3(256), 0, st,
                        (const float*)workspace, dU, n_out, chunks);
     return check_launch("edge_head_du_reduce");
   }

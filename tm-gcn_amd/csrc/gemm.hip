@@ -1055,6 +1055,26 @@ __global__ __launch_bounds__(256) void gemm_dw_reduce_kernel(const float* __rest
   if (w == 0 && in) dW[idx] = (float)((sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]));
 }
 
+// The same reduction for narrow layers (a handful of outputs, hundreds of slabs — the scripts' 2x6
+// and 6x2 weights): one block per output, its 256 threads stride over the slabs, xor butterfly per
+// wave, the four waves in order.  The kernel above would walk the slabs as one serial chain of
+// dependent-latency loads per wave (30 us for 12 outputs x 483 slabs, measured).
+__global__ __launch_bounds__(256) void gemm_dw_reduce_narrow_kernel(const float* __restrict__ part,
+                                                                     float* __restrict__ dW, int64_t n_out,
+                                                                     int32_t chunks) {
+  __shared__ double sh[4];
+  const int64_t idx = blockIdx.x;  // flat (batch, output)
+  const int64_t b = idx / n_out, o = idx % n_out;
+  const float* p = part + b * chunks * n_out + o;
+  double s = 0.0;
+  for (int c = threadIdx.x; c < chunks; c += 256) s += (double)p[(int64_t)c * n_out];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dW[idx] = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
 static bool use_small(int K, int Nf) { return (K < 16 || Nf < 16) && K <= 64 && Nf <= 64; }
 
 static void dw_plan(int64_t R, int64_t rows_per_batch, int64_t* n_batch, int* chunks,
@@ -1190,7 +1210,11 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
   if (rc) return rc;
   const int64_t n_out = (int64_t)K * Nf;
   const int64_t total = nb * n_out;
-  hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
-                     (const float*)workspace, dW, n_out, chunks, total);
+  if (total <= 1024 && chunks >= 64)
+    hipLaunchKernelGGL(gemm_dw_reduce_narrow_kernel, dim3((unsigned)total), dim3(256), 0, st, (const float*)workspace,
+                       dW, n_out, chunks);
+  else
+    hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st,
+                       (const float*)workspace, dW, n_out, chunks, total);
   return check_launch("gemm_dw_reduce");
 }

@@ -25,22 +25,43 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// one row of logits; CT = 2 / 4: the class count is known at compile time and the row is one
+// 8- / 16-byte vector (alignment checked by the launcher), CT = 0: C <= kLossMaxC at run time
+template <int CT>
+__device__ __forceinline__ void load_logits(const float* __restrict__ z, int64_t e, int C, float (&v)[kLossMaxC]) {
+  if constexpr (CT == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(z + 2 * e);
+    v[0] = t.x;
+    v[1] = t.y;
+  } else if constexpr (CT == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(z + 4 * e);
+    v[0] = t.x;
+    v[1] = t.y;
+    v[2] = t.z;
+    v[3] = t.w;
+  } else {
+    const float* ze = z + e * C;
+#pragma unroll
+    for (int c = 0; c < kLossMaxC; ++c)
+      if (c < C) v[c] = ze[c];
+  }
+}
+
 // partial[b] = {Σ w·nll, Σ w} over the edges of block b (grid-stride, fixed assignment)
+template <int CT>
 __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ tgt,
                                                        const float* __restrict__ w, int64_t E, int C,
                                                        int64_t ignore_index, double* __restrict__ partial) {
   __shared__ double sh[4];
+  if (CT) C = CT;
   double num = 0.0, den = 0.0;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
-    const float* ze = z + e * C;
     float v[kLossMaxC];
+    load_logits<CT>(z, e, C, v);
     float mx = -INFINITY;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)
-      if (c < C) {
-        v[c] = ze[c];
-        mx = fmaxf(mx, v[c]);
-      }
+      if (c < C) mx = fmaxf(mx, v[c]);
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)
@@ -90,22 +111,26 @@ __global__ __launch_bounds__(64) void wce_finish_kernel(const double* __restrict
 }
 
 // dz[e][c] = g · w[t_e]/den · (softmax(z_e)[c] − [c == t_e])
+template <int CT>
 __global__ __launch_bounds__(256) void wce_bwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ tgt,
                                                        const float* __restrict__ w, const double* __restrict__ stats,
                                                        const float* __restrict__ gout, int64_t E, int C,
                                                        int64_t ignore_index, float* __restrict__ dz) {
+  if (CT) C = CT;
   const float g = gout[0];
   const double den = stats[1];
+  // g·w[c]/den once per class, not once per edge (an fp64 division).  den is NaN when the forward
+  // met an invalid label: every valid row's gradient is NaN then
+  float cls_scale[kLossMaxC];
+#pragma unroll
+  for (int c = 0; c < kLossMaxC; ++c) cls_scale[c] = c < C ? (float)((double)g * (double)w[c] / den) : 0.f;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
-    const float* ze = z + e * C;
     float v[kLossMaxC];
+    load_logits<CT>(z, e, C, v);
     float mx = -INFINITY;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)
-      if (c < C) {
-        v[c] = ze[c];
-        mx = fmaxf(mx, v[c]);
-      }
+      if (c < C) mx = fmaxf(mx, v[c]);
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)
@@ -116,13 +141,33 @@ __global__ __launch_bounds__(256) void wce_bwd_kernel(const float* __restrict__ 
     const int64_t t64 = tgt[e];
     const bool valid = t64 >= 0 && t64 < C;
     const int t = valid ? (int)t64 : 0;
-    // den is NaN when the forward met an invalid label: every valid row's gradient is NaN then
-    const float scale = valid ? (float)((double)g * (double)w[t] / den) : (t64 == ignore_index ? 0.f : NAN);
+    float wt = 0.f;
+#pragma unroll
+    for (int c = 0; c < kLossMaxC; ++c)
+      if (c == t) wt = cls_scale[c];
+    const float scale = valid ? wt : (t64 == ignore_index ? 0.f : NAN);
     const float inv = 1.f / s;
 #pragma unroll
     for (int c = 0; c < kLossMaxC; ++c)
-      if (c < C) dz[e * C + c] = scale * (v[c] * inv - (c == t ? 1.f : 0.f));
+      if (c < C) v[c] = scale * (v[c] * inv - (c == t ? 1.f : 0.f));
+    if constexpr (CT == 2) {
+      *reinterpret_cast<float2*>(dz + 2 * e) = make_float2(v[0], v[1]);
+    } else if constexpr (CT == 4) {
+      *reinterpret_cast<float4*>(dz + 4 * e) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < kLossMaxC; ++c)
+        if (c < C) dz[e * C + c] = v[c];
+    }
   }
+}
+
+// compile-time class count of the vector kernels (0: generic) for these operands
+static int vector_classes(int C, const void* a, const void* b) {
+  const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b);
+  if (C == 2 && al % 8 == 0) return 2;
+  if (C == 4 && al % 16 == 0) return 4;
+  return 0;
 }
 
 static int loss_blocks(int64_t E) {
@@ -152,8 +197,11 @@ extern "C" int tmgcn_wce_fwd_f32(const float* logits, const int64_t* target, con
   }
   hipStream_t st = (hipStream_t)stream;
   const int nb = loss_blocks(E);
-  hipLaunchKernelGGL(wce_fwd_kernel, dim3(nb), dim3(256), 0, st, logits, target, weight, E, C, ignore_index,
-                     (double*)workspace);
+  switch (vector_classes(C, logits, logits)) {
+    case 2: hipLaunchKernelGGL(wce_fwd_kernel<2>, dim3(nb), dim3(256), 0, st, logits, target, weight, E, C, ignore_index, (double*)workspace); break;
+    case 4: hipLaunchKernelGGL(wce_fwd_kernel<4>, dim3(nb), dim3(256), 0, st, logits, target, weight, E, C, ignore_index, (double*)workspace); break;
+    default: hipLaunchKernelGGL(wce_fwd_kernel<0>, dim3(nb), dim3(256), 0, st, logits, target, weight, E, C, ignore_index, (double*)workspace);
+  }
   hipLaunchKernelGGL(wce_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, nb, loss_out, stats_out);
   return check_launch("wce_fwd");
 }
@@ -163,7 +211,12 @@ extern "C" int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, con
                                   int64_t ignore_index, float* dlogits, void* stream) {
   TMGCN_REQUIRE(E > 0 && C >= 1 && C <= kLossMaxC, "wce_bwd: bad shape");
   TMGCN_REQUIRE(logits && target && weight && stats && grad_loss && dlogits, "wce_bwd: null pointer");
-  hipLaunchKernelGGL(wce_bwd_kernel, dim3(loss_blocks(E) * 2), dim3(256), 0, (hipStream_t)stream, logits, target,
-                     weight, stats, grad_loss, E, C, ignore_index, dlogits);
+  const dim3 grid(loss_blocks(E) * 2);
+  hipStream_t st = (hipStream_t)stream;
+  switch (vector_classes(C, logits, dlogits)) {
+    case 2: hipLaunchKernelGGL(wce_bwd_kernel<2>, grid, dim3(256), 0, st, logits, target, weight, stats, grad_loss, E, C, ignore_index, dlogits); break;
+    case 4: hipLaunchKernelGGL(wce_bwd_kernel<4>, grid, dim3(256), 0, st, logits, target, weight, stats, grad_loss, E, C, ignore_index, dlogits); break;
+    default: hipLaunchKernelGGL(wce_bwd_kernel<0>, grid, dim3(256), 0, st, logits, target, weight, stats, grad_loss, E, C, ignore_index, dlogits);
+  }
   return check_launch("wce_bwd");
 }
