@@ -225,6 +225,7 @@ def gpu_epochs(g, spec, epochs, mode):
     mode: "eager"   device targets + nn.CrossEntropyLoss on device logits
           "graph"   the same epoch captured into one hipGraph and replayed
           "fused"   eager with tmgcn_amd.WeightedCrossEntropy (the opt-in fused loss)
+          "graph_fused"  the fused-loss epoch captured into one hipGraph and replayed
           "script"  what an untouched reference script does: `import tmgcn_amd.ehf as ehf`,
                     host-side targets, class weights and criterion (hosted.DeviceResult)"""
     import torch
@@ -247,7 +248,7 @@ def gpu_epochs(g, spec, epochs, mode):
             for q in m.parameters():
                 q.mul_(spec["scale"])
     opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
-    if mode == "fused":
+    if mode in ("fused", "graph_fused"):
         from tmgcn_amd.losses import WeightedCrossEntropy
         crit = WeightedCrossEntropy(torch.tensor([0.9, 0.1])).cuda()
     elif mode == "script":
@@ -265,7 +266,7 @@ def gpu_epochs(g, spec, epochs, mode):
     first = float(epoch().detach())
     for _ in range(3):
         epoch()
-    if mode == "graph":
+    if mode in ("graph", "graph_fused"):
         from tmgcn_amd.graphs import GraphedTrainStep
         step = GraphedTrainStep(m, crit, opt, labels)
         for _ in range(3):
@@ -325,7 +326,7 @@ def cpu_epochs(g, spec, epochs, threads):
     return first, times[len(times) // 2]
 
 
-def epochs_block(args, configs=("S1", "S2", "S3"), modes=("eager", "graph", "fused", "script")):
+def epochs_block(args, configs=("S1", "S2", "S3"), modes=("eager", "graph", "fused", "graph_fused", "script")):
     """north_star's epoch-throughput target (>= 10x the reference's CPU epoch on Reddit link
     prediction at 1 GPU), as a record: per config the GPU epoch in every mode, the CPU oracle's
     epoch (median of --cpu-epoch-reps at 8 and at 32 threads, the better one reported) and the

@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256) void edge_head_fwd_kernel(EdgeArgs a) {
   if (live) {
     const float* zs = a.Z + a.src[e] * a.F;
     const float* zd = a.Z + a.dst[e] * a.F;
+    // (feature quads per lane with 16-byte loads were tried: 1.3-3x slower — the U reads from LDS
+    // then stride 4·C floats across lanes and bank-conflict)
     for (int f = gl; f < a.F; f += G) {
       const float s = zs[f], d = zd[f];
       const float* us = Us + f * a.C;
@@ -176,6 +178,205 @@ __global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
     for (int c = 0; c < kMaxC; ++c)
       if (c < a.C) v = fmaf(s1[c], Us[(a.F + f) * a.C + c], fmaf(s0[c], Us[f * a.C + c], v));
     a.dZ[r * a.F + f] = v;
+  }
+}
+
+// Wide heads (F >= 16): the two halves of the kernel above want different lane counts — the entry
+// sums a few lanes per row (avg entries / 2), the product with U one lane per four features — so
+// they run as two kernels.  edge_head_dz_sums leaves S_src[c], S_dst[c] (as floats: what the fused
+// kernel multiplies too) in the first 2C floats of the row's dZ storage; edge_head_dz_expand reads
+// them back and overwrites the row with  dZ[r][f] = Σ_c S_src[c]·U[f][c] + S_dst[c]·U[F+f][c]  as
+// 16-byte stores.  All lanes of a row sit in one wave and load S before any of them stores (one
+// instruction stream), so expanding in place is safe; same sums in the same order as the fused
+// kernel, hence the same bits.
+template <int G>
+__global__ __launch_bounds__(256) void edge_head_dz_sums_kernel(EdgeBwdArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = gid / G;
+  const int gl = (int)(gid % G);
+  if (r >= a.R) return;
+  double S[2][kMaxC];
+#pragma unroll
+  for (int c = 0; c < kMaxC; ++c) S[0][c] = S[1][c] = 0.0;
+  const int64_t p_end = a.eptr[r + 1];
+  for (int64_t p = a.eptr[r] + gl; p < p_end; p += G) {
+    const int64_t x = a.eidx[p];
+    const float* g = a.dout + (x >> 1) * a.C;
+    const bool is_dst = x & 1;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < a.C) {
+        const double v = (double)g[c];
+        if (is_dst) S[1][c] += v; else S[0][c] += v;
+      }
+  }
+  if (G > 1) {
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1)
+#pragma unroll
+      for (int c = 0; c < kMaxC; ++c)
+        if (c < a.C) {
+          S[0][c] += __shfl_xor(S[0][c], o);
+          S[1][c] += __shfl_xor(S[1][c], o);
+        }
+  }
+  if (gl == 0) {
+    float* o = a.dZ + r * a.F;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < a.C) {
+        o[c] = (float)S[0][c];
+        o[a.C + c] = (float)S[1][c];
+      }
+  }
+}
+
+// LP lanes per row (a power of two >= F/4, <= 64), 64/LP rows per wave.  Persistent: a lane keeps its
+// four feature columns of U (both roles) in registers and strides over the rows.
+// CM = compile-time bound on the classes (2 or kMaxC): sizes the register arrays, i.e. the occupancy.
+template <int CM>
+__global__ __launch_bounds__(256) void edge_head_dz_expand_kernel(EdgeBwdArgs a, int LP) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int fl = (int)(gid % LP);
+  const bool live = 4 * fl < a.F;
+  float us[4][CM], ud[4][CM];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+      const int f = 4 * fl + i;
+      us[i][c] = (live && c < a.C) ? a.U[f * a.C + c] : 0.f;
+      ud[i][c] = (live && c < a.C) ? a.U[(a.F + f) * a.C + c] : 0.f;
+    }
+  const int64_t row_stride = (int64_t)gridDim.x * 256 / LP;
+  constexpr int RU = 4;  // rows in flight per lane group: the S loads of all of them are requested first
+  for (int64_t r = gid / LP; r < a.R; r += RU * row_stride) {
+    float s0[RU][CM], s1[RU][CM];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int64_t ru = r + u * row_stride;
+      const float* row = a.dZ + (ru < a.R ? ru : r) * a.F;
+#pragma unroll
+      for (int c = 0; c < CM; ++c) {
+        s0[u][c] = c < a.C ? row[c] : 0.f;
+        s1[u][c] = c < a.C ? row[a.C + c] : 0.f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every lane of a row's wave has read S before any store below
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int64_t ru = r + u * row_stride;
+      if (live && ru < a.R) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float t = 0.f;
+#pragma unroll
+          for (int c = 0; c < CM; ++c)
+            if (c < a.C) t = fmaf(s1[u][c], ud[i][c], fmaf(s0[u][c], us[i][c], t));
+          v[i] = t;
+        }
+        *reinterpret_cast<float4*>(a.dZ + ru * a.F + 4 * fl) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// dU slabs for wide heads (F >= 64): lane = feature.  Each wave owns a contiguous quarter of the
+// block's edges and walks it in batches of DUW_B (8 for binary heads): lanes 0..DUW_B-1 fetch the batch's endpoints and
+// upstream rows (coalesced), the endpoint rows of ALL edges of the batch are then requested back to
+// back (wave-uniform base from v_readlane + lane offset: coalesced 256-byte row segments) before
+// the first is used — two memory latencies per batch instead of two per edge.  Lane l holds
+// features l, l+64, ... of both roles and keeps its own (feature, class) sums in fp64 registers; no
+// LDS and no barrier inside the loop.  The four waves are folded in order through LDS at the end.
+// NJ = feature slots per lane (ceil(F/64)), CM = compile-time bound on the classes (2 or CM):
+// sizes the register arrays (NJ = 4, CM = 8 needs 312 VGPRs; the common 128-wide binary head 80)
+// DUW_B = edges per batch
+template <int NJ, int CM, int DUW_B>
+__global__ __launch_bounds__(256) void edge_head_du_wide_kernel(EdgeBwdArgs a) {
+  extern __shared__ double redw[];  // [3][2F*C]: waves 1..3
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_out = 2 * a.F * a.C;
+  const int64_t c0 = (int64_t)blockIdx.x * a.edges_per_chunk;
+  int64_t c1 = c0 + a.edges_per_chunk;
+  if (c1 > a.E) c1 = a.E;
+  const int64_t q = (c1 - c0 + 3) / 4;  // edges per wave
+  const int64_t e0 = c0 + wave * q;
+  int64_t e1 = e0 + q;
+  if (e1 > c1) e1 = c1;
+  double acc[NJ][2][CM];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int c = 0; c < CM; ++c) acc[j][0][c] = acc[j][1][c] = 0.0;
+  for (int64_t e = e0; e < e1; e += DUW_B) {
+    const int nb = (int)((e1 - e) < DUW_B ? (e1 - e) : DUW_B);
+    // lanes 0..nb-1: this batch's endpoints (as row offsets in floats) and upstream rows
+    int64_t so = 0, dof = 0;
+    float gl[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) gl[c] = 0.f;
+    if (lane < nb) {
+      so = a.src[e + lane] * a.F;
+      dof = a.dst[e + lane] * a.F;
+#pragma unroll
+      for (int c = 0; c < CM; ++c)
+        if (c < a.C) gl[c] = a.dout[(e + lane) * a.C + c];
+    }
+    float s[DUW_B][NJ], d[DUW_B][NJ];
+#pragma unroll
+    for (int i = 0; i < DUW_B; ++i) {
+      // lanes past the batch hold offset 0: a valid row, multiplied by an upstream row of zeros
+      const int64_t sb = __shfl(so, i), db = __shfl(dof, i);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int f = lane + 64 * j;
+        const bool ok = f < a.F;
+        s[i][j] = ok ? a.Z[sb + f] : 0.f;
+        d[i][j] = ok ? a.Z[db + f] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DUW_B; ++i) {
+      double g[CM];
+#pragma unroll
+      for (int c = 0; c < CM; ++c) g[c] = c < a.C ? (double)__shfl(gl[c], i) : 0.0;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+          if (c < a.C) {
+            acc[j][0][c] = fma((double)s[i][j], g[c], acc[j][0][c]);
+            acc[j][1][c] = fma((double)d[i][j], g[c], acc[j][1][c]);
+          }
+    }
+  }
+  if (wave) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int role = 0; role < 2; ++role)
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+          const int f = lane + 64 * j;
+          if (f < a.F && c < a.C) redw[(int64_t)(wave - 1) * n_out + (role * a.F + f) * a.C + c] = acc[j][role][c];
+        }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* P = a.part + (int64_t)blockIdx.x * n_out;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int role = 0; role < 2; ++role)
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+          const int f = lane + 64 * j;
+          if (f < a.F && c < a.C) {
+            const int o = (role * a.F + f) * a.C + c;
+            P[o] = (float)(((acc[j][role][c] + redw[o]) + redw[n_out + o]) + redw[2 * n_out + o]);
+          }
+        }
   }
 }
 
@@ -443,6 +644,33 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
   if (dZ && R > 0) {
     TMGCN_REQUIRE(eptr && (E == 0 || (eidx && dout)) && U, "edge_head_bwd: null pointer (dZ)");
     const size_t smem = (size_t)2 * F * C * sizeof(float);
+    if (F >= 16 && F % 4 == 0 && 2 * C <= F && reinterpret_cast<uintptr_t>(dZ) % 16 == 0) {
+      // wide head: entry sums into the row's own storage, then the in-place product with U
+      const int G = dz_lanes(1, E, R);
+      const unsigned gs = (unsigned)((R * G + 255) / 256);
+      switch (G) {
+        case 1: hipLaunchKernelGGL(edge_head_dz_sums_kernel<1>, dim3(gs), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(edge_head_dz_sums_kernel<2>, dim3(gs), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(edge_head_dz_sums_kernel<4>, dim3(gs), dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL(edge_head_dz_sums_kernel<8>, dim3(gs), dim3(256), 0, st, a); break;
+        case 16: hipLaunchKernelGGL(edge_head_dz_sums_kernel<16>, dim3(gs), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(edge_head_dz_sums_kernel<32>, dim3(gs), dim3(256), 0, st, a);
+      }
+      int rc = check_launch("edge_head_dz_sums");
+      if (rc) return rc;
+      int LP = 4;
+      while (LP * 4 < F) LP <<= 1;
+      int64_t gx = (R * LP + 255) / 256;  // 256 threads are a whole number of rows
+      if (C <= 2) {
+        const int64_t cap = persistent_grid(edge_head_dz_expand_kernel<2>, 256) * 2;  // the helper caps at 4 blocks per CU
+        hipLaunchKernelGGL(edge_head_dz_expand_kernel<2>, dim3((unsigned)(gx < cap ? gx : cap)), dim3(256), 0, st, a, LP);
+      } else {
+        const int64_t cap = persistent_grid(edge_head_dz_expand_kernel<kMaxC>, 256);
+        hipLaunchKernelGGL(edge_head_dz_expand_kernel<kMaxC>, dim3((unsigned)(gx < cap ? gx : cap)), dim3(256), 0, st, a, LP);
+      }
+      rc = check_launch("edge_head_dz_expand");
+      if (rc) return rc;
+    } else {
     const int G = dz_lanes(F, E, R);
     const unsigned grid = (unsigned)((R * G + 255) / 256);
     switch (G) {
@@ -456,6 +684,7 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
     }
     int rc = check_launch("edge_head_dz");
     if (rc) return rc;
+    }
   }
   if (dU) {
     if (E == 0) {
@@ -470,6 +699,20 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
     }
     if (small_head(F, C, Z, dout)) {
       TMGCN_HEAD_FC(edge_head_du_small_kernel, dim3((unsigned)chunks), dim3(256), 0, st, a)
+    } else if (F >= 64) {
+      const dim3 g((unsigned)chunks), b(256);
+      const size_t sm = (size_t)3 * 2 * F * C * sizeof(double);
+      const int nj = (F + 63) / 64;
+#define TMGCN_DUW(NJ_)                                                                              \
+  if (C <= 2) hipLaunchKernelGGL((edge_head_du_wide_kernel<NJ_, 2, 8>), g, b, sm, st, a);           \
+  else hipLaunchKernelGGL((edge_head_du_wide_kernel<NJ_, kMaxC, (NJ_ <= 2 ? 4 : 2)>), g, b, sm, st, a);
+      switch (nj) {
+        case 1: TMGCN_DUW(1) break;
+        case 2: TMGCN_DUW(2) break;
+        case 3: TMGCN_DUW(3) break;
+        default: TMGCN_DUW(4)
+      }
+#undef TMGCN_DUW
     } else {
       const size_t smem = (size_t)a.du_edges * (2 * F + C) * sizeof(float);
       hipLaunchKernelGGL(edge_head_du_kernel, dim3((unsigned)chunks), dim3(256), smem, st, a);
