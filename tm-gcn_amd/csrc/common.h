@@ -44,12 +44,15 @@ constexpr int kWave = 64;  // gfx950 wavefront
 
 template <typename K>
 inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0) {
-  static int cached = 0;  // one instance per kernel type/instantiation site
-  static const void* cached_for = nullptr;
+  // one cache entry per kernel type / instantiation site and per host thread (no shared mutable
+  // state between threads), valid for the kernel and the device it was computed for
+  thread_local int cached = 0, cached_dev = -1;
+  thread_local const void* cached_for = nullptr;
   const void* key = reinterpret_cast<const void*>(kernel);
-  if (cached && cached_for == key && dyn_smem == 0) return cached;  // dynamic LDS changes residency: re-query
   int dev = 0, cus = 256, per_cu = 1;
-  if (hipGetDevice(&dev) == hipSuccess) {
+  const bool have_dev = hipGetDevice(&dev) == hipSuccess;
+  if (cached && cached_for == key && cached_dev == dev && dyn_smem == 0) return cached;  // dynamic LDS changes residency: re-query
+  if (have_dev) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   }
@@ -60,6 +63,7 @@ inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0) {
   (void)hipGetLastError();
   cached = cus * per_cu;
   cached_for = key;
+  cached_dev = dev;
   return cached;
 }
 
