@@ -164,3 +164,23 @@ def test_device_result_takes_host_operands_the_way_the_scripts_use_them():
     MAP, MRR = ehf.compute_MAP_MRR(out, target, e)
     MAP2, MRR2 = ehf.compute_MAP_MRR(ref.detach().float(), target, e)
     assert abs(float(MAP) - float(MAP2)) <= 1e-12 and abs(float(MRR) - float(MRR2)) <= 1e-12
+
+
+def test_repeated_large_host_uploads_are_announced_once():
+    """hosted.DeviceResult uploads host operands on every call; for a large tensor that comes back every
+    epoch (the scripts' targets) it says so — once — instead of silently paying PCIe each time."""
+    import warnings
+    from tmgcn_amd import hosted
+    hosted._warned = False
+    hosted._UPLOADS.clear()
+    out = torch.zeros(300_000, 2, device="cuda").as_subclass(hosted.DeviceResult)
+    big = torch.ones(300_000, 2)                                     # 2.4 MB on the host
+    small = torch.ones(2)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        for _ in range(6):
+            r = out + big
+            r = r * small
+    assert r.is_cuda
+    mine = [w for w in seen if "uploaded each time" in str(w.message)]
+    assert len(mine) == 1 and issubclass(mine[0].category, RuntimeWarning)

@@ -20,9 +20,34 @@ Two more conveniences for the scripts' idioms:
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 import torch.nn.functional as F
 from torch.utils._pytree import tree_leaves, tree_map
+
+
+_UPLOADS: dict = {}          # (data_ptr, nbytes) -> times a host tensor was sent to the device
+_WARN_BYTES = 1 << 20
+_warned = False
+
+
+def _note_upload(x: torch.Tensor) -> None:
+    """The uploads are a convenience, not free: a host tensor that takes part in every epoch (the scripts'
+    targets) crosses PCIe every epoch.  Say so once instead of staying silent."""
+    global _warned
+    nbytes = x.numel() * x.element_size()
+    if _warned or nbytes < _WARN_BYTES:
+        return
+    key = (x.data_ptr(), nbytes)
+    n = _UPLOADS[key] = _UPLOADS.get(key, 0) + 1
+    if len(_UPLOADS) > 64:
+        _UPLOADS.clear()
+    if n == 3:
+        _warned = True
+        warnings.warn(f"tmgcn_amd: a host tensor of {nbytes / 1e6:.0f} MB is combined with a device-resident result on every "
+                      "call and is uploaded each time (about 20 us per MB); keep it on the device (`.cuda()`) to avoid that",
+                      RuntimeWarning, stacklevel=4)
 
 
 def _is_inplace_or_out(func, kwargs) -> bool:
@@ -36,6 +61,7 @@ class DeviceResult(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
+        # DisableTorchFunctionSubclass is the guard PyTorch's own __torch_function__ documentation uses
         with torch._C.DisableTorchFunctionSubclass():      # attribute access below must not re-enter
             dev = None
             for a in tree_leaves((args, kwargs)):               # also inside lists: torch.cat((host, result))
@@ -44,7 +70,10 @@ class DeviceResult(torch.Tensor):
                     break
             if dev is not None:
                 def follow(x):
-                    return x.to(dev) if isinstance(x, torch.Tensor) and x.device.type == "cpu" else x
+                    if isinstance(x, torch.Tensor) and x.device.type == "cpu":
+                        _note_upload(x)
+                        return x.to(dev)
+                    return x
 
                 if _is_inplace_or_out(func, kwargs):
                     # a host tensor that is written to stays where it is (cpu_buffer.copy_(result))
