@@ -17,6 +17,10 @@
 #include "common.h"
 #include "spmm_row.h"
 
+#ifndef TMGCN_FUSED_XCD_SWEEPS
+#define TMGCN_FUSED_XCD_SWEEPS 0
+#endif
+
 namespace tmgcn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -77,10 +81,24 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
 
   for (;;) {
     // next tile from the device counter (ascending, so resident blocks stay inside one slice)
+#if TMGCN_FUSED_XCD_SWEEPS
+    // EXPERIMENT (not the default; DESIGN.md §4 "XCD-aware order"): workgroups are dealt to the 8 XCDs
+    // round-robin, so blockIdx.x % 8 names the XCD; each XCD sweeps its own eighth of the tiles (its
+    // own slices) from its own counter.  Slower: eight 1-GB gather windows compete for the shared
+    // 256 MB Infinity Cache instead of one, and a 4 MB L2 holds none of them either way.
+    const unsigned sweep = blockIdx.x % TMGCN_FUSED_XCD_SWEEPS;
+    const int64_t per_sweep = (a.n_tiles + TMGCN_FUSED_XCD_SWEEPS - 1) / TMGCN_FUSED_XCD_SWEEPS;
+    if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter + sweep, 1u);
+    __syncthreads();
+    if ((int64_t)s_tile >= per_sweep) break;
+    const int64_t tile = sweep * per_sweep + s_tile;
+    if (tile >= a.n_tiles) break;
+#else
     if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter, 1u);
     __syncthreads();
     const int64_t tile = s_tile;
     if (tile >= a.n_tiles) break;
+#endif
     const int64_t batch = tile / a.tiles_per_batch;
     const int64_t row0 = batch * batch_rows + (tile % a.tiles_per_batch) * FBM;
     int64_t row_end = (batch + 1) * batch_rows;
@@ -281,7 +299,11 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
   a.tiles_per_batch = (br + FBM - 1) / FBM;
   a.n_tiles = nb * a.tiles_per_batch;
   TMGCN_REQUIRE(a.n_tiles < (int64_t)0x7fffffff, "spmm_gemm: too many row tiles");
+#if TMGCN_FUSED_XCD_SWEEPS
+  a.tile_counter = acquire_tile_counters((hipStream_t)stream, TMGCN_FUSED_XCD_SWEEPS);
+#else
   a.tile_counter = acquire_tile_counter((hipStream_t)stream);
+#endif
   TMGCN_REQUIRE(a.tile_counter, "spmm_gemm: cannot set up the tile counter");
   // persistent blocks: up to 4 per CU (LDS 33.8 KB each); tiles are dealt round-robin so the
   // blocks resident at any moment work on neighbouring rows of the same slice

@@ -28,7 +28,7 @@ libs = {"default": load(root + "/tm-gcn_amd/libtmgcn_hip.so")}
 for n in names:
     libs[n] = load(f"{root}/build/variants/{n}/libtmgcn_hip.so")
 
-T, N, F, deg = 4, 2_000_000, 128, 32
+T, N, F, deg = int(os.environ.get("AB_T", 4)), 2_000_000, 128, 32
 A = synth.device_er_csr(T, N, deg, "cuda")
 X = torch.rand(T, N, F, device="cuda")
 W = torch.randn(F, F, device="cuda") * 0.1
