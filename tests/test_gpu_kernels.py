@@ -407,7 +407,8 @@ def test_spmm_gemm_unsupported_width_raises():
 
 
 # ------------------------------------------------------------------------------------- P4 edge head
-@pytest.mark.parametrize("F,C", [(2, 2), (6, 2), (6, 3), (16, 8), (32, 2), (5, 1), (128, 2), (100, 3), (256, 8)])
+@pytest.mark.parametrize("F,C", [(2, 2), (6, 2), (6, 3), (16, 8), (32, 2), (5, 1), (128, 2), (100, 3), (256, 8),
+                                 (4, 4), (8, 1), (64, 2), (192, 2), (20, 3)])   # + every narrow / wide kernel instantiation family
 @pytest.mark.parametrize("E", [0, 1, 1000, 70001])
 def test_edge_head_fwd_bwd(F, C, E):
     T, N = 3, 97
@@ -505,7 +506,7 @@ def test_weighted_cross_entropy_ignore_index_and_corrupt_labels():
 
 
 
-@pytest.mark.parametrize("E,C", [(1, 2), (1000, 2), (5000, 3), (300, 8), (3_000_001, 2)])
+@pytest.mark.parametrize("E,C", [(1, 2), (1000, 2), (5000, 3), (300, 8), (3_000_001, 2), (777, 4), (40_001, 4)])
 def test_weighted_cross_entropy_matches_torch_fp64(E, C):
     from tmgcn_amd.losses import WeightedCrossEntropy
     g = torch.Generator().manual_seed(E + C)
