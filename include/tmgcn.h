@@ -118,6 +118,8 @@ int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int32_t* col, c
  * RCCL's exchange kernels on a side stream can become resident next to the compute kernel.  Supported when tmgcn_spmm_gemm_supported(K, Nf) != 0
  * (K a multiple of 8 in [16, 128] with Nf <= 128 — MFMA epilogue — or K in {1,2,3,4,6,8} with Nf <= 16 —
  * the reference's real widths, FMA epilogue); otherwise call the two kernels separately.
+ * The MFMA form reads X rows and writes AX rows as 16-byte vectors: X and AX must be 16-byte aligned
+ * (TMGCN_ERR_INVALID otherwise; the torch.ops layer copies a misaligned X once instead).
  */
 int tmgcn_spmm_gemm_supported(int32_t K, int32_t Nf);
 int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* val,

@@ -55,6 +55,11 @@ inline void ok(int rc, const char* what) {
   TORCH_CHECK(rc == 0, what, " failed (status ", rc, "): ", tmgcn_last_error());
 }
 inline Tensor none_like(const Tensor& t) { return at::empty({0}, t.options()); }
+// a contiguous view can start anywhere inside its allocation; the few entry points that need
+// 16-byte aligned rows get a fresh (allocator-aligned) copy in that rare case
+inline Tensor aligned16(const Tensor& t) {
+  return (!t.defined() || reinterpret_cast<uintptr_t>(t.const_data_ptr()) % 16 == 0) ? t : t.clone();
+}
 inline bool has(const Tensor& t) { return t.defined() && t.numel() > 0; }
 
 // ---------------------------------------------------------------------------------------
@@ -144,9 +149,9 @@ std::tuple<Tensor, Tensor, Tensor> spmm_gemm(const Tensor& rowptr, const Tensor&
   c10::DeviceGuard g(X.device());
   const WShape s = w_shape(W, trans_w, X.size(0), X.size(2), "spmm_gemm");
   Tensor Y = at::empty({X.size(0), N, s.wn}, X.options());
-  Tensor AX = want_ax ? at::empty_like(X) : Tensor();
+  Tensor AX = want_ax ? at::empty(X.sizes(), X.options()) : Tensor();
   Tensor pre = (want_pre && act != TMGCN_ACT_NONE) ? at::empty_like(Y) : Tensor();
-  spmm_gemm_launch(rowptr, col, val, X, N, W, trans_w, act, Y, AX, pre, grid_reserve);
+  spmm_gemm_launch(rowptr, col, val, aligned16(X), N, W, trans_w, act, Y, AX, pre, grid_reserve);
   return {Y, AX.defined() ? AX : none_like(X), pre.defined() ? pre : none_like(X)};
 }
 
@@ -165,7 +170,9 @@ void spmm_gemm_out(const Tensor& rowptr, const Tensor& col, const Tensor& val, c
   Tensor ax = AX.has_value() ? *AX : Tensor(), pr = pre.has_value() ? *pre : Tensor();
   if (ax.defined()) want(ax, "spmm_gemm out AX");
   if (pr.defined()) want(pr, "spmm_gemm out pre");
-  spmm_gemm_launch(rowptr, col, val, X, N, W, trans_w, act, Y, ax, pr, grid_reserve);
+  TORCH_CHECK(!ax.defined() || reinterpret_cast<uintptr_t>(ax.const_data_ptr()) % 16 == 0,
+              "spmm_gemm: the AX output view must start 16-byte aligned");
+  spmm_gemm_launch(rowptr, col, val, aligned16(X), N, W, trans_w, act, Y, ax, pr, grid_reserve);
 }
 
 std::tuple<Tensor, Tensor> bgemm(const Tensor& A, const Tensor& W, bool trans_w, int64_t act, bool want_pre,
