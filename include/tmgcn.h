@@ -103,7 +103,8 @@ int tmgcn_spmm_csr_batched_f32(const int64_t* rowptr, const int32_t* col, const 
                                const float* X, float* Y, int64_t n_rows, int32_t N, int32_t F,
                                void* stream);
 /* Same, with the caller's average stored non-zeros per row (< 0: unknown); it only steers
- * how many lanes share a row in the small-F kernel, never the result. */
+ * how many lanes share a row in the small-F kernel, i.e. the order in which a row's terms are
+ * added (results agree to fp32 rounding; for a given hint they are bitwise reproducible). */
 int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int32_t* col, const float* val,
                                     const float* X, float* Y, int64_t n_rows, int32_t N,
                                     int32_t F, float avg_nnz_per_row, void* stream);
@@ -127,6 +128,15 @@ int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* 
                         const float* W, int32_t Nf, int32_t trans_w,
                         int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
                         float* Y, float* AX, float* pre_act, int32_t grid_reserve, void* stream);
+/* Same, with the caller's average stored non-zeros per row (< 0: unknown) — steers how many lanes
+ * share a row in the narrow (K <= 8) kernel, i.e. the order in which a row's terms are added, as in
+ * tmgcn_spmm_csr_batched_f32_hint. */
+int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* col, const float* val,
+                             const float* X, int64_t n_rows, int32_t N, int32_t K,
+                             const float* W, int32_t Nf, int32_t trans_w,
+                             int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
+                             float* Y, float* AX, float* pre_act, int32_t grid_reserve,
+                             float avg_nnz_per_row, void* stream);
 
 /* ---- P3: feature·weight contraction ----------------------------------------------
  * Replaces  t.matmul(AtXt, Wt)  ehf:222, 330, 340, 344, 349, 415, 486-489.

@@ -34,6 +34,7 @@ SIGNATURES = {
     "tmgcn_spmm_csr_batched_f32_hint": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, C.c_float, _p]),
     "tmgcn_spmm_gemm_supported": (C.c_int, [_i32, _i32]),
     "tmgcn_spmm_gemm_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _i32, _i64, _i64, _i32, _p, _p, _p, _i32, _p]),
+    "tmgcn_spmm_gemm_f32_hint": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _i32, _i64, _i64, _i32, _p, _p, _p, _i32, C.c_float, _p]),
     "tmgcn_gemm_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _p]),
     "tmgcn_gemm_bf16w_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i32, _p]),
     "tmgcn_gemm_dw_workspace_bytes": (_i64, [_i64, _i32, _i32, _i64]),

@@ -258,12 +258,12 @@ extern "C" int tmgcn_spmm_gemm_supported(int32_t K, int32_t Nf) {
   return ((K % 8 == 0 && K >= 16 && K <= FKC && Nf >= 1 && Nf <= 128) || fused_small_ok(K, Nf)) ? 1 : 0;
 }
 
-extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* val,
-                                    const float* X, int64_t n_rows, int32_t N, int32_t K,
-                                    const float* W, int32_t Nf, int32_t trans_w,
-                                    int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
-                                    float* Y, float* AX, float* pre_act, int32_t grid_reserve,
-                                    void* stream) {
+extern "C" int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* col, const float* val,
+                                         const float* X, int64_t n_rows, int32_t N, int32_t K,
+                                         const float* W, int32_t Nf, int32_t trans_w,
+                                         int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
+                                         float* Y, float* AX, float* pre_act, int32_t grid_reserve,
+                                         float avg_nnz_per_row, void* stream) {
   TMGCN_REQUIRE(grid_reserve >= 0 && grid_reserve <= 4096, "spmm_gemm: grid_reserve %d out of range [0, 4096]", grid_reserve);
   TMGCN_REQUIRE(n_rows >= 0 && N > 0, "spmm_gemm: bad shape n_rows=%lld N=%d", (long long)n_rows, N);
   TMGCN_REQUIRE(tmgcn_spmm_gemm_supported(K, Nf),
@@ -277,9 +277,14 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
   if (fused_small_ok(K, Nf)) {
     FusedArgs s{rowptr, col, val, reinterpret_cast<const float4*>(X), n_rows, N, K, W, Nf, trans_w,
                 rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0, nullptr};
-    // 8 lanes per row: the row lengths live on the device (no hint in this entry point) and the
+    // lanes per row: from the caller's average row length where it is known (as in
+    // tmgcn_spmm_csr_batched_f32_hint), else 8 — the row lengths live on the device and the
     // reference's M-transformed adjacencies have tens of entries per row
-    const int G = 8;
+    int G = 8;
+    if (avg_nnz_per_row >= 0.f) {
+      G = 1;
+      while (G < 64 && (float)(2 * G) <= avg_nnz_per_row) G <<= 1;
+    }
     hipStream_t st2 = (hipStream_t)stream;
     switch (K) {
       case 1: return launch_fused_small<1>(s, G, st2);
@@ -334,4 +339,14 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
   }
 #undef TMGCN_FUSED_CASE
   return check_launch("spmm_gemm");
+}
+
+extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* val,
+                                    const float* X, int64_t n_rows, int32_t N, int32_t K,
+                                    const float* W, int32_t Nf, int32_t trans_w,
+                                    int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
+                                    float* Y, float* AX, float* pre_act, int32_t grid_reserve,
+                                    void* stream) {
+  return tmgcn_spmm_gemm_f32_hint(rowptr, col, val, X, n_rows, N, K, W, Nf, trans_w, rows_per_batch, w_batch_stride,
+                                  act, Y, AX, pre_act, grid_reserve, -1.f, stream);
 }

@@ -132,11 +132,14 @@ void spmm_gemm_launch(const Tensor& rowptr, const Tensor& col, const Tensor& val
                       const Tensor& W, bool trans_w, int64_t act, const Tensor& Y, const Tensor& AX,
                       const Tensor& pre, int64_t grid_reserve) {
   const WShape s = w_shape(W, trans_w, X.size(0), X.size(2), "spmm_gemm");
-  ok(tmgcn_spmm_gemm_f32((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val),
-                         (const float*)ptr(X), X.size(0) * N, (int32_t)N, (int32_t)X.size(2),
-                         (const float*)ptr(W), (int32_t)s.wn, trans_w ? 1 : 0, s.per_slice ? N : 0, s.stride,
-                         (int32_t)act, (float*)ptr(Y), (float*)ptr(AX), (float*)ptr(pre), (int32_t)grid_reserve,
-                         stream_of(X)),
+  // average row length from the tensors' own sizes (host-side metadata): steers the lanes per row of the narrow kernel
+  const int64_t n_rows = X.size(0) * N;
+  const float avg = n_rows > 0 ? (float)((double)col.numel() / (double)n_rows) : -1.f;
+  ok(tmgcn_spmm_gemm_f32_hint((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val),
+                              (const float*)ptr(X), n_rows, (int32_t)N, (int32_t)X.size(2),
+                              (const float*)ptr(W), (int32_t)s.wn, trans_w ? 1 : 0, s.per_slice ? N : 0, s.stride,
+                              (int32_t)act, (float*)ptr(Y), (float*)ptr(AX), (float*)ptr(pre), (int32_t)grid_reserve,
+                              avg, stream_of(X)),
      "tmgcn_spmm_gemm_f32");
 }
 
