@@ -207,6 +207,17 @@ int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const int64_t* d
                             const int64_t* eptr, const int64_t* eidx,
                             float* dZ, float* dU, int64_t R, int64_t E, int32_t F, int32_t C,
                             void* workspace, int64_t workspace_bytes, void* stream);
+/* The same two entry points with 32-bit index arrays (src, dst, eptr, eidx): for edge sets whose
+ * rows and 2·E fit 31 bits — every configuration of the reference's experiments — the index
+ * arrays are half the bytes these gather-bound kernels move.  Same results, bit for bit. */
+int tmgcn_edge_head_fwd_i32_f32(const float* Z, const int32_t* src, const int32_t* dst,
+                                const float* U, float* out, int64_t E, int32_t F, int32_t C,
+                                void* stream);
+int tmgcn_edge_head_bwd_i32_f32(const float* Z, const int32_t* src, const int32_t* dst,
+                                const float* U, const float* dout,
+                                const int32_t* eptr, const int32_t* eidx,
+                                float* dZ, float* dU, int64_t R, int64_t E, int32_t F, int32_t C,
+                                void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- class-weighted cross entropy, mean reduction (opt-in) -----------------------------
  * Same value as  nn.CrossEntropyLoss(weight=w)(logits, target)  used by every experiment script

@@ -43,6 +43,8 @@ SIGNATURES = {
     "tmgcn_edge_head_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_edge_head_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "tmgcn_edge_head_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i64, _p]),
+    "tmgcn_edge_head_fwd_i32_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "tmgcn_edge_head_bwd_i32_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i64, _p]),
     "tmgcn_wce_workspace_bytes": (_i64, [_i64]),
     "tmgcn_wce_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _i64, _p]),
     "tmgcn_wce_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i64, _p, _p]),

@@ -22,10 +22,13 @@ namespace tmgcn {
 constexpr int kMaxC = 8;     // classes
 constexpr int kMaxF = 256;   // embedding width handled by the fused head
 
+// IT = index type of the edge arrays: int64_t (the reference's flat index, ehf:196-198) or int32_t
+// (the *_i32 entry points: half the index bytes when rows and 2·E fit 31 bits)
+template <typename IT>
 struct EdgeArgs {
   const float* Z;       // [R][F]
-  const int64_t* src;   // [E] flat row index t*N+node (ehf:196-198)
-  const int64_t* dst;   // [E]
+  const IT* src;        // [E] flat row index t*N+node (ehf:196-198)
+  const IT* dst;        // [E]
   const float* U;       // [2F][C]
   float* out;           // [E][C]
   int64_t E;
@@ -34,8 +37,8 @@ struct EdgeArgs {
 
 // G lanes share one edge: lane gl takes features gl, gl+G, ... of both endpoint rows (coalesced
 // across the group), partial dot products are combined with a shuffle butterfly.  U sits in LDS.
-template <int G>
-__global__ __launch_bounds__(256) void edge_head_fwd_kernel(EdgeArgs a) {
+template <int G, typename IT>
+__global__ __launch_bounds__(256) void edge_head_fwd_kernel(EdgeArgs<IT> a) {
   extern __shared__ float Us[];  // [2F][C]
   for (int t = threadIdx.x; t < 2 * a.F * a.C; t += 256) Us[t] = a.U[t];
   __syncthreads();
@@ -47,8 +50,8 @@ __global__ __launch_bounds__(256) void edge_head_fwd_kernel(EdgeArgs a) {
 #pragma unroll
   for (int c = 0; c < kMaxC; ++c) acc[c] = 0.f;
   if (live) {
-    const float* zs = a.Z + a.src[e] * a.F;
-    const float* zd = a.Z + a.dst[e] * a.F;
+    const float* zs = a.Z + (int64_t)a.src[e] * a.F;
+    const float* zd = a.Z + (int64_t)a.dst[e] * a.F;
     // (feature quads per lane with 16-byte loads were tried: 1.3-3x slower — the U reads from LDS
     // then stride 4·C floats across lanes and bank-conflict)
     for (int f = gl; f < a.F; f += G) {
@@ -75,12 +78,12 @@ __global__ __launch_bounds__(256) void edge_head_fwd_kernel(EdgeArgs a) {
 // compile time — the 2·FT/2 row loads are 8-byte vectors all in flight at once, U is read through
 // uniform (scalar) loads into SGPRs, the CT logits leave as one vector store.  Needs an 8-byte
 // aligned Z (and out for CT = 2 / 4): checked by the launcher.
-template <int FT, int CT>
-__global__ __launch_bounds__(256) void edge_head_fwd_small_kernel(EdgeArgs a) {
+template <int FT, int CT, typename IT>
+__global__ __launch_bounds__(256) void edge_head_fwd_small_kernel(EdgeArgs<IT> a) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= a.E) return;
-  const float2* zs = reinterpret_cast<const float2*>(a.Z + a.src[e] * FT);
-  const float2* zd = reinterpret_cast<const float2*>(a.Z + a.dst[e] * FT);
+  const float2* zs = reinterpret_cast<const float2*>(a.Z + (int64_t)a.src[e] * FT);
+  const float2* zd = reinterpret_cast<const float2*>(a.Z + (int64_t)a.dst[e] * FT);
   float2 s[FT / 2], d[FT / 2];
 #pragma unroll
   for (int i = 0; i < FT / 2; ++i) {
@@ -111,14 +114,15 @@ __global__ __launch_bounds__(256) void edge_head_fwd_small_kernel(EdgeArgs a) {
   }
 }
 
+template <typename IT>
 struct EdgeBwdArgs {
   const float* Z;
-  const int64_t* src;
-  const int64_t* dst;
+  const IT* src;
+  const IT* dst;
   const float* U;
   const float* dout;     // [E][C]
-  const int64_t* eptr;   // [R+1] inverted index: entries of row r are eidx[eptr[r] .. eptr[r+1])
-  const int64_t* eidx;   // [2E]  entry = 2*edge + role (0: the row is the edge's src, 1: its dst)
+  const IT* eptr;        // [R+1] inverted index: entries of row r are eidx[eptr[r] .. eptr[r+1])
+  const IT* eidx;        // [2E]  entry = 2*edge + role (0: the row is the edge's src, 1: its dst)
   float* dZ;             // [R][F]
   float* part;           // dU slabs [chunks][2F][C]
   int64_t R, E;
@@ -132,8 +136,8 @@ struct EdgeBwdArgs {
 // G independent chains of dependent index -> dout loads instead of one), the partial sums are
 // combined with an xor butterfly — every lane ends with the same bits, in an order fixed by G —
 // then lane gl writes features gl, gl+G, ...
-template <int G>
-__global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
+template <int G, typename IT>
+__global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs<IT> a) {
   extern __shared__ float Us[];
   for (int t = threadIdx.x; t < 2 * a.F * a.C; t += 256) Us[t] = a.U[t];
   __syncthreads();
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
   const int64_t p_end = a.eptr[r + 1];
   for (int64_t p = a.eptr[r] + gl; p < p_end; p += G) {
     const int64_t x = a.eidx[p];
-    const float* g = a.dout + (x >> 1) * a.C;
+    const float* g = a.dout + (int64_t)(x >> 1) * a.C;
     const bool is_dst = x & 1;
 #pragma unroll
     for (int c = 0; c < kMaxC; ++c)
@@ -189,8 +193,8 @@ __global__ __launch_bounds__(256) void edge_head_dz_kernel(EdgeBwdArgs a) {
 // 16-byte stores.  All lanes of a row sit in one wave and load S before any of them stores (one
 // instruction stream), so expanding in place is safe; same sums in the same order as the fused
 // kernel, hence the same bits.
-template <int G>
-__global__ __launch_bounds__(256) void edge_head_dz_sums_kernel(EdgeBwdArgs a) {
+template <int G, typename IT>
+__global__ __launch_bounds__(256) void edge_head_dz_sums_kernel(EdgeBwdArgs<IT> a) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t r = gid / G;
   const int gl = (int)(gid % G);
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void edge_head_dz_sums_kernel(EdgeBwdArgs a) {
   const int64_t p_end = a.eptr[r + 1];
   for (int64_t p = a.eptr[r] + gl; p < p_end; p += G) {
     const int64_t x = a.eidx[p];
-    const float* g = a.dout + (x >> 1) * a.C;
+    const float* g = a.dout + (int64_t)(x >> 1) * a.C;
     const bool is_dst = x & 1;
 #pragma unroll
     for (int c = 0; c < kMaxC; ++c)
@@ -234,8 +238,8 @@ __global__ __launch_bounds__(256) void edge_head_dz_sums_kernel(EdgeBwdArgs a) {
 // LP lanes per row (a power of two >= F/4, <= 64), 64/LP rows per wave.  Persistent: a lane keeps its
 // four feature columns of U (both roles) in registers and strides over the rows.
 // CM = compile-time bound on the classes (2 or kMaxC): sizes the register arrays, i.e. the occupancy.
-template <int CM>
-__global__ __launch_bounds__(256) void edge_head_dz_expand_kernel(EdgeBwdArgs a, int LP) {
+template <int CM, typename IT>
+__global__ __launch_bounds__(256) void edge_head_dz_expand_kernel(EdgeBwdArgs<IT> a, int LP) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int fl = (int)(gid % LP);
   const bool live = 4 * fl < a.F;
@@ -292,8 +296,8 @@ __global__ __launch_bounds__(256) void edge_head_dz_expand_kernel(EdgeBwdArgs a,
 // NJ = feature slots per lane (ceil(F/64)), CM = compile-time bound on the classes (2 or CM):
 // sizes the register arrays (NJ = 4, CM = 8 needs 312 VGPRs; the common 128-wide binary head 80)
 // DUW_B = edges per batch
-template <int NJ, int CM, int DUW_B>
-__global__ __launch_bounds__(256) void edge_head_du_wide_kernel(EdgeBwdArgs a) {
+template <int NJ, int CM, int DUW_B, typename IT>
+__global__ __launch_bounds__(256) void edge_head_du_wide_kernel(EdgeBwdArgs<IT> a) {
   extern __shared__ double redw[];  // [3][2F*C]: waves 1..3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_out = 2 * a.F * a.C;
@@ -317,8 +321,8 @@ __global__ __launch_bounds__(256) void edge_head_du_wide_kernel(EdgeBwdArgs a) {
 #pragma unroll
     for (int c = 0; c < CM; ++c) gl[c] = 0.f;
     if (lane < nb) {
-      so = a.src[e + lane] * a.F;
-      dof = a.dst[e + lane] * a.F;
+      so = (int64_t)a.src[e + lane] * a.F;
+      dof = (int64_t)a.dst[e + lane] * a.F;
 #pragma unroll
       for (int c = 0; c < CM; ++c)
         if (c < a.C) gl[c] = a.dout[(e + lane) * a.C + c];
@@ -385,7 +389,8 @@ __global__ __launch_bounds__(256) void edge_head_du_wide_kernel(EdgeBwdArgs a) {
 // 12 x 2 = 24 outputs), otherwise each thread owns up to 16 outputs; fp64 running sums, groups
 // combined through LDS in fixed order.
 constexpr int DU_OMAX = 16;  // 2*256*8 / 256
-__global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
+template <typename IT>
+__global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs<IT> a) {
   extern __shared__ float sm[];  // [du_edges][2F] gathered rows, then [du_edges][C] dout rows
   __shared__ double red[256];
   const int K = 2 * a.F;
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
     __syncthreads();
     for (int t = threadIdx.x; t < ne * K; t += 256) {
       const int i = t / K, k = t % K;
-      const int64_t row = k < a.F ? a.src[e + i] : a.dst[e + i];
+      const int64_t row = k < a.F ? (int64_t)a.src[e + i] : (int64_t)a.dst[e + i];
       sz[t] = a.Z[row * a.F + (k < a.F ? k : k - a.F)];
     }
     for (int t = threadIdx.x; t < ne * a.C; t += 256) sd[t] = a.dout[e * a.C + t];
@@ -453,8 +458,8 @@ __global__ __launch_bounds__(256) void edge_head_du_kernel(EdgeBwdArgs a) {
 // (edge e0 + t, e0 + t + 256, ... of the block's chunk) in fp64 registers — no LDS staging, no
 // barrier inside the edge loop, the row / dout loads of successive edges are independent — and the
 // block folds them once at the end: xor butterfly inside each wave, then the four waves in order.
-template <int FT, int CT>
-__global__ __launch_bounds__(256) void edge_head_du_small_kernel(EdgeBwdArgs a) {
+template <int FT, int CT, typename IT>
+__global__ __launch_bounds__(256) void edge_head_du_small_kernel(EdgeBwdArgs<IT> a) {
   constexpr int K = 2 * FT, NO = K * CT;
   __shared__ double red[4][NO];
   const int64_t e0 = (int64_t)blockIdx.x * a.edges_per_chunk;
@@ -466,8 +471,8 @@ __global__ __launch_bounds__(256) void edge_head_du_small_kernel(EdgeBwdArgs a) 
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[k][c] = 0.0;
   for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
-    const float2* zs = reinterpret_cast<const float2*>(a.Z + a.src[e] * FT);
-    const float2* zd = reinterpret_cast<const float2*>(a.Z + a.dst[e] * FT);
+    const float2* zs = reinterpret_cast<const float2*>(a.Z + (int64_t)a.src[e] * FT);
+    const float2* zd = reinterpret_cast<const float2*>(a.Z + (int64_t)a.dst[e] * FT);
     float z[K], g[CT];
 #pragma unroll
     for (int i = 0; i < FT / 2; ++i) {
@@ -535,10 +540,10 @@ static bool small_head(int F, int C, const void* Z, const void* io) {
 }
 #define TMGCN_HEAD_C(KERNEL, FT, ...)                                                           \
   switch (C) {                                                                                  \
-    case 1: hipLaunchKernelGGL((KERNEL<FT, 1>), __VA_ARGS__); break;                            \
-    case 2: hipLaunchKernelGGL((KERNEL<FT, 2>), __VA_ARGS__); break;                            \
-    case 3: hipLaunchKernelGGL((KERNEL<FT, 3>), __VA_ARGS__); break;                            \
-    default: hipLaunchKernelGGL((KERNEL<FT, 4>), __VA_ARGS__);                                  \
+    case 1: hipLaunchKernelGGL((KERNEL<FT, 1, IT>), __VA_ARGS__); break;                            \
+    case 2: hipLaunchKernelGGL((KERNEL<FT, 2, IT>), __VA_ARGS__); break;                            \
+    case 3: hipLaunchKernelGGL((KERNEL<FT, 3, IT>), __VA_ARGS__); break;                            \
+    default: hipLaunchKernelGGL((KERNEL<FT, 4, IT>), __VA_ARGS__);                                  \
   }
 #define TMGCN_HEAD_FC(KERNEL, ...)                                                              \
   switch (F) {                                                                                  \
@@ -592,15 +597,15 @@ extern "C" int tmgcn_edge_head_supported(int32_t F, int32_t C) {
   return (F >= 1 && F <= kMaxF && C >= 1 && C <= kMaxC) ? 1 : 0;
 }
 
-extern "C" int tmgcn_edge_head_fwd_f32(const float* Z, const int64_t* src, const int64_t* dst,
-                                        const float* U, float* out, int64_t E, int32_t F, int32_t C,
-                                        void* stream) {
+template <typename IT>
+static int edge_head_fwd_impl(const float* Z, const IT* src, const IT* dst, const float* U, float* out, int64_t E,
+                              int32_t F, int32_t C, void* stream) {
   TMGCN_REQUIRE(tmgcn_edge_head_supported(F, C), "edge_head: unsupported widths F=%d C=%d (F <= %d, C <= %d)", F, C,
                 kMaxF, kMaxC);
   TMGCN_REQUIRE(E >= 0, "edge_head: negative E");
   if (E == 0) return TMGCN_OK;
   TMGCN_REQUIRE(Z && src && dst && U && out, "edge_head: null pointer");
-  EdgeArgs a{Z, src, dst, U, out, E, F, C};
+  EdgeArgs<IT> a{Z, src, dst, U, out, E, F, C};
   const size_t smem = (size_t)2 * F * C * sizeof(float);
   const int G = lanes_per_item(F);
   const unsigned grid = (unsigned)((E * G + 255) / 256);
@@ -610,13 +615,13 @@ extern "C" int tmgcn_edge_head_fwd_f32(const float* Z, const int64_t* src, const
     return check_launch("edge_head_fwd_small");
   }
   switch (G) {
-    case 1: hipLaunchKernelGGL(edge_head_fwd_kernel<1>, dim3(grid), dim3(256), smem, st, a); break;
-    case 2: hipLaunchKernelGGL(edge_head_fwd_kernel<2>, dim3(grid), dim3(256), smem, st, a); break;
-    case 4: hipLaunchKernelGGL(edge_head_fwd_kernel<4>, dim3(grid), dim3(256), smem, st, a); break;
-    case 8: hipLaunchKernelGGL(edge_head_fwd_kernel<8>, dim3(grid), dim3(256), smem, st, a); break;
-    case 16: hipLaunchKernelGGL(edge_head_fwd_kernel<16>, dim3(grid), dim3(256), smem, st, a); break;
-    case 32: hipLaunchKernelGGL(edge_head_fwd_kernel<32>, dim3(grid), dim3(256), smem, st, a); break;
-    default: hipLaunchKernelGGL(edge_head_fwd_kernel<64>, dim3(grid), dim3(256), smem, st, a);
+    case 1: hipLaunchKernelGGL((edge_head_fwd_kernel<1, IT>), dim3(grid), dim3(256), smem, st, a); break;
+    case 2: hipLaunchKernelGGL((edge_head_fwd_kernel<2, IT>), dim3(grid), dim3(256), smem, st, a); break;
+    case 4: hipLaunchKernelGGL((edge_head_fwd_kernel<4, IT>), dim3(grid), dim3(256), smem, st, a); break;
+    case 8: hipLaunchKernelGGL((edge_head_fwd_kernel<8, IT>), dim3(grid), dim3(256), smem, st, a); break;
+    case 16: hipLaunchKernelGGL((edge_head_fwd_kernel<16, IT>), dim3(grid), dim3(256), smem, st, a); break;
+    case 32: hipLaunchKernelGGL((edge_head_fwd_kernel<32, IT>), dim3(grid), dim3(256), smem, st, a); break;
+    default: hipLaunchKernelGGL((edge_head_fwd_kernel<64, IT>), dim3(grid), dim3(256), smem, st, a);
   }
   return check_launch("edge_head_fwd");
 }
@@ -629,18 +634,17 @@ extern "C" int64_t tmgcn_edge_head_bwd_workspace_bytes(int64_t E, int32_t F, int
   return (int64_t)chunks * 2 * F * C * (int64_t)sizeof(float);
 }
 
-extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const int64_t* dst,
-                                        const float* U, const float* dout, const int64_t* eptr,
-                                        const int64_t* eidx, float* dZ, float* dU, int64_t R, int64_t E,
-                                        int32_t F, int32_t C, void* workspace, int64_t workspace_bytes,
-                                        void* stream) {
+template <typename IT>
+static int edge_head_bwd_impl(const float* Z, const IT* src, const IT* dst, const float* U, const float* dout,
+                              const IT* eptr, const IT* eidx, float* dZ, float* dU, int64_t R, int64_t E,
+                              int32_t F, int32_t C, void* workspace, int64_t workspace_bytes, void* stream) {
   TMGCN_REQUIRE(tmgcn_edge_head_supported(F, C), "edge_head_bwd: unsupported widths F=%d C=%d", F, C);
   TMGCN_REQUIRE(R >= 0 && E >= 0, "edge_head_bwd: negative extent");
   hipStream_t st = (hipStream_t)stream;
   int chunks;
   int64_t per;
   du_plan(E, F, &chunks, &per);
-  EdgeBwdArgs a{Z, src, dst, U, dout, eptr, eidx, dZ, (float*)workspace, R, E, F, C, chunks, per, du_tile_edges(F)};
+  EdgeBwdArgs<IT> a{Z, src, dst, U, dout, eptr, eidx, dZ, (float*)workspace, R, E, F, C, chunks, per, du_tile_edges(F)};
   if (dZ && R > 0) {
     TMGCN_REQUIRE(eptr && (E == 0 || (eidx && dout)) && U, "edge_head_bwd: null pointer (dZ)");
     const size_t smem = (size_t)2 * F * C * sizeof(float);
@@ -649,12 +653,12 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
       const int G = dz_lanes(1, E, R);
       const unsigned gs = (unsigned)((R * G + 255) / 256);
       switch (G) {
-        case 1: hipLaunchKernelGGL(edge_head_dz_sums_kernel<1>, dim3(gs), dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(edge_head_dz_sums_kernel<2>, dim3(gs), dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL(edge_head_dz_sums_kernel<4>, dim3(gs), dim3(256), 0, st, a); break;
-        case 8: hipLaunchKernelGGL(edge_head_dz_sums_kernel<8>, dim3(gs), dim3(256), 0, st, a); break;
-        case 16: hipLaunchKernelGGL(edge_head_dz_sums_kernel<16>, dim3(gs), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL(edge_head_dz_sums_kernel<32>, dim3(gs), dim3(256), 0, st, a);
+        case 1: hipLaunchKernelGGL((edge_head_dz_sums_kernel<1, IT>), dim3(gs), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((edge_head_dz_sums_kernel<2, IT>), dim3(gs), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((edge_head_dz_sums_kernel<4, IT>), dim3(gs), dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((edge_head_dz_sums_kernel<8, IT>), dim3(gs), dim3(256), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((edge_head_dz_sums_kernel<16, IT>), dim3(gs), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((edge_head_dz_sums_kernel<32, IT>), dim3(gs), dim3(256), 0, st, a);
       }
       int rc = check_launch("edge_head_dz_sums");
       if (rc) return rc;
@@ -662,11 +666,11 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
       while (LP * 4 < F) LP <<= 1;
       int64_t gx = (R * LP + 255) / 256;  // 256 threads are a whole number of rows
       if (C <= 2) {
-        const int64_t cap = persistent_grid(edge_head_dz_expand_kernel<2>, 256) * 2;  // the helper caps at 4 blocks per CU
-        hipLaunchKernelGGL(edge_head_dz_expand_kernel<2>, dim3((unsigned)(gx < cap ? gx : cap)), dim3(256), 0, st, a, LP);
+        const int64_t cap = persistent_grid(edge_head_dz_expand_kernel<2, IT>, 256) * 2;  // the helper caps at 4 blocks per CU
+        hipLaunchKernelGGL((edge_head_dz_expand_kernel<2, IT>), dim3((unsigned)(gx < cap ? gx : cap)), dim3(256), 0, st, a, LP);
       } else {
-        const int64_t cap = persistent_grid(edge_head_dz_expand_kernel<kMaxC>, 256);
-        hipLaunchKernelGGL(edge_head_dz_expand_kernel<kMaxC>, dim3((unsigned)(gx < cap ? gx : cap)), dim3(256), 0, st, a, LP);
+        const int64_t cap = persistent_grid(edge_head_dz_expand_kernel<kMaxC, IT>, 256);
+        hipLaunchKernelGGL((edge_head_dz_expand_kernel<kMaxC, IT>), dim3((unsigned)(gx < cap ? gx : cap)), dim3(256), 0, st, a, LP);
       }
       rc = check_launch("edge_head_dz_expand");
       if (rc) return rc;
@@ -674,13 +678,13 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
     const int G = dz_lanes(F, E, R);
     const unsigned grid = (unsigned)((R * G + 255) / 256);
     switch (G) {
-      case 1: hipLaunchKernelGGL(edge_head_dz_kernel<1>, dim3(grid), dim3(256), smem, st, a); break;
-      case 2: hipLaunchKernelGGL(edge_head_dz_kernel<2>, dim3(grid), dim3(256), smem, st, a); break;
-      case 4: hipLaunchKernelGGL(edge_head_dz_kernel<4>, dim3(grid), dim3(256), smem, st, a); break;
-      case 8: hipLaunchKernelGGL(edge_head_dz_kernel<8>, dim3(grid), dim3(256), smem, st, a); break;
-      case 16: hipLaunchKernelGGL(edge_head_dz_kernel<16>, dim3(grid), dim3(256), smem, st, a); break;
-      case 32: hipLaunchKernelGGL(edge_head_dz_kernel<32>, dim3(grid), dim3(256), smem, st, a); break;
-      default: hipLaunchKernelGGL(edge_head_dz_kernel<64>, dim3(grid), dim3(256), smem, st, a);
+      case 1: hipLaunchKernelGGL((edge_head_dz_kernel<1, IT>), dim3(grid), dim3(256), smem, st, a); break;
+      case 2: hipLaunchKernelGGL((edge_head_dz_kernel<2, IT>), dim3(grid), dim3(256), smem, st, a); break;
+      case 4: hipLaunchKernelGGL((edge_head_dz_kernel<4, IT>), dim3(grid), dim3(256), smem, st, a); break;
+      case 8: hipLaunchKernelGGL((edge_head_dz_kernel<8, IT>), dim3(grid), dim3(256), smem, st, a); break;
+      case 16: hipLaunchKernelGGL((edge_head_dz_kernel<16, IT>), dim3(grid), dim3(256), smem, st, a); break;
+      case 32: hipLaunchKernelGGL((edge_head_dz_kernel<32, IT>), dim3(grid), dim3(256), smem, st, a); break;
+      default: hipLaunchKernelGGL((edge_head_dz_kernel<64, IT>), dim3(grid), dim3(256), smem, st, a);
     }
     int rc = check_launch("edge_head_dz");
     if (rc) return rc;
@@ -704,8 +708,8 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
       const size_t sm = (size_t)3 * 2 * F * C * sizeof(double);
       const int nj = (F + 63) / 64;
 #define TMGCN_DUW(NJ_)                                                                              \
-  if (C <= 2) hipLaunchKernelGGL((edge_head_du_wide_kernel<NJ_, 2, 8>), g, b, sm, st, a);           \
-  else hipLaunchKernelGGL((edge_head_du_wide_kernel<NJ_, kMaxC, (NJ_ <= 2 ? 4 : 2)>), g, b, sm, st, a);
+  if (C <= 2) hipLaunchKernelGGL((edge_head_du_wide_kernel<NJ_, 2, 8, IT>), g, b, sm, st, a);           \
+  else hipLaunchKernelGGL((edge_head_du_wide_kernel<NJ_, kMaxC, (NJ_ <= 2 ? 4 : 2), IT>), g, b, sm, st, a);
       switch (nj) {
         case 1: TMGCN_DUW(1) break;
         case 2: TMGCN_DUW(2) break;
@@ -715,7 +719,7 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
 #undef TMGCN_DUW
     } else {
       const size_t smem = (size_t)a.du_edges * (2 * F + C) * sizeof(float);
-      hipLaunchKernelGGL(edge_head_du_kernel, dim3((unsigned)chunks), dim3(256), smem, st, a);
+      hipLaunchKernelGGL(edge_head_du_kernel<IT>, dim3((unsigned)chunks), dim3(256), smem, st, a);
     }
     int rc = check_launch("edge_head_du");
     if (rc) return rc;
@@ -725,4 +729,36 @@ extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const
     return check_launch("edge_head_du_reduce");
   }
   return TMGCN_OK;
+}
+
+extern "C" int tmgcn_edge_head_fwd_f32(const float* Z, const int64_t* src, const int64_t* dst,
+                                        const float* U, float* out, int64_t E, int32_t F, int32_t C,
+                                        void* stream) {
+  return edge_head_fwd_impl<int64_t>(Z, src, dst, U, out, E, F, C, stream);
+}
+
+extern "C" int tmgcn_edge_head_fwd_i32_f32(const float* Z, const int32_t* src, const int32_t* dst,
+                                            const float* U, float* out, int64_t E, int32_t F, int32_t C,
+                                            void* stream) {
+  return edge_head_fwd_impl<int32_t>(Z, src, dst, U, out, E, F, C, stream);
+}
+
+extern "C" int tmgcn_edge_head_bwd_f32(const float* Z, const int64_t* src, const int64_t* dst,
+                                        const float* U, const float* dout, const int64_t* eptr,
+                                        const int64_t* eidx, float* dZ, float* dU, int64_t R, int64_t E,
+                                        int32_t F, int32_t C, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
+  return edge_head_bwd_impl<int64_t>(Z, src, dst, U, dout, eptr, eidx, dZ, dU, R, E, F, C, workspace, workspace_bytes,
+                                     stream);
+}
+
+extern "C" int tmgcn_edge_head_bwd_i32_f32(const float* Z, const int32_t* src, const int32_t* dst,
+                                            const float* U, const float* dout, const int32_t* eptr,
+                                            const int32_t* eidx, float* dZ, float* dU, int64_t R, int64_t E,
+                                            int32_t F, int32_t C, void* workspace, int64_t workspace_bytes,
+                                            void* stream) {
+  TMGCN_REQUIRE(R < (int64_t)0x7fffffff && 2 * E < (int64_t)0x7fffffff, "edge_head_bwd_i32: R=%lld or 2E=%lld does not fit 31 bits",
+                (long long)R, (long long)(2 * E));
+  return edge_head_bwd_impl<int32_t>(Z, src, dst, U, dout, eptr, eidx, dZ, dU, R, E, F, C, workspace, workspace_bytes,
+                                     stream);
 }

@@ -223,16 +223,23 @@ Tensor bgemm_dW(const Tensor& A, const Tensor& dY, bool per_slice, int64_t algo)
 Tensor edge_head_fwd(const Tensor& Z2, const Tensor& src, const Tensor& dst, const Tensor& U) {
   want(Z2, "edge_head Z");
   want(U, "edge_head U");
-  want(src, "edge_head src", at::kLong);
-  want(dst, "edge_head dst", at::kLong);
+  const bool i32 = src.defined() && src.scalar_type() == at::kInt;  // EdgeIndex keeps 32-bit arrays where they fit
+  want(src, "edge_head src", i32 ? at::kInt : at::kLong);
+  want(dst, "edge_head dst", i32 ? at::kInt : at::kLong);
   TORCH_CHECK(Z2.dim() == 2 && U.dim() == 2 && U.size(0) == 2 * Z2.size(1), "edge_head: U ", U.sizes(),
               " does not match F=", Z2.size(1));
+  TORCH_CHECK(src.numel() == dst.numel(), "edge_head: src and dst differ in length");
   c10::DeviceGuard g(Z2.device());
   const int64_t E = src.numel(), F = Z2.size(1), C = U.size(1);
   Tensor out = at::empty({E, C}, Z2.options());
-  ok(tmgcn_edge_head_fwd_f32((const float*)ptr(Z2), (const int64_t*)ptr(src), (const int64_t*)ptr(dst),
-                             (const float*)ptr(U), (float*)ptr(out), E, (int32_t)F, (int32_t)C, stream_of(Z2)),
-     "tmgcn_edge_head_fwd_f32");
+  if (i32)
+    ok(tmgcn_edge_head_fwd_i32_f32((const float*)ptr(Z2), (const int32_t*)ptr(src), (const int32_t*)ptr(dst),
+                                   (const float*)ptr(U), (float*)ptr(out), E, (int32_t)F, (int32_t)C, stream_of(Z2)),
+       "tmgcn_edge_head_fwd_i32_f32");
+  else
+    ok(tmgcn_edge_head_fwd_f32((const float*)ptr(Z2), (const int64_t*)ptr(src), (const int64_t*)ptr(dst),
+                               (const float*)ptr(U), (float*)ptr(out), E, (int32_t)F, (int32_t)C, stream_of(Z2)),
+       "tmgcn_edge_head_fwd_f32");
   return out;
 }
 
@@ -242,8 +249,12 @@ std::tuple<Tensor, Tensor> edge_head_bwd(const Tensor& Z2, const Tensor& src, co
   want(Z2, "edge_head Z");
   want(U, "edge_head U");
   want(dout, "edge_head dout");
-  want(eptr, "edge_head eptr", at::kLong);
-  want(eidx, "edge_head eidx", at::kLong);
+  const bool i32 = src.defined() && src.scalar_type() == at::kInt;
+  const auto it = i32 ? at::kInt : at::kLong;
+  want(src, "edge_head src", it);
+  want(dst, "edge_head dst", it);
+  want(eptr, "edge_head eptr", it);
+  want(eidx, "edge_head eidx", it);
   c10::DeviceGuard g(Z2.device());
   const int64_t R = Z2.size(0), F = Z2.size(1), C = U.size(1), E = src.numel();
   TORCH_CHECK(eptr.numel() == R + 1 && eidx.numel() == 2 * E, "edge_head_bwd: inverted index does not match R=", R,
@@ -252,11 +263,18 @@ std::tuple<Tensor, Tensor> edge_head_bwd(const Tensor& Z2, const Tensor& src, co
   Tensor dU = need_du ? at::empty_like(U) : Tensor();
   const int64_t need = tmgcn_edge_head_bwd_workspace_bytes(E, (int32_t)F, (int32_t)C);
   Tensor ws = at::empty({need > 0 ? need : 1}, Z2.options().dtype(at::kByte));
-  ok(tmgcn_edge_head_bwd_f32((const float*)ptr(Z2), (const int64_t*)ptr(src), (const int64_t*)ptr(dst),
-                             (const float*)ptr(U), (const float*)ptr(dout), (const int64_t*)ptr(eptr),
-                             (const int64_t*)ptr(eidx), (float*)ptr(dZ), (float*)ptr(dU), R, E, (int32_t)F,
-                             (int32_t)C, ptr(ws), ws.numel(), stream_of(Z2)),
-     "tmgcn_edge_head_bwd_f32");
+  if (i32)
+    ok(tmgcn_edge_head_bwd_i32_f32((const float*)ptr(Z2), (const int32_t*)ptr(src), (const int32_t*)ptr(dst),
+                                   (const float*)ptr(U), (const float*)ptr(dout), (const int32_t*)ptr(eptr),
+                                   (const int32_t*)ptr(eidx), (float*)ptr(dZ), (float*)ptr(dU), R, E, (int32_t)F,
+                                   (int32_t)C, ptr(ws), ws.numel(), stream_of(Z2)),
+       "tmgcn_edge_head_bwd_i32_f32");
+  else
+    ok(tmgcn_edge_head_bwd_f32((const float*)ptr(Z2), (const int64_t*)ptr(src), (const int64_t*)ptr(dst),
+                               (const float*)ptr(U), (const float*)ptr(dout), (const int64_t*)ptr(eptr),
+                               (const int64_t*)ptr(eidx), (float*)ptr(dZ), (float*)ptr(dU), R, E, (int32_t)F,
+                               (int32_t)C, ptr(ws), ws.numel(), stream_of(Z2)),
+       "tmgcn_edge_head_bwd_f32");
   return {dZ.defined() ? dZ : none_like(Z2), dU.defined() ? dU : none_like(Z2)};
 }
 

@@ -71,10 +71,16 @@ class EdgeIndex:
                 raise EdgeIndexError(f"edge {j} = (slice {int(e[0, j])}, src {int(e[1, j])}, dst {int(e[2, j])}) is outside "
                                      f"the embedding tensor (T={T}, N={N})")
         e = e.to(device=device, dtype=torch.int64)
-        self.src = (e[0] * N + e[1]).contiguous()
-        self.dst = (e[0] * N + e[2]).contiguous()
-        self.E = int(self.src.numel())
+        src, dst = e[0] * N + e[1], e[0] * N + e[2]
+        self.E = int(src.numel())
         self.T = T
+        # The kernels are gather-bound and the index arrays are a third of what they read: on the
+        # device they are kept in 32 bits whenever every row index and 2·E fit (always, for the
+        # reference's experiments), in the reference's 64 bits otherwise.
+        small = T is not None and T * N < 2 ** 31 - 1 and 2 * self.E < 2 ** 31 - 1
+        self.index_dtype = torch.int32 if (small and e.device.type == "cuda") else torch.int64
+        self.src = src.to(self.index_dtype).contiguous()
+        self.dst = dst.to(self.index_dtype).contiguous()
         self._inv = None
 
     def inverted(self, R: int):
@@ -84,12 +90,15 @@ class EdgeIndex:
                            int(self.src.min()) < 0 or int(self.dst.min()) < 0):
                 raise EdgeIndexError("edge index out of range for the embedding matrix")
             ids = torch.arange(self.E, device=self.src.device, dtype=torch.int64) * 2
-            rows = torch.cat((self.src, self.dst))
+            rows = torch.cat((self.src, self.dst)).long()
             ent = torch.cat((ids, ids + 1))
             order = torch.sort(rows, stable=True).indices
             eptr = torch.zeros(R + 1, dtype=torch.int64, device=self.src.device)
             torch.cumsum(torch.bincount(rows, minlength=R), 0, out=eptr[1:])
-            self._inv = (R, eptr, ent[order].contiguous())
+            it = self.index_dtype if R < 2 ** 31 - 1 else torch.int64
+            if it != self.index_dtype:     # the four arrays go to one entry point: one width
+                self.index_dtype, self.src, self.dst = it, self.src.to(it), self.dst.to(it)
+            self._inv = (R, eptr.to(it), ent[order].to(it).contiguous())
         return self._inv[1], self._inv[2]
 
 
@@ -435,7 +444,7 @@ def edge_head(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, fuse: Optional
             return kernels.ops.edge_head(Z, U.contiguous(), edges.src, edges.dst, eptr, eidx)
         return _EdgeHead.apply(Z.contiguous(), U.contiguous(), edges)
     Zf = Z.reshape(-1, F)
-    return torch.matmul(torch.cat((Zf[edges.src], Zf[edges.dst]), dim=1), U)
+    return torch.matmul(torch.cat((Zf[edges.src.long()], Zf[edges.dst.long()]), dim=1), U)
 
 
 def activation(x: torch.Tensor, act) -> torch.Tensor:

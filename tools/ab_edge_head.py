@@ -21,6 +21,9 @@ def load(path):
     lib.tmgcn_edge_head_bwd_workspace_bytes.restype = i64
     lib.tmgcn_edge_head_bwd_workspace_bytes.argtypes = [i64, i32, i32]
     lib.tmgcn_edge_head_bwd_f32.argtypes = [p, p, p, p, p, p, p, p, p, i64, i64, i32, i32, p, i64, p]
+    if hasattr(lib, "tmgcn_edge_head_fwd_i32_f32"):
+        lib.tmgcn_edge_head_fwd_i32_f32.argtypes = lib.tmgcn_edge_head_fwd_f32.argtypes
+        lib.tmgcn_edge_head_bwd_i32_f32.argtypes = lib.tmgcn_edge_head_bwd_f32.argtypes
     return lib
 
 
@@ -28,6 +31,7 @@ names = sys.argv[1:] or sorted(os.path.basename(os.path.dirname(f)) for f in glo
 libs = {"default": load(root + "/tm-gcn_amd/libtmgcn_hip.so")}
 for n in names:
     libs[n] = load(f"{root}/build/variants/{n}/libtmgcn_hip.so")
+libs["i32"] = libs["default"]      # the same library through its 32-bit-index entry points
 
 F, Cn = int(os.environ.get("AB_F", 6)), int(os.environ.get("AB_C", 2))
 T, N = int(os.environ.get("AB_T", 65)), int(os.environ.get("AB_N", 3800))
@@ -51,7 +55,16 @@ ptr = lambda x: C.c_void_p(x.data_ptr())
 ws = torch.empty(max(int(libs["default"].tmgcn_edge_head_bwd_workspace_bytes(E, F, Cn)), 1) * 2, dtype=torch.uint8, device="cuda")
 
 
-def run(lib, which, out):
+src32, dst32, eptr32, eidx32 = src.int(), dst.int(), eptr.int(), eidx.int()
+
+
+def run(lib, which, out, name=""):
+    if name == "i32":
+        if which == "fwd":
+            return lib.tmgcn_edge_head_fwd_i32_f32(ptr(Z), ptr(src32), ptr(dst32), ptr(U), ptr(out), E, F, Cn, st)
+        dz, du = (ptr(out), None) if which == "dZ" else (None, ptr(out))
+        return lib.tmgcn_edge_head_bwd_i32_f32(ptr(Z), ptr(src32), ptr(dst32), ptr(U), ptr(dout), ptr(eptr32), ptr(eidx32),
+                                               dz, du, R, E, F, Cn, ptr(ws), ws.numel(), st)
     if which == "fwd":
         return lib.tmgcn_edge_head_fwd_f32(ptr(Z), ptr(src), ptr(dst), ptr(U), ptr(out), E, F, Cn, st)
     if which == "dZ":
@@ -66,13 +79,13 @@ res, outs = {}, {}
 for which in ("fwd", "dZ", "dU"):
     for name, lib in libs.items():
         outs[(which, name)] = torch.zeros(*shapes[which], device="cuda")
-        assert run(lib, which, outs[(which, name)]) == 0, (which, name)
+        assert run(lib, which, outs[(which, name)], name) == 0, (which, name)
     torch.cuda.synchronize()
     for rnd in range(9):
         for name, lib in libs.items():
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            run(lib, which, outs[(which, name)])
+            run(lib, which, outs[(which, name)], name)
             e.record()
             torch.cuda.synchronize()
             res.setdefault((which, name), []).append(s.elapsed_time(e) * 1e3)
