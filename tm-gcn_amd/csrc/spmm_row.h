@@ -6,6 +6,9 @@
 #ifndef TMGCN_NT_COLVAL
 #define TMGCN_NT_COLVAL 0   // 1: stream (col,val) with non-temporal loads
 #endif
+#ifndef TMGCN_NT_GATHER
+#define TMGCN_NT_GATHER 0   // 1: gather the X rows with non-temporal loads (A/B: see DESIGN.md §4)
+#endif
 #ifndef TMGCN_NT_STORE
 #define TMGCN_NT_STORE 1    // 1: non-temporal stores for the SpMM / fused outputs (A/B: -1.5 % on the fused kernel)
 #endif
@@ -67,7 +70,15 @@ __device__ __forceinline__ float4 gather_row(const int32_t* __restrict__ col,
         const int cc = __shfl(c, idx & 63);
         vv[u] = __shfl(v, idx & 63);
         x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if TMGCN_NT_GATHER
+        if (idx < n && f_ok) {
+          typedef float g_f4 __attribute__((ext_vector_type(4)));
+          const g_f4 t = __builtin_nontemporal_load(reinterpret_cast<const g_f4*>(Xs + (int64_t)cc * F4 + fl));
+          x[u] = make_float4(t.x, t.y, t.z, t.w);
+        }
+#else
         if (idx < n && f_ok) x[u] = Xs[(int64_t)cc * F4 + fl];
+#endif
         if (idx >= n) vv[u] = 0.f;
       }
 #pragma unroll
