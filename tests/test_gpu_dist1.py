@@ -50,3 +50,48 @@ def test_world1_rccl_paths_match_unsharded(pg, exchange, pipeline, F0, condensed
             assert_close(layer.to_node_sharded(Y.detach()), Y.detach(), 0.0, "to_node_sharded at G=1")
     for a, b, what in zip(res[1], res[0], ("Y", "dX", "dW")):
         assert_close(a, b, REL_TOL, f"{exchange} pipeline={pipeline} {what}")
+
+
+MODEL_CASES = {
+    "gcn2_twice_selu": ("gcn2", dict(condensed_W=True, use_Minv=False, apply_M_twice=True, nonlin2="selu")),
+    "gcn2_three_relu_per_slice_W": ("gcn2", dict(condensed_W=False, use_Minv=False, apply_M_twice=True,
+                                                  apply_M_three_times=True, nonlin2="relu")),
+    "gcn2_default_leaky": ("gcn2", dict(condensed_W=True, use_Minv=False, nonlin2="leaky")),
+    "gcn_minv": ("gcn", dict(condensed_W=True, use_Minv=True)),
+    "gcn_per_slice_W": ("gcn", dict(condensed_W=False, use_Minv=False)),
+    "kwgcn_2layer_selu": ("kw", dict(nonlin2="selu")),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MODEL_CASES))
+def test_world1_rccl_sharded_models_match_unsharded(pg, name):
+    """The drop-in models with ``group=`` — SliceShard's padded all-gather / reduce-scatter, the
+    all-reduce of shared weights' gradients and the rank-major logits gather — through RCCL itself
+    (world size 1: the collectives are issued and take RCCL's dtype / contiguity checks; the
+    world-size-2/3 logic is pinned on CPU by test_dist_models_gloo.py and on the device over gloo by
+    test_gpu_dist_models.py).  Same seed => same weights; logits and every gradient must agree."""
+    import tmgcn_amd.layers as ehf
+    kind, kw = MODEL_CASES[name]
+    T, N = 7, 90
+    g = synth.dynamic_graph(T, N, edges_per_slice=200, seed=5, no_diag=3, F0=3)
+    At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
+    edges = torch.from_numpy(g.edges)
+    gen = torch.Generator().manual_seed(11)
+    out = []
+    for group in (None, dist.group.WORLD):
+        torch.manual_seed(3)
+        if kind == "gcn":
+            m = ehf.EmbeddingGCN(At, X, edges, M, hidden_feat=[6, 2], group=group, **kw)
+        elif kind == "gcn2":
+            m = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=[6, 6, 2], group=group, **kw)
+        else:
+            m = ehf.EmbeddingKWGCN(At, X, edges, hidden_feat=[6, 6, 2], group=group, **kw)
+        logits = m()
+        if not out:
+            dlogits = torch.randn(logits.shape, generator=gen).cuda()
+        logits.backward(dlogits)
+        torch.cuda.synchronize()
+        out.append((logits.detach(), {n: q.grad.clone() for n, q in m.named_parameters()}))
+    assert_close(out[1][0], out[0][0], REL_TOL, f"{name} logits")
+    for n in out[0][1]:
+        assert_close(out[1][1][n], out[0][1][n], REL_TOL, f"{name} d{n}")
