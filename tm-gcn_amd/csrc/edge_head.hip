@@ -15,6 +15,13 @@
 //        in fixed order.
 // Everything is summed in a fixed order: bitwise reproducible (torch's index_put backward on
 // the GPU uses float atomics and is not).
+//
+// Each of the three has a generic form (G lanes per edge / row, any F <= 256, C <= 8) and the
+// specialisations the launcher picks from the widths, the average row degree and the pointer
+// alignment: *_small<F,C> for the reference's own heads (even F <= 8, C <= 4: one edge per lane,
+// everything in registers), for wide heads a two-kernel dZ (entry sums, then an in-place expand)
+// and a lane-per-feature dU.  All forms produce the same bits (tools/ab_edge_head.py).  The index
+// arrays are int64 (the reference's) or int32 (template parameter IT; the *_i32 entry points).
 #include "common.h"
 
 namespace tmgcn {
