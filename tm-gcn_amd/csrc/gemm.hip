@@ -11,8 +11,12 @@
 //                  persistent loop, so W is read once per block.  The k index inside a
 //                  step is permuted (lane half h takes k = 8j+4h+s) so that one
 //                  ds_read_b128 feeds four MFMAs.
+//                  gemm_bf16x3<1> takes a weight STORED in bf16 as it is (three plane products).
 //   gemm_small     thread-per-row FMA kernel for the reference's real sizes (2x6, 6x6, 12x2):
-//                  MFMA tiles would be >90 % padding there; the op is a pure HBM stream.
+//                  MFMA tiles would be >90 % padding there; the op is a pure HBM stream
+//                  (outputs leave through an LDS tile as one coalesced stream).
+//   gemm_dw_narrow dW for even K, Nf <= 8: per-lane fp64 register sums, one block fold at the end;
+//   gemm_dw_small  the general small-shape dW (LDS-staged rows).
 //   gemm_dw_bf16x3 dW = AᵀdY on the bf16 matrix cores after an exact 3-way split of the fp32 operands
 //                  (fp32-accurate, reproducible; the default for K, Nf >= 16) — see the kernel.
 //   gemm_dw_lds    the exact-f32 MFMA form of the same product.  The reduction index is the row r, so the MFMA operands have the
