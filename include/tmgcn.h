@@ -53,7 +53,7 @@ const char* tmgcn_last_error(void);
 /* algorithm of tmgcn_gemm_f32 (instruction choice only; both fp32-accurate and reproducible) */
 enum {
   TMGCN_GEMM_AUTO = 0,    /* bf16 matrix cores after an exact 3-way split of the fp32 operands where the shapes
-                             allow (K a multiple of 4 in [16, 128], 16-byte aligned A), else exact f32 */
+                             allow (K a multiple of 4 in [16, 512] — above 128 as 128-wide k-chunks —, 16-byte aligned A), else exact f32 */
   TMGCN_GEMM_F32MFMA = 1  /* always the exact-f32 MFMA kernel: bitwise an fmaf chain in k order */
 };
 

@@ -224,4 +224,4 @@ def test_reserved_register_zone_is_untouched_by_compiler_code():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_reserved_vgprs.py")], capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(": OK") == 3, r.stdout   # two instantiations of the GEMM + the M-transform
+    assert r.stdout.count(": OK") == 5, r.stdout   # four instantiations of the GEMM + the M-transform

@@ -190,7 +190,8 @@ def ref_gemm(A, W, trans_w=False, per_slice=False):
 
 
 @pytest.mark.parametrize("K,Nf", [(2, 6), (6, 6), (6, 2), (12, 2), (16, 16), (128, 128), (128, 64), (100, 50),
-                                  (32, 200), (300, 40), (7, 33), (64, 5)])
+                                  (32, 200), (300, 40), (7, 33), (64, 5),
+                                  (132, 64), (256, 128), (384, 100), (512, 36), (516, 16)])   # k-chunked split kernel; 516: past it
 @pytest.mark.parametrize("per_slice", [False, True])
 @pytest.mark.parametrize("trans_w", [False, True])
 def test_gemm(K, Nf, per_slice, trans_w):
@@ -204,7 +205,7 @@ def test_gemm(K, Nf, per_slice, trans_w):
 
 
 @pytest.mark.parametrize("K,Nf", [(2, 6), (6, 2), (16, 16), (128, 128), (128, 64), (64, 100), (100, 50), (36, 200),
-                                  (300, 40)])
+                                  (300, 40), (256, 128), (132, 32)])
 @pytest.mark.parametrize("per_slice", [False, True])
 @pytest.mark.parametrize("trans_w", [False, True])
 def test_gemm_bf16_stored_weight(K, Nf, per_slice, trans_w):
@@ -243,7 +244,7 @@ def test_gemm_bf16_stored_weight_autograd_and_ragged_tiles():
 
 
 @pytest.mark.parametrize("act", ["relu", "leaky", "selu"])
-@pytest.mark.parametrize("K,Nf", [(2, 6), (128, 128)])
+@pytest.mark.parametrize("K,Nf", [(2, 6), (128, 128), (256, 64), (200, 130)])
 def test_gemm_fused_activation(act, K, Nf):
     from oracle import tmgcn_oracle as orc
     A = torch.randn(2, 100, K, generator=torch.Generator().manual_seed(1))

@@ -52,6 +52,10 @@ struct GemmArgs {
   unsigned int* tile_counter;  // dynamic tile scheduling (common.h); one counter per blockIdx.y strip
   int32_t w_bf16;              // W holds bf16 elements (tmgcn_gemm_bf16w_f32): W points at uint16_t
   int32_t stage_off;           // gemm_small: float offset of the output tile in dynamic LDS (0 = store directly)
+  // gemm_bf16x3<WP, true> — one 128-wide k-chunk of a wider product (128 < K <= 512): K above is the
+  // chunk's width, lda the full row length of A (and of a transposed W), k0 the chunk's first k;
+  // accum: add to what Y already holds (every chunk but the first)
+  int32_t lda, k0, accum;
 };
 
 // element (k, n) of the operator at element offset woff (the batch's weight) of W, fp32 or bf16 storage
@@ -209,7 +213,8 @@ struct GxTile {
 // activation + stores of one 64-row tile.  C/D map of the 32x32 MFMA: col = lane&31,
 // row = (i&3) + 8*(i>>2) + 4*(lane>>5).  One 64-bit base per lane and 32-bit row offsets; whole
 // tiles take the branch-free path.
-template <int ACT>
+// ADD: the tile is one k-chunk's contribution — add what Y already holds before the activation
+template <int ACT, bool ADD = false>
 __device__ __forceinline__ void gx_store_rows(const f32x16 (&acc)[2], float* yb, float* pb, int Nf, int tile_rows,
                                               int rows_left) {
   if (tile_rows == BM) {
@@ -218,7 +223,8 @@ __device__ __forceinline__ void gx_store_rows(const f32x16 (&acc)[2], float* yb,
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int off = (mb * 32 + (i & 3) + 8 * (i >> 2)) * Nf;
-        const float sv = acc[mb][i];
+        float sv = acc[mb][i];
+        if (ADD) sv += yb[off];
         if (pb) pb[off] = sv;
         yb[off] = act_apply(sv, ACT);
       }
@@ -229,7 +235,8 @@ __device__ __forceinline__ void gx_store_rows(const f32x16 (&acc)[2], float* yb,
       for (int i = 0; i < 16; ++i) {
         const int rr = mb * 32 + (i & 3) + 8 * (i >> 2);
         if (rr < rows_left) {
-          const float sv = acc[mb][i];
+          float sv = acc[mb][i];
+          if (ADD) sv += yb[rr * Nf];
           if (pb) pb[rr * Nf] = sv;
           yb[rr * Nf] = act_apply(sv, ACT);
         }
@@ -241,7 +248,7 @@ __device__ __forceinline__ void gx_store_rows(const f32x16 (&acc)[2], float* yb,
 // quad) is transposed in registers (quad_transpose4), after which lane j of a quad owns row j and
 // columns 4q..4q+3.  y0 / p0 point at (tile row 0, this wave's column strip); needs Nf % 4 == 0 and
 // 16-byte aligned outputs (checked by the caller).  Rows past the tile's end are predicated off.
-template <int ACT>
+template <int ACT, bool ADD = false>
 __device__ __forceinline__ void gx_store_rows_v4(const f32x16 (&acc)[2], float* y0, float* p0, int Nf, int rows,
                                                  int li, int lh, bool cols_ok) {
   // opaque copies: otherwise the eight row offsets and row tests are hoisted out of the tile loop as
@@ -257,6 +264,13 @@ __device__ __forceinline__ void gx_store_rows_v4(const f32x16 (&acc)[2], float* 
       const int rr = mb * 32 + 8 * g + 4 * lh + j;
       if (rr < rows && cols_ok) {
         const int off = rr * Nf + 4 * q;
+        if (ADD) {
+          const float4 old = *reinterpret_cast<const float4*>(y0 + off);
+          v[0] += old.x;
+          v[1] += old.y;
+          v[2] += old.z;
+          v[3] += old.w;
+        }
         if (p0) *reinterpret_cast<float4*>(p0 + off) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(y0 + off) =
             make_float4(act_apply(v[0], ACT), act_apply(v[1], ACT), act_apply(v[2], ACT), act_apply(v[3], ACT));
@@ -269,7 +283,9 @@ __device__ __forceinline__ void gx_store_rows_v4(const f32x16 (&acc)[2], float* 
 // bf16 (tmgcn_gemm_bf16w_f32: the weight IS its high plane, three products per term, a third of the
 // fragment registers) — the same sums in the same order, so bf16 W gives bit-identical results to
 // its fp32-widened copy at half the matrix-core work.
-template <int WP>
+// CH = the launch is one k-chunk of a product wider than 128 (see GemmArgs::lda): the non-chunked
+// instantiations compile to exactly the code they had before the chunked form existed.
+template <int WP, bool CH = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[3 * GX_PLANE];
   const int lane = threadIdx.x & 63;
@@ -293,14 +309,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   // Wop[k][n] = W[k*sk + n*sn]; this lane's column n0+li, clamped (columns / rows outside are zeroed by
   // the mask, so the 64 loads are unconditional: no exec-mask branches)
   const int ncol = n0 + li < a.Nf ? n0 + li : a.Nf - 1;
-  const int sk = a.trans_w ? 1 : a.Nf, sn = a.trans_w ? a.K : 1;
+  const int LD = CH ? a.lda : a.K;  // row length of A / of a transposed W in memory
+  const int sk = a.trans_w ? 1 : a.Nf, sn = a.trans_w ? LD : 1;
   const float zn = n0 + li < a.Nf ? 1.f : 0.f;
-  auto load_w = [&](int64_t woff) {
+  auto load_w = [&](int64_t woff) __attribute__((always_inline)) {
     int koff = 8 * lh;
     // opaque to the optimiser: otherwise the 64 loop-invariant element offsets are hoisted out of
     // the tile loop into 64 VGPRs (and spilled) for a routine that runs once per weight
     asm volatile("" : "+v"(koff));
-    const int64_t wl = woff + (int64_t)ncol * sn;
+    const int64_t wl = woff + (int64_t)ncol * sn + (CH ? (int64_t)a.k0 * sk : 0);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
@@ -320,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
       }
   };
   // the plane products of one (k-step, row block): small terms first
-  auto products = [&](f32x16& c, const gx_bf16x8 ah, const gx_bf16x8 am, const gx_bf16x8 al, int ks) {
+  auto products = [&](f32x16& c, const gx_bf16x8 ah, const gx_bf16x8 am, const gx_bf16x8 al, int ks) __attribute__((always_inline)) {
     const gx_bf16x8 bh = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
     if constexpr (WP == 3) {
       const gx_bf16x8 bm = __builtin_bit_cast(gx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   // flight across the barriers.  With compiler-visible loads hipcc drains the queue (vmcnt(0)) at
   // the first use after the branches of the epilogue, which degrades a two-deep ring to a one-deep
   // one (measured in round 1 on the dW kernel).
-  auto tile_rows = [&](unsigned tile) {  // tile ids fit 31 bits (checked by the launcher): 32-bit scalar arithmetic
+  auto tile_rows = [&](unsigned tile) __attribute__((always_inline)) {  // tile ids fit 31 bits (checked by the launcher): 32-bit scalar arithmetic
     const unsigned tpb = (unsigned)a.tiles_per_batch;
     const unsigned b = tile / tpb;
     GxTile t;
@@ -359,13 +376,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   };
   // scalar base of the tile + a 32-bit per-lane offset: no 64-bit address pairs held in VGPRs.
   // No conditional load: rows past the end re-read the tile's last row and are zeroed at the split.
-  auto fetch = [&](auto set, const GxTile& t) {
+  auto fetch = [&](auto set, const GxTile& t) __attribute__((always_inline)) {
     constexpr int SET = decltype(set)::value;
-    const float* tbase = a.A + t.row0 * a.K;
-    auto voff = [&](int i) {
+    const float* tbase = a.A + t.row0 * LD + (CH ? a.k0 : 0);
+    auto voff = [&](int i) __attribute__((always_inline)) {
       int rr = rg + 8 * i;
       if (rr >= t.rows) rr = t.rows - 1;
-      return (unsigned)(rr * a.K + qcol) * 4u;
+      return (unsigned)(rr * LD + qcol) * 4u;
     };
     stage8_load_s<SET, 0>(voff(0), tbase);
     stage8_load_s<SET, 1>(voff(1), tbase);
@@ -376,14 +393,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
     stage8_load_s<SET, 6>(voff(6), tbase);
     stage8_load_s<SET, 7>(voff(7), tbase);
   };
-  auto landed = [&](bool newer_in_flight) {  // the OLDER set's 8 loads are complete
+  auto landed = [&](bool newer_in_flight) __attribute__((always_inline)) {  // the OLDER set's 8 loads are complete
     if (newer_in_flight)
       TMGCN_WAIT_VM(8);
     else
       TMGCN_WAIT_VM(0);
   };
-  auto zrow = [&](int i, const GxTile& t) { return (rg + 8 * i < t.rows) ? zq : 0.f; };  // 0 for rows / k-quads outside
-  auto split_one = [&](const stage_f32x4& v, int i) {  // v arrives masked (stage8_read_mul)
+  auto zrow = [&](int i, const GxTile& t) __attribute__((always_inline)) { return (rg + 8 * i < t.rows) ? zq : 0.f; };  // 0 for rows / k-quads outside
+  auto split_one = [&](const stage_f32x4& v, int i) __attribute__((always_inline)) {  // v arrives masked (stage8_read_mul)
     unsigned h0, m0, l0, h1, m1, l1;
     gx_split3(v[0], v[1], h0, m0, l0);
     gx_split3(v[2], v[3], h1, m1, l1);
@@ -392,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
     *reinterpret_cast<uint2*>(w + GX_PLANE) = make_uint2(m0, m1);
     *reinterpret_cast<uint2*>(w + 2 * GX_PLANE) = make_uint2(l0, l1);
   };
-  auto split_store = [&](auto set, const GxTile& t) {
+  auto split_store = [&](auto set, const GxTile& t) __attribute__((always_inline)) {
     constexpr int SET = decltype(set)::value;
     split_one(stage8_read_mul<SET, 0>(zrow(0, t)), 0);
     split_one(stage8_read_mul<SET, 1>(zrow(1, t)), 1);
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   // and stores; the counted wait for the other staging set sits between the two
   int cur_batch = -1;
   f32x16 acc[2];
-  auto k_step = [&](int ks) {  // 2 row blocks x 6 plane products of one 16-deep k-step
+  auto k_step = [&](int ks) __attribute__((always_inline)) {  // 2 row blocks x 6 plane products of one 16-deep k-step
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       const unsigned char* p = rd + mb * 32 * GX_PITCH + ks * 32;
@@ -420,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
       products(acc[mb], ah, am, al, ks);
     }
   };
-  auto multiply = [&](const GxTile& tc) {
+  auto multiply = [&](const GxTile& tc) __attribute__((always_inline)) {
     if (tc.batch != cur_batch) {
       load_w(a.rows_per_batch ? (int64_t)tc.batch * a.w_batch_stride : 0);
       cur_batch = tc.batch;
@@ -438,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
       struct Frag3 {
         uint4 h, m, l;
       };
-      auto read_group = [&](int g) {
+      auto read_group = [&](int g) __attribute__((always_inline)) {
         const unsigned char* p = rd + (g & 1) * 32 * GX_PITCH + (g >> 1) * 32;
         Frag3 f;
         f.h = *reinterpret_cast<const uint4*>(p);
@@ -468,13 +485,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   // 16-byte stores need whole column quads inside Nf and aligned rows
   const bool v4 = (a.Nf % 4 == 0) && (reinterpret_cast<uintptr_t>(a.Y) % 16 == 0) &&
                   (!a.pre || reinterpret_cast<uintptr_t>(a.pre) % 16 == 0);
-  auto store_tile = [&](const GxTile& tc) {
+  auto store_tile = [&](const GxTile& tc) __attribute__((always_inline)) {
     if (!strip) return;
     if (v4) {  // every lane takes part in the quad transposes; columns past Nf are predicated off
       const int64_t base = tc.row0 * a.Nf + n0;
       float* y0 = a.Y + base;
       float* p0 = a.pre ? a.pre + base : nullptr;
       const bool cols_ok = n0 + 4 * (li >> 2) < a.Nf;
+      if constexpr (CH) {
+        if (a.accum) {
+          switch (a.act) {
+            case TMGCN_ACT_RELU: gx_store_rows_v4<TMGCN_ACT_RELU, true>(acc, y0, p0, a.Nf, tc.rows, li, lh, cols_ok); break;
+            case TMGCN_ACT_LEAKY: gx_store_rows_v4<TMGCN_ACT_LEAKY, true>(acc, y0, p0, a.Nf, tc.rows, li, lh, cols_ok); break;
+            case TMGCN_ACT_SELU: gx_store_rows_v4<TMGCN_ACT_SELU, true>(acc, y0, p0, a.Nf, tc.rows, li, lh, cols_ok); break;
+            default: gx_store_rows_v4<TMGCN_ACT_NONE, true>(acc, y0, p0, a.Nf, tc.rows, li, lh, cols_ok);
+          }
+          return;
+        }
+      }
       switch (a.act) {
         case TMGCN_ACT_RELU: gx_store_rows_v4<TMGCN_ACT_RELU>(acc, y0, p0, a.Nf, tc.rows, li, lh, cols_ok); break;
         case TMGCN_ACT_LEAKY: gx_store_rows_v4<TMGCN_ACT_LEAKY>(acc, y0, p0, a.Nf, tc.rows, li, lh, cols_ok); break;
@@ -489,6 +517,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
     float* yb = a.Y + base;
     float* pb = a.pre ? a.pre + base : nullptr;
     const int rows_left = tc.rows - 4 * lh;
+    if constexpr (CH) {
+      if (a.accum) {
+        switch (a.act) {
+          case TMGCN_ACT_RELU: gx_store_rows<TMGCN_ACT_RELU, true>(acc, yb, pb, a.Nf, tc.rows, rows_left); break;
+          case TMGCN_ACT_LEAKY: gx_store_rows<TMGCN_ACT_LEAKY, true>(acc, yb, pb, a.Nf, tc.rows, rows_left); break;
+          case TMGCN_ACT_SELU: gx_store_rows<TMGCN_ACT_SELU, true>(acc, yb, pb, a.Nf, tc.rows, rows_left); break;
+          default: gx_store_rows<TMGCN_ACT_NONE, true>(acc, yb, pb, a.Nf, tc.rows, rows_left);
+        }
+        return;
+      }
+    }
     switch (a.act) {  // chosen once per tile, not once per element
       case TMGCN_ACT_RELU: gx_store_rows<TMGCN_ACT_RELU>(acc, yb, pb, a.Nf, tc.rows, rows_left); break;
       case TMGCN_ACT_LEAKY: gx_store_rows<TMGCN_ACT_LEAKY>(acc, yb, pb, a.Nf, tc.rows, rows_left); break;
@@ -1207,7 +1246,7 @@ static int gemm_launch(const float* A, const void* W, bool w_bf16, float* Y, flo
   TMGCN_REQUIRE(A && W && Y, "gemm: null pointer");
   hipStream_t st = (hipStream_t)stream;
   GemmArgs a{A, static_cast<const float*>(W), Y, pre_act, R, K, Nf, trans_w, rows_per_batch, w_batch_stride,
-             act, 0, 0, nullptr, w_bf16 ? 1 : 0, 0};
+             act, 0, 0, nullptr, w_bf16 ? 1 : 0, 0, 0, 0, 0};
   if (use_small(K, Nf)) {
     const int Nfp = (Nf + 7) & ~7;
     const int64_t br = rows_per_batch ? rows_per_batch : R;
@@ -1231,6 +1270,29 @@ static int gemm_launch(const float* A, const void* W, bool w_bf16, float* Y, flo
   TMGCN_REQUIRE(a.n_tiles < (int64_t)0x7fffffff && gy <= 64, "gemm: shape too large for the tile scheduler");
   const bool x3 = algo == TMGCN_GEMM_AUTO && K % 4 == 0 && K >= 16 && K <= 128 &&
                   reinterpret_cast<uintptr_t>(A) % 16 == 0;
+  // 128 < K <= 512: the same kernel once per 128-wide k-chunk, every chunk after the first adding to
+  // Y (one more read of Y per chunk; still ~1.5-1.8x the exact-f32 MFMA kernel, which is compute-bound)
+  const bool x3_chunked = algo == TMGCN_GEMM_AUTO && K % 4 == 0 && K > 128 && K <= 512 &&
+                          reinterpret_cast<uintptr_t>(A) % 16 == 0;
+  if (x3_chunked) {
+    int64_t gx = w_bf16 ? persistent_grid(gemm_bf16x3_kernel<1, true>, 256) : persistent_grid(gemm_bf16x3_kernel<3, true>, 256);
+    if (gx > a.n_tiles) gx = a.n_tiles;
+    for (int k0 = 0; k0 < K; k0 += 128) {
+      GemmArgs c = a;
+      const bool last = k0 + 128 >= K;
+      c.K = last ? K - k0 : 128;
+      c.lda = K;
+      c.k0 = k0;
+      c.accum = k0 > 0;
+      c.act = last ? act : TMGCN_ACT_NONE;
+      c.pre = last ? pre_act : nullptr;
+      if (w_bf16)
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<1, true>), dim3((unsigned)gx, gy), dim3(256), 0, st, c);
+      else
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<3, true>), dim3((unsigned)gx, gy), dim3(256), 0, st, c);
+    }
+    return check_launch("gemm_bf16x3 (k-chunks)");
+  }
   if (x3) {  // static persistent schedule: no tile counter
     int64_t gx = w_bf16 ? persistent_grid(gemm_bf16x3_kernel<1>, 256) : persistent_grid(gemm_bf16x3_kernel<3>, 256);
     if (gx > a.n_tiles) gx = a.n_tiles;

@@ -29,12 +29,12 @@ names = sys.argv[1:] or sorted(os.path.basename(os.path.dirname(f)) for f in glo
 libs = {"default": load(root + "/tm-gcn_amd/libtmgcn_hip.so")}
 for n in names:
     libs[n] = load(f"{root}/build/variants/{n}/libtmgcn_hip.so")
-R, K, Nf = 8_000_000, 128, 128
+R, K, Nf = int(os.environ.get("AB_R", 8_000_000)), int(os.environ.get("AB_K", 128)), int(os.environ.get("AB_NF", 128))
 A = torch.rand(R, K, device="cuda")
 W = torch.randn(K, Nf, device="cuda")
 Wh = W.to(torch.bfloat16)
 dY = torch.rand(R, Nf, device="cuda")
-Y = torch.empty(R, Nf, device="cuda")
+Y = torch.empty(R, max(K, Nf), device="cuda")     # gemm writes [R,Nf], gemm_dA [R,K]
 dW = torch.empty(K, Nf, device="cuda")
 ws = torch.empty(int(libs["default"].tmgcn_gemm_dw_workspace_bytes(R, K, Nf, 0)), dtype=torch.uint8, device="cuda")
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
