@@ -402,14 +402,14 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
   // Row positions are recomputed per tile from an opaque copy of jg: hoisted out of the tile loop
   // they would pin 16 VGPRs of 64-bit offsets (plus 32 more for the stores below) beside the
   // 96-VGPR operator strip.
-  auto fetch = [&](auto set, unsigned tile) {  // no conditional load: columns past C re-read the last quad, rows past T_in the last row; zeroed at the split
+  auto fetch = [&](auto set, unsigned tile) __attribute__((always_inline)) {  // no conditional load: columns past C re-read the last quad, rows past T_in the last row; zeroed at the split
     constexpr int SET = decltype(set)::value;
     int64_t c = (int64_t)tile * MX_COLS + 4 * cq;
     if (c > last_quad) c = last_quad;
     const float* base = a.X + c;
     int jq = jg;
     asm volatile("" : "+v"(jq));
-    auto rowp = [&](int b, int i) {
+    auto rowp = [&](int b, int i) __attribute__((always_inline)) {
       const int j = 4 * (jq + 16 * b) + i;
       return base + row_pos(j < a.T_in ? j : a.T_in - 1, a.T_in, a.x_tl) * a.C;
     };
@@ -422,15 +422,15 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
     stage8_load<SET, 6>(rowp(1, 2));
     stage8_load<SET, 7>(rowp(1, 3));
   };
-  auto landed = [&](bool newer_in_flight) {  // the OLDER set's 8 loads are complete
+  auto landed = [&](bool newer_in_flight) __attribute__((always_inline)) {  // the OLDER set's 8 loads are complete
     if (newer_in_flight)
       TMGCN_WAIT_VM(8);
     else
       TMGCN_WAIT_VM(0);
   };
-  auto zrow = [&](int b, int i, float zc) { return (4 * (jg + 16 * b) + i < a.T_in) ? zc : 0.f; };  // 0 outside T_in / C
+  auto zrow = [&](int b, int i, float zc) __attribute__((always_inline)) { return (4 * (jg + 16 * b) + i < a.T_in) ? zc : 0.f; };  // 0 outside T_in / C
   auto split_block = [&](const stage_f32x4& s0, const stage_f32x4& s1, const stage_f32x4& s2, const stage_f32x4& s3,
-                         int b) {  // the four rows arrive masked (stage8_read_mul)
+                         int b) __attribute__((always_inline)) {  // the four rows arrive masked (stage8_read_mul)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       unsigned h0, m0, l0, h1, m1, l1;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
       *reinterpret_cast<uint2*>(w + 2 * MX_PLANE) = make_uint2(l0, l1);
     }
   };
-  auto split_store = [&](auto set, unsigned tile) {
+  auto split_store = [&](auto set, unsigned tile) __attribute__((always_inline)) {
     constexpr int SET = decltype(set)::value;
     const float zc = ((int64_t)tile * MX_COLS + 4 * cq < a.C) ? 1.f : 0.f;
     split_block(stage8_read_mul<SET, 0>(zrow(0, 0, zc)), stage8_read_mul<SET, 1>(zrow(0, 1, zc)),
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
   struct Frag3 {
     uint4 h, m, l;
   };
-  auto read_group = [&](int js, int cb) {  // X-plane fragments of j-step js, column block cb
+  auto read_group = [&](int js, int cb) __attribute__((always_inline)) {  // X-plane fragments of j-step js, column block cb
     const unsigned char* p = rd + (js >> 1) * MX_JB + cb * 8 * MX_QPITCH + (js & 1) * 32;
     Frag3 f;
     f.h = *reinterpret_cast<const uint4*>(p);
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
     f.l = *reinterpret_cast<const uint4*>(p + 2 * MX_PLANE);
     return f;
   };
-  auto six = [&](int js, int cb, const Frag3& f) {  // the six plane products of one (j-step, column block)
+  auto six = [&](int js, int cb, const Frag3& f) __attribute__((always_inline)) {  // the six plane products of one (j-step, column block)
     const mx_bf16x8 ah = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][0][0], am[js][0][1], am[js][0][2], am[js][0][3]));
     const mx_bf16x8 amid = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][1][0], am[js][1][1], am[js][1][2], am[js][1][3]));
     const mx_bf16x8 al = __builtin_bit_cast(mx_bf16x8, make_uint4(am[js][2][0], am[js][2][1], am[js][2][2], am[js][2][3]));
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
   // the three fragment reads of group g+1 are issued in front of the six MFMAs of group g
   // (sched_barrier pins the order), so a read has 192 cycles of matrix-pipe time to land instead of
   // being waited for right in front of its MFMA.
-  auto pipelined = [&](auto lo_tag, auto hi_tag) {
+  auto pipelined = [&](auto lo_tag, auto hi_tag) __attribute__((always_inline)) {
     constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value, NG = 2 * (HI - LO);
     Frag3 cur = read_group(LO, 0);
 #pragma unroll
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
       cur = nxt;
     }
   };
-  auto multiply = [&]() {
+  auto multiply = [&]() __attribute__((always_inline)) {
     if (!wave_live) return;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
   // registers x 4 columns on a lane quad) is transposed in registers (quad_transpose4, common.h):
   // lane j of a quad then owns row j and four consecutive columns — one 16-byte store per lane
   // instead of four dword stores (the dword epilogue is bound by store issue, not bandwidth).
-  auto store_tile = [&](unsigned tile) {
+  auto store_tile = [&](unsigned tile) __attribute__((always_inline)) {
     if (!wave_live) return;
     const int64_t c0 = (int64_t)tile * MX_COLS;
     int lq = li, kb = k0 + 4 * lh;
