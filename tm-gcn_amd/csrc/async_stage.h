@@ -20,6 +20,12 @@
 // s_waitcnt the data is moved into ordinary values with v_mov_b32 (16 moves per thread and step,
 // against ~200 VALU instructions of the split it feeds).  Volatile asm statements keep their
 // program order, so a TMGCN_Q_READ placed after TMGCN_WAIT_VM executes after it.
+//
+// Everything that uses these macros must be inlined into the kernel: the lambdas of the two kernels
+// carry __attribute__((always_inline)).  Left to the inliner's size heuristics a lambda can become an
+// out-of-line function (it happened when the chunked GEMM instantiations grew the kernel), in which
+// the scalar base of TMGCN_Q_LOAD_S arrives in VGPRs ("invalid operand" at assembly time — loud, at
+// least) and which would need its own reserved-zone check.
 #pragma once
 
 // 16-byte load into the reserved quad v[a:d]; 64-bit per-lane address
