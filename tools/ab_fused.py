@@ -28,7 +28,8 @@ libs = {"default": load(root + "/tm-gcn_amd/libtmgcn_hip.so")}
 for n in names:
     libs[n] = load(f"{root}/build/variants/{n}/libtmgcn_hip.so")
 
-T, N, F, deg = int(os.environ.get("AB_T", 4)), 2_000_000, 128, 32
+T, N, F, deg = (int(os.environ.get("AB_T", 4)), int(os.environ.get("AB_N", 2_000_000)), int(os.environ.get("AB_F", 128)),
+                int(os.environ.get("AB_DEG", 32)))
 A = synth.device_er_csr(T, N, deg, "cuda")
 X = torch.rand(T, N, F, device="cuda")
 W = torch.randn(F, F, device="cuda") * 0.1
@@ -62,4 +63,4 @@ for which in ("spmm", "fused", "fused+ax"):
 by = A.nnz * (8 + F * 4 + (4 + F * 4) / (A.nnz / A.n_rows))
 for (which, name), ms in res.items():
     med = statistics.median(ms)
-    print(f"{which:9s} {name:16s} median {med:7.2f} ms  min {min(ms):7.2f}  {by / med / 1e6:6.0f} GB/s")
+    print(f"{which:9s} {name:16s} median {med:8.3f} ms  min {min(ms):8.3f}  {by / med / 1e6:6.0f} GB/s")
