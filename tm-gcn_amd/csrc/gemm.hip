@@ -1254,7 +1254,7 @@ static int gemm_launch(const float* A, const void* W, bool w_bf16, float* Y, flo
     size_t smem = (size_t)max_w * K * Nfp * sizeof(float);
     TMGCN_REQUIRE(smem <= 64 * 1024, "gemm: per-slice weights too small a batch (%lld rows)",
                   (long long)br);
-    if (Nfp <= 32) {  // output tile through LDS: 256 rows x (Nfp + 1) floats, <= 33 KB
+    if (Nfp <= 32 && smem + (size_t)256 * (Nfp + 1) * sizeof(float) <= 64 * 1024) {  // output tile through LDS: 256 rows x (Nfp + 1) floats, <= 33 KB; the launch stays within 64 KB of dynamic LDS
       a.stage_off = (int32_t)(smem / sizeof(float));
       smem += (size_t)256 * (Nfp + 1) * sizeof(float);
     }
