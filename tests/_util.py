@@ -64,3 +64,12 @@ def load_c_oracle():
 
 def cptr(t):
     return C.c_void_p(t.data_ptr())
+
+
+def free_port():
+    """A TCP port that is free on loopback right now (rendezvous of the multi-process tests: fixed
+    ports collide when two suites share a box)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

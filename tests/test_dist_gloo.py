@@ -96,7 +96,8 @@ def _reference_local(g, X, W, dY, act):
 @pytest.mark.parametrize("F0", [4, 16])  # 16: widths the fused kernel takes -> pipelined per-slice exchange
 def test_sharded_layer_matches_unsharded(exchange, condensed, act, F0):
     world = 2
-    port = 29600 + (abs(hash((exchange, condensed, F0))) % 300)
+    from _util import free_port
+    port = free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, exchange, condensed, act, F0, ret), nprocs=world, join=True)
@@ -110,7 +111,8 @@ def test_sharded_layer_world_size_4(exchange, condensed, act, F0):
     """Four ranks: two slices and eight nodes per rank — the group-interleaved send / receive layouts
     with more than one peer on either side."""
     world = 4
-    port = 29900 + (abs(hash((exchange, condensed, F0))) % 90)
+    from _util import free_port
+    port = free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, exchange, condensed, act, F0, ret), nprocs=world, join=True)

@@ -89,6 +89,16 @@ def _worker(rank, world, port, name, ret):
             with torch.no_grad():
                 ov = m(v["A"] if kind == "kw" else v["At"], v["X"], v["edges"])
             close(ov, d["logits_val"], "validation logits")
+            if kind == "kw":
+                # the same window handed over as a pre-built BatchedCSR (shorter than T): ranks whose
+                # slices all lie behind the window must get an empty shard, not fail alone while the
+                # others wait in gather_rows' all-gather (layers._Sharding._own)
+                from tmgcn_amd.csr import BatchedCSR
+                A_csr = BatchedCSR.from_coo_list(v["A"], N=v["N"], device="cpu")
+                assert A_csr.T < i["T"]
+                with torch.no_grad():
+                    ov2 = m(A_csr, v["X"], v["edges"])
+                assert torch.equal(ov2, ov), "BatchedCSR window differs from the list window"
         dist.barrier()
         ret[rank] = "ok"
     except Exception as e:
@@ -99,8 +109,9 @@ def _worker(rank, world, port, name, ret):
             dist.destroy_process_group()
 
 
-def _spawn(world, name, base):
-    port = base + (abs(hash(name)) % 200)
+def _spawn(world, name, base=None):
+    from _util import free_port
+    port = free_port()
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, name, ret), nprocs=world, join=True)
     for r in range(world):
@@ -117,3 +128,38 @@ def test_sharded_models_uneven_shards_world3(name):
     """T = 10 (G3) / 9 (G4) slices over 3 ranks: shards of 4+3+3 slices, padded collectives; the G4
     validation window (4 slices) leaves the last rank without any slice of it."""
     _spawn(3, name, 30400)
+
+
+def _too_few_slices_worker(rank, world, port, ret):
+    try:
+        for p in (ROOT, HERE):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tmgcn_amd import ops, synth
+        from _oracle_kernels import OracleKernels
+        import tmgcn_amd.layers as ehf
+        ops.kernels = OracleKernels()
+        g = synth.dynamic_graph(2, 12, edges_per_slice=20, seed=0, no_diag=1, F0=2)
+        try:
+            ehf.EmbeddingGCN(g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.edges), torch.from_numpy(g.M),
+                             hidden_feat=[3, 2], condensed_W=True, use_Minv=False, device="cpu", group=dist.group.WORLD)
+            ret[rank] = "no error"
+        except RuntimeError as e:
+            ret[rank] = "raised" if "cannot be sharded" in str(e) else f"other: {e}"
+    except Exception as e:
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_fewer_slices_than_ranks_raises_on_every_rank():
+    """T = 2 over 3 ranks: EVERY rank raises (the verdict is a function of T and G only), none is
+    left waiting in a collective for a rank that has already failed."""
+    from _util import free_port
+    ret = mp.Manager().dict()
+    mp.spawn(_too_few_slices_worker, args=(3, free_port(), ret), nprocs=3, join=True)
+    assert [ret.get(r) for r in range(3)] == ["raised"] * 3, dict(ret)

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.distributed as dist
 
-from _util import REL_TOL, assert_close
+from _util import REL_TOL, assert_close, free_port
 from tmgcn_amd import synth
 from tmgcn_amd.csr import BatchedCSR
 from tmgcn_amd.dist import ShardedTMGCNLayer
@@ -18,8 +18,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def pg():
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29577")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(free_port())
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     yield

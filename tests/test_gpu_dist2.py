@@ -76,7 +76,8 @@ def _worker(rank, world, port, exchange, F0, F1, condensed, act, pipeline, ret):
 @pytest.mark.parametrize("condensed,act", [(True, None), (False, "selu")])
 def test_two_ranks_one_gpu(exchange, F0, F1, pipeline, condensed, act):
     world = 2
-    port = 29700 + abs(hash((exchange, F0, pipeline, condensed))) % 250
+    from _util import free_port
+    port = free_port()
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, exchange, F0, F1, condensed, act, pipeline, ret), nprocs=world, join=True)
     for r in range(world):
@@ -89,7 +90,8 @@ def test_four_ranks_one_gpu(exchange, F0, F1, condensed, act):
     """Two slices and 24 nodes per rank: the band kernel's group-interleaved send / receive layouts
     with four groups, and the per-slice pipeline with three peers."""
     world = 4
-    port = 29960 + abs(hash((exchange, F0, condensed))) % 30
+    from _util import free_port
+    port = free_port()
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, exchange, F0, F1, condensed, act, True, ret), nprocs=world, join=True)
     for r in range(world):

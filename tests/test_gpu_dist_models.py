@@ -122,7 +122,8 @@ def _worker(rank, world, port, name, ret):
 
 
 def _spawn(world, name, base):
-    port = base + (abs(hash(name)) % 200)
+    from _util import free_port
+    port = free_port()
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, name, ret), nprocs=world, join=True)
     for r in range(world):

@@ -42,29 +42,46 @@ constexpr int kWave = 64;  // gfx950 wavefront
 // MI355X_MICROARCH.md warns the API can over-report by one for SGPR-heavy kernels; a persistent
 // grid that is not fully resident runs its tail blocks serially).  Cached per kernel.
 
+// CU count of a device, queried once per device and host thread (hipGetDeviceProperties fills a
+// multi-KB struct: too slow for the launch path of 0.2 ms epochs).
+inline int device_cu_count(int dev) {
+  thread_local int cus[16] = {0};
+  if (dev >= 0 && dev < 16 && cus[dev]) return cus[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (dev >= 0 && dev < 16) cus[dev] = n;
+  return n;
+}
+
 template <typename K>
 inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0) {
-  // one cache entry per kernel type / instantiation site and per host thread (no shared mutable
-  // state between threads), valid for the kernel and the device it was computed for
-  thread_local int cached = 0, cached_dev = -1;
-  thread_local const void* cached_for = nullptr;
+  // K is the function-pointer TYPE, which every kernel with the same argument list shares, so the
+  // cache is a small per-thread table keyed on (kernel address, device, block size): alternating
+  // between instantiations (fp32 / bf16 weights, layers of different widths) hits it every time.
+  // No shared mutable state between host threads.  Dynamic LDS changes residency: not cached.
+  struct Entry { const void* k; int dev, threads, blocks_per_cu; };
+  constexpr int kSlots = 16;
+  thread_local Entry table[kSlots] = {};
+  thread_local int next = 0;
   const void* key = reinterpret_cast<const void*>(kernel);
-  int dev = 0, cus = 256, per_cu = 1;
-  const bool have_dev = hipGetDevice(&dev) == hipSuccess;
-  if (cached && cached_for == key && cached_dev == dev && dyn_smem == 0) return cached;  // dynamic LDS changes residency: re-query
-  if (have_dev) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const int cus = device_cu_count(dev);
+  if (dyn_smem == 0)
+    for (int i = 0; i < kSlots; ++i)
+      if (table[i].k == key && table[i].dev == dev && table[i].threads == block_threads)
+        return cus * table[i].blocks_per_cu;
+  int per_cu = 1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dyn_smem) != hipSuccess ||
       per_cu < 1)
     per_cu = 1;
   if (per_cu > 4) per_cu = 4;
   (void)hipGetLastError();
-  cached = cus * per_cu;
-  cached_for = key;
-  cached_dev = dev;
-  return cached;
+  if (dyn_smem == 0) {
+    table[next] = Entry{key, dev, block_threads, per_cu};
+    next = (next + 1) % kSlots;
+  }
+  return cus * per_cu;
 }
 
 // Persistent grid minus `reserve` block slots (a per-call argument of the C-ABI): in the multi-GPU

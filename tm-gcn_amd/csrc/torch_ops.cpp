@@ -130,11 +130,14 @@ WShape w_shape(const Tensor& W, bool trans_w, int64_t T, int64_t K, const char* 
 
 void spmm_gemm_launch(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& X, int64_t N,
                       const Tensor& W, bool trans_w, int64_t act, const Tensor& Y, const Tensor& AX,
-                      const Tensor& pre, int64_t grid_reserve) {
+                      const Tensor& pre, int64_t grid_reserve, double avg_nnz_per_row) {
   const WShape s = w_shape(W, trans_w, X.size(0), X.size(2), "spmm_gemm");
-  // average row length from the tensors' own sizes (host-side metadata): steers the lanes per row of the narrow kernel
+  // average row length (steers the lanes per row of the narrow kernel, hence its summation order):
+  // the CALLER's figure for the rows it launches over.  A one-slice view of a larger CSR shares
+  // the whole col/val arrays, so col.numel() / n_rows would be T times too large there; a
+  // negative value means "unknown" and takes the kernel's default.
   const int64_t n_rows = X.size(0) * N;
-  const float avg = n_rows > 0 ? (float)((double)col.numel() / (double)n_rows) : -1.f;
+  const float avg = (float)avg_nnz_per_row;
   ok(tmgcn_spmm_gemm_f32_hint((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val),
                               (const float*)ptr(X), n_rows, (int32_t)N, (int32_t)X.size(2),
                               (const float*)ptr(W), (int32_t)s.wn, trans_w ? 1 : 0, s.per_slice ? N : 0, s.stride,
@@ -145,7 +148,8 @@ void spmm_gemm_launch(const Tensor& rowptr, const Tensor& col, const Tensor& val
 
 std::tuple<Tensor, Tensor, Tensor> spmm_gemm(const Tensor& rowptr, const Tensor& col, const Tensor& val,
                                              const Tensor& X, int64_t N, const Tensor& W, bool trans_w,
-                                             int64_t act, bool want_ax, bool want_pre, int64_t grid_reserve) {
+                                             int64_t act, bool want_ax, bool want_pre, int64_t grid_reserve,
+                                             double avg_nnz_per_row) {
   want(X, "spmm_gemm X");
   want(W, "spmm_gemm W");
   check_csr(rowptr, col, val, X, N, "spmm_gemm");
@@ -154,14 +158,14 @@ std::tuple<Tensor, Tensor, Tensor> spmm_gemm(const Tensor& rowptr, const Tensor&
   Tensor Y = at::empty({X.size(0), N, s.wn}, X.options());
   Tensor AX = want_ax ? at::empty(X.sizes(), X.options()) : Tensor();
   Tensor pre = (want_pre && act != TMGCN_ACT_NONE) ? at::empty_like(Y) : Tensor();
-  spmm_gemm_launch(rowptr, col, val, aligned16(X), N, W, trans_w, act, Y, AX, pre, grid_reserve);
+  spmm_gemm_launch(rowptr, col, val, aligned16(X), N, W, trans_w, act, Y, AX, pre, grid_reserve, avg_nnz_per_row);
   return {Y, AX.defined() ? AX : none_like(X), pre.defined() ? pre : none_like(X)};
 }
 
 // writes into caller-provided (views of) tensors: the slice-by-slice pipelined multi-GPU path
 void spmm_gemm_out(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& X, int64_t N,
                    const Tensor& W, bool trans_w, int64_t act, Tensor Y, const OptTensor& AX,
-                   const OptTensor& pre, int64_t grid_reserve) {
+                   const OptTensor& pre, int64_t grid_reserve, double avg_nnz_per_row) {
   want(X, "spmm_gemm X");
   want(W, "spmm_gemm W");
   want(Y, "spmm_gemm out Y");
@@ -175,7 +179,7 @@ void spmm_gemm_out(const Tensor& rowptr, const Tensor& col, const Tensor& val, c
   if (pr.defined()) want(pr, "spmm_gemm out pre");
   TORCH_CHECK(!ax.defined() || reinterpret_cast<uintptr_t>(ax.const_data_ptr()) % 16 == 0,
               "spmm_gemm: the AX output view must start 16-byte aligned");
-  spmm_gemm_launch(rowptr, col, val, aligned16(X), N, W, trans_w, act, Y, ax, pr, grid_reserve);
+  spmm_gemm_launch(rowptr, col, val, aligned16(X), N, W, trans_w, act, Y, ax, pr, grid_reserve, avg_nnz_per_row);
 }
 
 std::tuple<Tensor, Tensor> bgemm(const Tensor& A, const Tensor& W, bool trans_w, int64_t act, bool want_pre,
@@ -256,7 +260,12 @@ std::tuple<Tensor, Tensor> edge_head_bwd(const Tensor& Z2, const Tensor& src, co
   want(eptr, "edge_head eptr", it);
   want(eidx, "edge_head eidx", it);
   c10::DeviceGuard g(Z2.device());
+  TORCH_CHECK(Z2.dim() == 2 && U.dim() == 2 && U.size(0) == 2 * Z2.size(1), "edge_head_bwd: U ", U.sizes(),
+              " does not match F=", Z2.dim() == 2 ? Z2.size(1) : -1);
+  TORCH_CHECK(src.numel() == dst.numel(), "edge_head_bwd: src and dst differ in length");
   const int64_t R = Z2.size(0), F = Z2.size(1), C = U.size(1), E = src.numel();
+  TORCH_CHECK(dout.dim() == 2 && dout.size(0) == E && dout.size(1) == C, "edge_head_bwd: dout ", dout.sizes(),
+              " is not [E=", E, ", C=", C, "]");
   TORCH_CHECK(eptr.numel() == R + 1 && eidx.numel() == 2 * E, "edge_head_bwd: inverted index does not match R=", R,
               " E=", E);
   Tensor dZ = need_dz ? at::empty_like(Z2) : Tensor();
@@ -420,7 +429,7 @@ struct SpmmFeatureGemmFn : public torch::autograd::Function<SpmmFeatureGemmFn> {
                         const OptTensor& t_val, int64_t N, double avg, int64_t act, int64_t grid_reserve,
                         bool need_x, bool need_w) {
     at::AutoDispatchBelowADInplaceOrView guard;
-    auto [Y, AX, pre] = spmm_gemm(rowptr, col, val, X, N, W, false, act, need_w, need_x || need_w, grid_reserve);
+    auto [Y, AX, pre] = spmm_gemm(rowptr, col, val, X, N, W, false, act, need_w, need_x || need_w, grid_reserve, avg);
     if (need_x)
       TORCH_CHECK(t_rowptr.has_value() && t_col.has_value() && t_val.has_value(),
                   "spmm_feature_gemm: X requires grad but no transposed adjacency was passed");
@@ -443,7 +452,7 @@ struct SpmmFeatureGemmFn : public torch::autograd::Function<SpmmFeatureGemmFn> {
     if (ctx->needs_input_grad(0)) {
       if (spmm_gemm_supported(dY.size(-1), W.size(-2)))
         dX = std::get<0>(spmm_gemm(sv[3], sv[4], sv[5], dY, N, W, true, TMGCN_ACT_NONE, false, false,
-                                   ctx->saved_data["reserve"].toInt()));
+                                   ctx->saved_data["reserve"].toInt(), ctx->saved_data["avg"].toDouble()));
       else  // the transposed widths have no fused kernel: dA = dY·Wᵀ, then Âᵀ·dA
         dX = spmm_csr_batched(sv[3], sv[4], sv[5], std::get<0>(bgemm(dY, W, true, TMGCN_ACT_NONE, false, TMGCN_GEMM_AUTO)), N,
                               ctx->saved_data["avg"].toDouble());
@@ -541,9 +550,9 @@ TORCH_LIBRARY(tmgcn, m) {
         "int x_group_rows, int y_group_rows) -> Tensor");
   m.def("spmm_csr_batched(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, float avg_nnz_per_row) -> Tensor");
   m.def("spmm_gemm(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, Tensor W, bool trans_w, int act, "
-        "bool want_ax, bool want_pre, int grid_reserve) -> (Tensor, Tensor, Tensor)");
+        "bool want_ax, bool want_pre, int grid_reserve, float avg_nnz_per_row=-1.0) -> (Tensor, Tensor, Tensor)");
   m.def("spmm_gemm_out(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, Tensor W, bool trans_w, int act, "
-        "Tensor(a!) Y, Tensor(b!)? AX, Tensor(c!)? pre, int grid_reserve) -> ()");
+        "Tensor(a!) Y, Tensor(b!)? AX, Tensor(c!)? pre, int grid_reserve, float avg_nnz_per_row=-1.0) -> ()");
   m.def("bgemm(Tensor A, Tensor W, bool trans_w, int act, bool want_pre, int algo) -> (Tensor, Tensor)");
   m.def("bgemm_dW(Tensor A, Tensor dY, bool per_slice, int algo) -> Tensor");
   m.def("edge_head_fwd(Tensor Z2, Tensor src, Tensor dst, Tensor U) -> Tensor");

@@ -109,7 +109,10 @@ class _Sharding:
         if group is not None:
             from .dist import SliceShard
             self._shard = SliceShard(group, self.T)
-            if self._shard.Tl == 0:
+            # T < G is the same verdict on every rank, so all of them raise together (testing
+            # this rank's own Tl == 0 would stop only the ranks >= T and leave the others
+            # waiting in their first collective)
+            if self.T < self._shard.G:
                 raise RuntimeError(f"T={self.T} slices cannot be sharded over {self._shard.G} ranks")
 
     def _own(self, seq):
@@ -117,7 +120,10 @@ class _Sharding:
         if self._shard is None:
             return seq
         if isinstance(seq, BatchedCSR):
-            return seq.slices(self._shard.k0, min(self._shard.k1, seq.T))
+            # a window shorter than T (KWGCN's validation call, ehf:469-473): both ends clamp, so a
+            # rank whose slices all lie behind the window gets an EMPTY shard (and goes on to the
+            # same collectives as the others) instead of failing alone
+            return seq.slices(min(self._shard.k0, seq.T), min(self._shard.k1, seq.T))
         return seq[self._shard.k0:self._shard.k1]
 
     def _mt_input(self, X: torch.Tensor, op) -> torch.Tensor:

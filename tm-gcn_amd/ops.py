@@ -204,10 +204,12 @@ class HipKernels:
         if out is not None:
             Y, AX, pre = out
             self._run(tag, X.device, lambda: self.ops.spmm_gemm_out(
-                A.rowptr, A.col, A.val, X, A.N, W, bool(trans_w), act_id, Y, AX, pre, int(grid_reserve)))
+                A.rowptr, A.col, A.val, X, A.N, W, bool(trans_w), act_id, Y, AX, pre, int(grid_reserve),
+                float(A.avg_nnz_per_row)))
             return Y, AX, pre
         Y, AX, pre = self._run(tag, X.device, lambda: self.ops.spmm_gemm(
-            A.rowptr, A.col, A.val, X, A.N, W, bool(trans_w), act_id, bool(want_ax), bool(want_pre), int(grid_reserve)))
+            A.rowptr, A.col, A.val, X, A.N, W, bool(trans_w), act_id, bool(want_ax), bool(want_pre), int(grid_reserve),
+            float(A.avg_nnz_per_row)))
         return Y, (AX if AX.numel() else None), (pre if pre.numel() else None)
 
     # P3 ---------------------------------------------------------------------------------
