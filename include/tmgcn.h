@@ -44,7 +44,8 @@ typedef enum {
 /* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
 enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
 
-/* ABI version 2: no process-wide settings.  What used to be tmgcn_config_set() knobs are
+/* ABI version 3 = version 2 + tmgcn_mtransform_ld_f32 (column-window M-transform).
+ * ABI version 2: no process-wide settings.  What used to be tmgcn_config_set() knobs are
  * per-call arguments (grid_reserve of tmgcn_spmm_gemm_f32, algo of tmgcn_gemm_dw_f32): two callers
  * in one process never see each other's choices. */
 int tmgcn_abi_version(void);
@@ -88,6 +89,18 @@ int tmgcn_mtransform_f32(const float* M, int32_t Tm, int32_t ldm, int32_t transp
                          int32_t band_lo, int32_t band_hi,
                          const float* X, float* Y, int64_t C,
                          int32_t x_group_rows, int32_t y_group_rows, void* stream);
+/* The same on a COLUMN WINDOW of wider tensors (ABI 3): X rows are ldx floats apart, Y rows ldy
+ * floats apart (ldx, ldy >= C; X / Y point at the window's first column).  This is the consumer
+ * of the node-chunked all-gather of the slice-sharded layer: a gathered chunk [T][Nc*F] is
+ * transformed straight into columns [c0*F, (c0+Nc)*F) of the resident [T/G][N*F] result (and, in
+ * backward, the window of the upstream gradient straight into the reduce-scatter send buffer), so
+ * the replicated [T][N*F] tensor of ehf:204 / 308 never exists.  Per output element the
+ * arithmetic is that of tmgcn_mtransform_f32 (same kernel): chunked == unchunked, bit for bit. */
+int tmgcn_mtransform_ld_f32(const float* M, int32_t Tm, int32_t ldm, int32_t transpose,
+                            int32_t row_off, int32_t col_off, int32_t T_out, int32_t T_in,
+                            int32_t band_lo, int32_t band_hi,
+                            const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t C,
+                            int32_t x_group_rows, int32_t y_group_rows, void* stream);
 
 /* ---- P2: batched CSR SpMM (per-frontal-slice Â_k · X_k) -------------------------
  * Replaces the loops  for k in range(T): AtXt[k] = t.sparse.mm(At[k], Xt[k])

@@ -45,6 +45,11 @@ class OracleKernels:
             Y = out
         return Y
 
+    def mtransform_out(self, op, X, Y, transpose=False, row_off=0, col_off=0, x_group_rows=0, y_group_rows=0, tag=None):
+        """Column-window form (tmgcn_mtransform_ld_f32): X / Y may be strided views; written into Y."""
+        Y.copy_(self.mtransform(op, X.contiguous(), transpose, row_off, col_off, Y.shape[0], x_group_rows, y_group_rows))
+        return Y
+
     def spmm(self, A, X, tag=None):
         return orc.slice_spmm(_view_coo(A), X.double())
 

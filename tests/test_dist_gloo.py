@@ -65,6 +65,24 @@ def _worker(rank, world, port, exchange, condensed, act, F0, ret):
         if exchange == "a2a":  # slice-sharded output back to node-sharded (input of a next layer)
             Yn = layer.to_node_sharded(Y.detach())
             close(Yn, Yr[:, n0:n1], "to_node_sharded")
+        else:
+            # the all-gather ran node-chunked (automatic chunk size: one chunk at this N).  The literal
+            # unchunked form and a ragged multi-chunk split must give the same bits: per output
+            # element the arithmetic is the same, only the grouping of the collectives differs.
+            assert layer.gather_chunk_nodes == N and len(layer.gather_chunks()) == 1
+            for chunk in (0, 7, 1):
+                l2 = ShardedTMGCNLayer(A_local, g.M, T, group=None, exchange="allgather", gather_chunk_nodes=chunk)
+                X2 = Xin.detach().clone().requires_grad_(True)
+                W2 = Wl.detach().clone().requires_grad_(True)
+                Y2 = l2(X2, W2, act=act)
+                Y2.backward(dY[k0:k1].contiguous())
+                if chunk:
+                    assert len(l2.gather_chunks()) == -(-N // chunk) and l2._gbufs[0].numel() == T * chunk * F0
+                else:
+                    assert l2._gbufs is None                    # the literal form materialises [T,N,F] instead
+                assert torch.equal(Y2.detach(), Y.detach()), f"Y differs, chunk={chunk}"
+                assert torch.equal(X2.grad, Xin.grad), f"dX differs, chunk={chunk}"
+                assert torch.equal(W2.grad, Wl.grad), f"dW differs, chunk={chunk}"
         dist.barrier()
         ret[rank] = "ok"
     except Exception as e:  # surface the failure in the parent
@@ -125,3 +143,21 @@ def test_even_bounds():
     assert even_bounds(128, 8)[3] == (48, 64)
     b = even_bounds(10, 4)
     assert b == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_memory_plan_of_the_headline_config():
+    """S4 at G = 8 (T = 128, N = 2 M, F = 128, 66 M stored non-zeros per slice): north_star's literal
+    all-gather needs [T,N,F] twice (it cannot fit a 288 GB device); node-chunked it needs two 8 GB
+    buffers and fits with room to spare, as the all-to-all form does."""
+    from tmgcn_amd.dist import chunk_nodes_for, memory_plan
+    T, G, N, F, nnz = 128, 8, 2_000_000, 128, 16 * 66_000_000
+    literal = memory_plan("allgather", T, G, N, F, F, nnz, gather_chunk_nodes=0)
+    chunked = memory_plan("allgather", T, G, N, F, F, nnz)
+    a2a = memory_plan("a2a", T, G, N, F, F, nnz)
+    assert literal["exchange"] == 2 * T * N * F * 4 and literal["total"] > 288e9
+    assert chunked["total"] < 200e9 and a2a["total"] < 200e9
+    nc = chunk_nodes_for(T, N, F)
+    assert chunked["exchange"] == 2 * T * nc * F * 4 <= 2 * (8 << 30) and -(-N // nc) == 16
+    assert memory_plan("none", 16, 1, N, F, F, nnz)["exchange"] == 0
+    # equal-sized chunks, never more than the target, never more than N
+    assert chunk_nodes_for(8, 30, 4) == 30 and chunk_nodes_for(128, 2_000_000, 128, target=1 << 30) * 128 * 128 * 4 <= 1 << 30

@@ -26,9 +26,12 @@ def pg():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,pipeline,F0", [("a2a", True, 16), ("a2a", False, 16), ("a2a", True, 6), ("allgather", True, 16)])
+@pytest.mark.parametrize("exchange,pipeline,F0,chunk", [("a2a", True, 16, None), ("a2a", False, 16, None), ("a2a", True, 6, None),
+                                                        ("allgather", True, 16, None),   # node-chunked gather, one chunk
+                                                        ("allgather", True, 16, 50),     # three chunks, ragged tail
+                                                        ("allgather", True, 16, 0)])     # the literal unchunked form
 @pytest.mark.parametrize("condensed,act", [(True, None), (False, "leaky")])
-def test_world1_rccl_paths_match_unsharded(pg, exchange, pipeline, F0, condensed, act):
+def test_world1_rccl_paths_match_unsharded(pg, exchange, pipeline, F0, chunk, condensed, act):
     T, N, F1 = 6, 120, 32
     g = synth.dynamic_graph(T, N, edges_per_slice=300, seed=2, no_diag=4, F0=F0)
     A = BatchedCSR.from_scipy_list(g.Ct, device="cuda")
@@ -38,7 +41,8 @@ def test_world1_rccl_paths_match_unsharded(pg, exchange, pipeline, F0, condensed
     dY = torch.randn(T, N, F1, generator=gen).cuda()
     res = []
     for force in (False, True):
-        layer = ShardedTMGCNLayer(A, g.M, T, exchange=exchange, pipeline=pipeline, force_collectives=force)
+        layer = ShardedTMGCNLayer(A, g.M, T, exchange=exchange, pipeline=pipeline, force_collectives=force,
+                                  gather_chunk_nodes=chunk)
         assert layer.collective == force
         X = X0.clone().requires_grad_(True)
         W = W0.clone().requires_grad_(True)

@@ -58,6 +58,23 @@ def _worker(rank, world, port, exchange, F0, F1, condensed, act, pipeline, ret):
         close(Y.detach(), Yr.detach()[k0:k1], "Y")
         close(Xin.grad, Xr.grad[:, n0:n1] if exchange == "a2a" else Xr.grad[k0:k1], "dX")
         close(Wl.grad, Wr.grad if condensed else Wr.grad[k0:k1], "dW")
+        if exchange == "allgather":
+            # node-chunked (what ran above: the automatic size = one chunk here) vs ragged multi-chunk
+            # splits vs the literal unchunked form: the same bits with the real kernels, the side
+            # stream and the two alternating chunk buffers
+            assert len(layer.gather_chunks()) == 1
+            for chunk in (0, 40, 7):
+                l2 = ShardedTMGCNLayer(A.slices(k0, k1), g.M, T, exchange="allgather", gather_chunk_nodes=chunk)
+                X2 = Xin.detach().clone().requires_grad_(True)
+                W2 = Wl.detach().clone().requires_grad_(True)
+                for _ in range(2):                       # twice: the buffers are reused across passes
+                    X2.grad = W2.grad = None
+                    Y2 = l2(X2, W2, act=act)
+                    Y2.backward(dY0[k0:k1].contiguous().cuda())
+                torch.cuda.synchronize()
+                assert torch.equal(Y2.detach(), Y.detach()), f"Y differs, chunk={chunk}"
+                assert torch.equal(X2.grad, Xin.grad), f"dX differs, chunk={chunk}"
+                assert torch.equal(W2.grad, Wl.grad), f"dW differs, chunk={chunk}"
         dist.barrier()
         ret[rank] = "ok"
     except Exception as e:

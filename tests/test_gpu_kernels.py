@@ -178,6 +178,45 @@ def test_mtransform_windowed_rows():
     assert_close(dX, ref_mt(M, pad, True), REL_TOL, "adjoint window")
 
 
+@pytest.mark.parametrize("T,band,F", [(24, 6, 4), (24, 6, 3),      # band kernel: float4 and scalar (C % 4 != 0) forms
+                                      (96, None, 4),                # dense bf16-split kernel
+                                      (160, None, 4)])              # exact-f32 matrix-core kernel (T_in > 128)
+def test_mtransform_column_window_is_bitwise_the_contiguous_product(T, band, F):
+    """tmgcn_mtransform_ld_f32 (ops.kernels.mtransform_out): a chunk of columns transformed into /
+    out of a column window of a wider tensor — the consumer of the node-chunked all-gather.  Per
+    output element it must be the SAME arithmetic as the contiguous product: bit-equal, for the
+    forward row window, for the adjoint, and with the group-interleaved row storage on either side."""
+    N, Tl, k0, tl = 52, 8, 8, 8
+    g = torch.Generator().manual_seed(11)
+    if band:
+        M = torch.from_numpy(synth.band_M(T, band, "matlab")).contiguous()
+    else:
+        M = (torch.randn(T, T, generator=g, dtype=torch.float64) / T ** 0.5 + torch.eye(T, dtype=torch.float64)).contiguous()
+    op = ops.MOperator(M, DEV)
+    X = torch.randn(T, N, F, generator=g).to(DEV)
+    K = ops.kernels
+    whole = K.mtransform(op, X, row_off=k0, col_off=0, T_out=Tl)                 # [Tl, N, F]
+    dY = torch.randn(Tl, N, F, generator=g).to(DEV)
+    whole_T = K.mtransform(op, dY, transpose=True, row_off=0, col_off=k0, T_out=T)  # [T, N, F]
+    pos = torch.tensor([(k % tl) * (T // tl) + k // tl for k in range(T)], device=DEV)
+    Xg = torch.empty_like(X)
+    Xg[pos] = X                                                                   # grouped storage of the input rows
+    for chunks in ([(0, N)], [(0, 20), (20, 40), (40, N)], [(0, 1), (1, N)]):
+        out = torch.full((Tl, N, F), float("nan"), device=DEV)
+        out_T = torch.full((T, N, F), float("nan"), device=DEV)
+        for c0, c1 in chunks:
+            # forward: contiguous (gathered) chunk -> window of the resident result
+            K.mtransform_out(op, Xg[:, c0:c1].contiguous(), out[:, c0:c1], row_off=k0, col_off=0, x_group_rows=tl)
+            # adjoint: window of the upstream gradient -> contiguous send buffer, grouped rows
+            buf = torch.empty(T, c1 - c0, F, device=DEV)
+            K.mtransform_out(op, dY[:, c0:c1], buf, transpose=True, row_off=0, col_off=k0, y_group_rows=tl)
+            out_T[:, c0:c1] = buf[pos]
+        assert torch.equal(out, whole), f"forward window differs, chunks={chunks}"
+        assert torch.equal(out_T, whole_T), f"adjoint window differs, chunks={chunks}"
+    with pytest.raises(RuntimeError):                                              # slices must be dense [n, F] blocks
+        K.mtransform_out(op, X.transpose(1, 2), torch.empty(Tl, F, N, device=DEV), row_off=k0)
+
+
 # ------------------------------------------------------------------------------------- P3
 def ref_gemm(A, W, trans_w=False, per_slice=False):
     lib = load_c_oracle()

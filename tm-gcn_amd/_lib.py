@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tmgcn.h")
 ACT_IDS = {None: 0, "none": 0, "relu": 1, "leaky": 2, "selu": 3}
 DW_ALGOS = {None: 0, "auto": 0, "f32mfma": 1}   # TMGCN_DW_AUTO / TMGCN_DW_F32MFMA
 GEMM_ALGOS = {None: 0, "auto": 0, "f32mfma": 1}  # TMGCN_GEMM_AUTO / TMGCN_GEMM_F32MFMA
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class TmgcnLibraryError(RuntimeError):
@@ -30,6 +30,7 @@ SIGNATURES = {
     "tmgcn_abi_version": (C.c_int, []),
     "tmgcn_last_error": (C.c_char_p, []),
     "tmgcn_mtransform_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i64, _i32, _i32, _p]),
+    "tmgcn_mtransform_ld_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
     "tmgcn_spmm_csr_batched_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_spmm_csr_batched_f32_hint": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, C.c_float, _p]),
     "tmgcn_spmm_gemm_supported": (C.c_int, [_i32, _i32]),

@@ -34,6 +34,7 @@ struct MtArgs {
   int32_t rows_per_chunk;
   int32_t x_tl, y_tl;  // group-interleaved row storage (0 = plain row order), see tmgcn.h
   unsigned int* tile_counter;  // dense MFMA kernel: dynamic column-tile scheduling (common.h)
+  int64_t ldx, ldy;            // row strides of X and Y in floats (>= C): a column window of a wider tensor
 };
 
 // storage position of logical row k of a tensor with T rows stored in groups of tl rows:
@@ -108,7 +109,7 @@ struct BandBody {
     const int q = q0 + uc;
     const int qc = q < 0 ? 0 : (q >= a.T_in ? a.T_in - 1 : q);
     const int64_t pos = PERM ? row_pos(qc, a.T_in, a.x_tl) : (int64_t)qc;
-    V v = CT::load(X + pos * a.C + c);
+    V v = CT::load(X + pos * a.ldx + c);
     CT::mask(v, q == qc ? 0xFFFFFFFFu : 0u);  // rows outside the tensor are zero (bit mask: no branch)
     return v;
   }
@@ -123,7 +124,7 @@ struct BandBody {
 #pragma unroll
     for (int d = 0; d < WIDTH; ++d) CT::fma(acc, m[d], win[(i - d + 2 * W) % W]);
     const int64_t pos = PERM ? row_pos(k, a.T_out, a.y_tl) : (int64_t)k;
-    if (live) CT::store(Y + pos * a.C + c, acc);
+    if (live) CT::store(Y + pos * a.ldy + c, acc);
   }
 };
 
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void mtransform_dense_kernel(MtArgs a) {
   int j_hi = k0 + RT - 1 + d_hi;
   if (j_hi > a.T_in - 1) j_hi = a.T_in - 1;
   for (int j = j_lo; j <= j_hi; ++j) {
-    const V x = CT::load(a.X + row_pos(j, a.T_in, a.x_tl) * a.C + c);
+    const V x = CT::load(a.X + row_pos(j, a.T_in, a.x_tl) * a.ldx + c);
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const int k = k0 + i;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void mtransform_dense_kernel(MtArgs a) {
 #pragma unroll
   for (int i = 0; i < RT; ++i) {
     const int k = k0 + i;
-    if (k < a.T_out) CT::store(a.Y + row_pos(k, a.T_out, a.y_tl) * a.C + c, acc[i]);
+    if (k < a.T_out) CT::store(a.Y + row_pos(k, a.T_out, a.y_tl) * a.ldy + c, acc[i]);
   }
 }
 
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void mtransform_dense_mfma_kernel(MtArgs a) {
   const int s_lo = j_lo / 2, s_hi = wave_live && j_hi >= j_lo ? j_hi / 2 + 1 : 0;
 
   const int64_t n_tiles = (a.C + kDenseCols - 1) / kDenseCols;
-  const bool vec = (a.C % 4 == 0) && (reinterpret_cast<uintptr_t>(a.X) % 16 == 0);
+  const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(a.X) % 16 == 0);
   __shared__ unsigned int s_tile;
   for (;;) {
     __syncthreads();  // previous tile's LDS reads and s_tile reads are done
@@ -275,13 +276,13 @@ __global__ __launch_bounds__(256) void mtransform_dense_mfma_kernel(MtArgs a) {
         const int j = t / (kDenseCols / 4), q = t % (kDenseCols / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c0 + 4 * q < a.C)
-          v = *reinterpret_cast<const float4*>(a.X + row_pos(j, a.T_in, a.x_tl) * a.C + c0 + 4 * q);
+          v = *reinterpret_cast<const float4*>(a.X + row_pos(j, a.T_in, a.x_tl) * a.ldx + c0 + 4 * q);
         *reinterpret_cast<float4*>(&Xs[j * kDenseCols + 4 * q]) = v;
       }
     } else {
       for (int t = threadIdx.x; t < a.T_in * kDenseCols; t += 256) {
         const int j = t / kDenseCols, q = t % kDenseCols;
-        Xs[t] = (c0 + q < a.C) ? a.X[row_pos(j, a.T_in, a.x_tl) * a.C + c0 + q] : 0.f;
+        Xs[t] = (c0 + q < a.C) ? a.X[row_pos(j, a.T_in, a.x_tl) * a.ldx + c0 + q] : 0.f;
       }
     }
     __syncthreads();
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void mtransform_dense_mfma_kernel(MtArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = k0 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-          if (k < a.T_out) a.Y[row_pos(k, a.T_out, a.y_tl) * a.C + c] = acc[i];
+          if (k < a.T_out) a.Y[row_pos(k, a.T_out, a.y_tl) * a.ldy + c] = acc[i];
         }
       }
     }
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
     asm volatile("" : "+v"(jq));
     auto rowp = [&](int b, int i) __attribute__((always_inline)) {
       const int j = 4 * (jq + 16 * b) + i;
-      return base + row_pos(j < a.T_in ? j : a.T_in - 1, a.T_in, a.x_tl) * a.C;
+      return base + row_pos(j < a.T_in ? j : a.T_in - 1, a.T_in, a.x_tl) * a.ldx;
     };
     stage8_load<SET, 0>(rowp(0, 0));
     stage8_load<SET, 1>(rowp(0, 1));
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void mtransform_bf16x3_kernel(MtArgs a) {
         quad_transpose4(v, j);
         const int k = kb + 8 * g + j;
         if (k < a.T_out && c < a.C)
-          *reinterpret_cast<float4*>(a.Y + row_pos(k, a.T_out, a.y_tl) * a.C + c) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(a.Y + row_pos(k, a.T_out, a.y_tl) * a.ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -665,13 +666,15 @@ static int dispatch(MtArgs a, hipStream_t st) {
 
 using namespace tmgcn;
 
-extern "C" int tmgcn_mtransform_f32(const float* M, int32_t Tm, int32_t ldm, int32_t transpose,
-                                     int32_t row_off, int32_t col_off, int32_t T_out,
-                                     int32_t T_in, int32_t band_lo, int32_t band_hi,
-                                     const float* X, float* Y, int64_t C, int32_t x_group_rows,
-                                     int32_t y_group_rows, void* stream) {
+extern "C" int tmgcn_mtransform_ld_f32(const float* M, int32_t Tm, int32_t ldm, int32_t transpose,
+                                        int32_t row_off, int32_t col_off, int32_t T_out,
+                                        int32_t T_in, int32_t band_lo, int32_t band_hi,
+                                        const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t C,
+                                        int32_t x_group_rows, int32_t y_group_rows, void* stream) {
   TMGCN_REQUIRE(Tm > 0 && ldm >= Tm, "mtransform: bad operator shape Tm=%d ldm=%d", Tm, ldm);
   TMGCN_REQUIRE(T_out >= 0 && T_in >= 0 && C >= 0, "mtransform: negative extent");
+  TMGCN_REQUIRE(ldx >= C && ldy >= C, "mtransform: row strides ldx=%lld ldy=%lld are smaller than C=%lld", (long long)ldx,
+                (long long)ldy, (long long)C);
   TMGCN_REQUIRE(row_off >= 0 && col_off >= 0 && row_off + T_out <= Tm && col_off + T_in <= Tm,
                 "mtransform: window [%d+%d) x [%d+%d) exceeds the %dx%d operator", row_off,
                 T_out, col_off, T_in, Tm, Tm);
@@ -685,8 +688,17 @@ extern "C" int tmgcn_mtransform_f32(const float* M, int32_t Tm, int32_t ldm, int
                 "mtransform: y_group_rows=%d does not divide T_out=%d", y_group_rows, T_out);
   if (band_lo > Tm) band_lo = Tm;
   if (band_hi > Tm) band_hi = Tm;
-  MtArgs a{M, ldm, transpose, row_off, col_off, T_out, T_in, band_lo, band_hi, X, Y, C, T_out, x_group_rows, y_group_rows, nullptr};
-  const bool vec_ok = (C % 4 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0) &&
+  MtArgs a{M, ldm, transpose, row_off, col_off, T_out, T_in, band_lo, band_hi, X, Y, C, T_out, x_group_rows, y_group_rows, nullptr, ldx, ldy};
+  const bool vec_ok = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (reinterpret_cast<uintptr_t>(X) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
   return vec_ok ? dispatch<4>(a, (hipStream_t)stream) : dispatch<1>(a, (hipStream_t)stream);
+}
+
+extern "C" int tmgcn_mtransform_f32(const float* M, int32_t Tm, int32_t ldm, int32_t transpose,
+                                     int32_t row_off, int32_t col_off, int32_t T_out,
+                                     int32_t T_in, int32_t band_lo, int32_t band_hi,
+                                     const float* X, float* Y, int64_t C, int32_t x_group_rows,
+                                     int32_t y_group_rows, void* stream) {
+  return tmgcn_mtransform_ld_f32(M, Tm, ldm, transpose, row_off, col_off, T_out, T_in, band_lo, band_hi, X, C, Y, C, C,
+                                 x_group_rows, y_group_rows, stream);
 }

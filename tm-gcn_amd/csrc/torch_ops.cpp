@@ -87,6 +87,35 @@ Tensor mtransform(const Tensor& M, const Tensor& X, bool transpose, int64_t row_
   return Y;
 }
 
+// Column-window form: X [T_in, n, F] and Y [T_out, n, F] may be views whose slices are further apart
+// than n*F (e.g. Xt[:, c0:c1, :] of a resident [T, N, F] tensor); inside a slice they are dense.
+// The consumer of the node-chunked all-gather (dist.py) — a chunk is transformed into / out of its
+// column window of the resident tensor, the replicated [T, N, F] tensor never exists.
+void mtransform_out(const Tensor& M, const Tensor& X, Tensor Y, bool transpose, int64_t row_off, int64_t col_off,
+                    int64_t band_lo, int64_t band_hi, int64_t x_group_rows, int64_t y_group_rows) {
+  want(M, "mtransform M");
+  auto window = [](const Tensor& t, const char* name) {
+    TORCH_CHECK(t.defined() && t.is_cuda() && t.scalar_type() == at::kFloat, name, ": expected an fp32 ROCm tensor");
+    TORCH_CHECK(t.dim() == 3, name, ": expected [T, n, F]");
+    TORCH_CHECK(t.size(0) == 0 || t.numel() == 0 ||
+                    (t.stride(2) == 1 && t.stride(1) == t.size(2) && (t.size(0) == 1 || t.stride(0) >= t.size(1) * t.size(2))),
+                name, ": slices must be dense [n, F] blocks (strides ", t.strides(), ")");
+  };
+  window(X, "mtransform_out X");
+  window(Y, "mtransform_out Y");
+  TORCH_CHECK(M.dim() == 2 && M.size(0) == M.size(1), "mtransform: M must be square");
+  TORCH_CHECK(X.size(1) == Y.size(1) && X.size(2) == Y.size(2), "mtransform_out: X ", X.sizes(), " and Y ", Y.sizes(),
+              " differ in their column extent");
+  c10::DeviceGuard g(X.device());
+  const int64_t T_in = X.size(0), T_out = Y.size(0), C = X.size(1) * X.size(2);
+  const int64_t ldx = T_in > 1 ? X.stride(0) : C, ldy = T_out > 1 ? Y.stride(0) : C;
+  ok(tmgcn_mtransform_ld_f32((const float*)ptr(M), (int32_t)M.size(0), (int32_t)M.size(0), transpose ? 1 : 0,
+                             (int32_t)row_off, (int32_t)col_off, (int32_t)T_out, (int32_t)T_in, (int32_t)band_lo,
+                             (int32_t)band_hi, (const float*)ptr(X), ldx, (float*)ptr(Y), ldy, C, (int32_t)x_group_rows,
+                             (int32_t)y_group_rows, stream_of(X)),
+     "tmgcn_mtransform_ld_f32");
+}
+
 void check_csr(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& X, int64_t N,
                const char* who) {
   want(rowptr, "rowptr", at::kLong);
@@ -548,6 +577,8 @@ TORCH_LIBRARY(tmgcn, m) {
   // kernel-level
   m.def("mtransform(Tensor M, Tensor X, bool transpose, int row_off, int col_off, int T_out, int band_lo, int band_hi, "
         "int x_group_rows, int y_group_rows) -> Tensor");
+  m.def("mtransform_out(Tensor M, Tensor X, Tensor(a!) Y, bool transpose, int row_off, int col_off, int band_lo, "
+        "int band_hi, int x_group_rows, int y_group_rows) -> ()");
   m.def("spmm_csr_batched(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, float avg_nnz_per_row) -> Tensor");
   m.def("spmm_gemm(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, Tensor W, bool trans_w, int act, "
         "bool want_ax, bool want_pre, int grid_reserve, float avg_nnz_per_row=-1.0) -> (Tensor, Tensor, Tensor)");
@@ -581,6 +612,7 @@ TORCH_LIBRARY(tmgcn, m) {
 // ROCm tensors carry the CUDA dispatch key in PyTorch-ROCm
 TORCH_LIBRARY_IMPL(tmgcn, CUDA, m) {
   m.impl("mtransform", &mtransform);
+  m.impl("mtransform_out", &mtransform_out);
   m.impl("spmm_csr_batched", &spmm_csr_batched);
   m.impl("spmm_gemm", &spmm_gemm);
   m.impl("spmm_gemm_out", &spmm_gemm_out);

@@ -11,11 +11,17 @@ the backward pass.  Two exchange modes (DESIGN.md §6 has the byte counts):
                its output in the all-to-all send layout; one all-to-all per local slice
                re-partitions it to SLICE-sharded [T/G, N, F]; P2 and P3 are local.  Each rank
                moves (G-1)/G of ITS OWN shard, spread over all 7 xGMI links.
-  "allgather"  the layer input arrives SLICE-sharded ([T/G, N, F]); one all-gather replicates
+  "allgather"  the layer input arrives SLICE-sharded ([T/G, N, F]); an all-gather replicates
                it, every rank transforms only its own output slices (row window of M), P2 and
                P3 are local.  Backward is a reduce-scatter.  This is the north-star's literal
-               pattern; it materialises the whole [T,N,F] tensor on every GPU, so it is the
-               choice only when that fits (small N·F or small G).
+               pattern.  Taken literally it materialises the whole [T,N,F] tensor on every GPU
+               (131 GB at S4 / G = 8, and again as the reduce-scatter input), so the gather is
+               NODE-CHUNKED and fused with its consumer: chunk c (all T slices of Nc nodes)
+               is gathered on a side stream into one of two [T, Nc, F] buffers while P1
+               transforms chunk c-1 straight into columns of the resident [T/G, N, F] result
+               (tmgcn_mtransform_ld_f32) — the replicated tensor never exists, the bytes on the
+               links are the same, and per output element the arithmetic is that of the
+               unchunked form (bit-equal; `gather_chunk_nodes=0` keeps the unchunked form).
 
 condensed_W (one shared weight) adds an all-reduce of dW — F0·F1 floats.
 The collectives used (all_to_all_single, all_gather_into_tensor, reduce_scatter_tensor,
@@ -42,6 +48,58 @@ def even_bounds(n: int, parts: int) -> List[Tuple[int, int]]:
         out.append((lo, hi))
         lo = hi
     return out
+
+
+GATHER_CHUNK_BYTES = 8 << 30   # target size of ONE [T, Nc, F] chunk buffer of the chunked all-gather
+
+
+def chunk_nodes_for(T: int, N: int, F: int, elem: int = 4, target: int = GATHER_CHUNK_BYTES) -> int:
+    """Nodes per chunk so that a [T, Nc, F] buffer is about `target` bytes; chunks of equal size
+    (the last one may be shorter), at least 1 node, at most N."""
+    per_node = max(1, T * F * elem)
+    nc = max(1, min(N, target // per_node))
+    n_chunks = -(-N // nc)
+    return -(-N // n_chunks)
+
+
+def memory_plan(exchange: str, T: int, G: int, N: int, F: int, F1: int, nnz_rank: int,
+                gather_chunk_nodes: Optional[int] = None, elem: int = 4) -> dict:
+    """Per-rank HBM bytes of one training step (forward + backward, X and W require grad) of
+    ShardedTMGCNLayer, by component — computed from shapes alone, before anything is allocated.
+    bench.py prints it for both exchange modes and refuses to start a mode that cannot fit.
+      resident   adjacency (CSR + transposed CSR: 2 x (8 B/nnz + 8 B/row)), X, dY, W
+      step       tensors alive at the step's peak: Xt, Y, AX (saved for dW), dXt, dX, dW scratch
+      exchange   what the mode adds: a2a = send + receive-side layouts of one pass;
+                 allgather = two [T, Nc, F] chunk buffers (chunked) or [T,N,F] twice (unchunked)"""
+    if exchange not in ("a2a", "allgather", "none"):
+        raise RuntimeError(f"unknown exchange {exchange!r}")
+    Tl = T // G
+    slab_in, slab_out = Tl * N * F * elem, Tl * N * F1 * elem
+    rows = Tl * N
+    plan = {
+        "adjacency": 2 * (nnz_rank * 8 + (rows + 1) * 8),
+        "X": slab_in, "dY": slab_out, "W": F * F1 * elem,
+        "Xt": slab_in, "Y": slab_out, "AX": slab_in,
+        "dXt": slab_in, "dX": slab_in,
+        "dW_scratch": 64 << 20,
+    }
+    if exchange == "a2a" and G > 1:
+        plan["exchange"] = 2 * slab_in          # P1 output in the send layout (+ its adjoint in backward)
+        plan["exchange_note"] = "send-layout copy of the node-sharded P1 output, forward and backward"
+    elif exchange == "allgather" and G > 1:
+        if gather_chunk_nodes == 0:
+            plan["exchange"] = 2 * T * N * F * elem
+            plan["exchange_note"] = "unchunked: [T,N,F] gathered (forward) and again as the reduce-scatter input (backward)"
+        else:
+            nc = chunk_nodes_for(T, N, F, elem) if gather_chunk_nodes is None else max(1, min(N, gather_chunk_nodes))
+            plan["exchange"] = 2 * T * nc * F * elem
+            plan["exchange_note"] = f"two alternating [T, {nc}, F] chunk buffers ({-(-N // nc)} chunks)"
+    else:
+        plan["exchange"] = 0
+        plan["exchange_note"] = "no exchange"
+    plan["total"] = sum(v for k, v in plan.items() if isinstance(v, int))
+    plan["total_gb"] = round(plan["total"] / 1e9, 1)
+    return plan
 
 
 def _world(group):
@@ -111,6 +169,98 @@ class _AllGatherSlices(torch.autograd.Function):
         out = torch.empty((d.shape[0] // G,) + tuple(d.shape[1:]), dtype=d.dtype, device=d.device)
         dist.reduce_scatter_tensor(out, d.contiguous(), op=dist.ReduceOp.SUM, group=ctx.group)
         return out, None
+
+
+class _ChunkedGatherTransform(torch.autograd.Function):
+    """"allgather" mode, node-chunked: Xt[kk] = Σ_j M[k0+kk][j] · X_full[j] without ever holding
+    X_full.  Forward, per chunk of Nc nodes: one all-gather per local slice into a [T/G][G][Nc][F]
+    buffer (the group-interleaved row order tmgcn_mtransform takes as `x_group_rows`: no staging
+    copy on either side), then the row window of M applied to the chunk and written into columns
+    [c0, c1) of the resident result.  Backward, per chunk: Mᵀ applied to the same columns of the
+    upstream gradient into a [T/G][G][Nc][F] buffer, one reduce-scatter per local slice straight
+    into dX[kk, c0:c1].  Two buffers alternate, collectives run on the layer's side stream:
+    chunk c+1 is on the links while chunk c is in the M-transform.  (ehf:204, 308: the statement
+    being sharded is t.matmul(self.M, X.reshape(self.T,-1)).)"""
+
+    @staticmethod
+    def forward(ctx, X, layer):
+        G, Tl, T, N = layer.G, layer.Tl, layer.T, layer.N
+        F = X.shape[2]
+        K = ops.kernels
+        X = X.contiguous()
+        Xt = torch.empty(Tl, N, F, dtype=X.dtype, device=X.device)
+        chunks = layer.gather_chunks()
+        bufs = layer.gather_buffers(F, X.dtype, X.device)
+        use_streams = X.is_cuda
+        if use_streams:
+            main = torch.cuda.current_stream(X.device)
+            comm = layer.comm_stream()
+            comm.wait_stream(main)              # X is complete; the buffers' previous users are done
+            done = []
+        for ci, (c0, c1) in enumerate(chunks):
+            nc = c1 - c0
+            buf = bufs[ci % 2][:Tl * G * nc * F].view(Tl, G, nc, F)
+            if use_streams:
+                with torch.cuda.stream(comm):
+                    if ci >= 2:
+                        comm.wait_event(done[ci - 2])   # the transform that last read this buffer
+                    for kk in range(Tl):
+                        dist.all_gather_into_tensor(buf[kk].view(G * nc, F), X[kk, c0:c1], group=layer.group)
+                    ev = torch.cuda.Event()
+                    ev.record(comm)
+                main.wait_event(ev)
+            else:
+                for kk in range(Tl):
+                    dist.all_gather_into_tensor(buf[kk].view(G * nc, F), X[kk, c0:c1], group=layer.group)
+            # logical input slice j = r*Tl + kk sits at storage row kk*G + r: x_group_rows = Tl
+            K.mtransform_out(layer.Mop, buf.view(T, nc, F), Xt[:, c0:c1], row_off=layer.k0, col_off=0, x_group_rows=Tl)
+            if use_streams:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                done.append(ev)
+        ctx.layer, ctx.F = layer, F
+        return Xt
+
+    @staticmethod
+    def backward(ctx, dXt):
+        layer, F = ctx.layer, ctx.F
+        G, Tl, T, N = layer.G, layer.Tl, layer.T, layer.N
+        K = ops.kernels
+        dXt = dXt.contiguous()
+        dX = torch.empty(Tl, N, F, dtype=dXt.dtype, device=dXt.device)
+        chunks = layer.gather_chunks()
+        bufs = layer.gather_buffers(F, dXt.dtype, dXt.device)
+        use_streams = dXt.is_cuda
+        if use_streams:
+            main = torch.cuda.current_stream(dXt.device)
+            comm = layer.comm_stream()
+            main.wait_stream(comm)              # nothing of an earlier pass still uses the buffers
+            comm.wait_stream(main)              # dX exists before the first reduce-scatter writes it
+            sent = []
+        for ci, (c0, c1) in enumerate(chunks):
+            nc = c1 - c0
+            buf = bufs[ci % 2][:Tl * G * nc * F].view(Tl, G, nc, F)
+            if use_streams and ci >= 2:
+                main.wait_event(sent[ci - 2])           # the reduce-scatter that last read this buffer
+            # adjoint of the row window: all T rows of Mᵀ[:, k0:k0+Tl] · dXt, in the send layout
+            K.mtransform_out(layer.Mop, dXt[:, c0:c1], buf.view(T, nc, F), transpose=True, row_off=0, col_off=layer.k0,
+                             y_group_rows=Tl)
+            if use_streams:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(comm):
+                    comm.wait_event(ev)
+                    for kk in range(Tl):
+                        dist.reduce_scatter_tensor(dX[kk, c0:c1], buf[kk].view(G * nc, F), op=dist.ReduceOp.SUM, group=layer.group)
+                    ev2 = torch.cuda.Event()
+                    ev2.record(comm)
+                    sent.append(ev2)
+            else:
+                for kk in range(Tl):
+                    dist.reduce_scatter_tensor(dX[kk, c0:c1], buf[kk].view(G * nc, F), op=dist.ReduceOp.SUM, group=layer.group)
+        if use_streams:
+            main.wait_stream(comm)
+        return dX, None
 
 
 class _SharedWeight(torch.autograd.Function):
@@ -231,7 +381,8 @@ class ShardedTMGCNLayer:
 
     def __init__(self, A_local: BatchedCSR, M, T: int, group=None, exchange: str = "a2a",
                  apply_m: bool = True, fuse: Optional[bool] = None, pipeline: bool = True,
-                 force_collectives: bool = False, local_only: bool = False, grid_reserve: Optional[int] = None):
+                 force_collectives: bool = False, local_only: bool = False, grid_reserve: Optional[int] = None,
+                 gather_chunk_nodes: Optional[int] = None):
         # local_only: ignore any initialised process group (an unsharded layer inside a
         # distributed job, e.g. to cross-check a sharded result)
         self.rank, self.G = (0, 1) if local_only else _world(group)
@@ -246,6 +397,10 @@ class ShardedTMGCNLayer:
         if grid_reserve is None:
             grid_reserve = 256 if (self.G > 1 and pipeline and exchange == "a2a") else 0
         self.grid_reserve = int(grid_reserve)   # passed with every fused launch of THIS layer; nothing process-wide
+        # "allgather" mode: nodes per chunk of the chunked gather (None: sized so that one
+        # [T, Nc, F] chunk buffer stays near GATHER_CHUNK_BYTES; 0: the unchunked literal form)
+        self.gather_chunk_nodes = gather_chunk_nodes
+        self._gbufs = None
         self._comm_stream = None
         self._views = None
         self.group = group
@@ -266,6 +421,27 @@ class ShardedTMGCNLayer:
         self.Mop = ops.MOperator(M, A_local.device) if apply_m else None
         if apply_m and self.Mop.T != T:
             raise RuntimeError(f"M is {self.Mop.T}x{self.Mop.T}, expected {T}x{T}")
+
+    def gather_chunks(self, F: Optional[int] = None) -> List[Tuple[int, int]]:
+        """Node ranges of the chunked all-gather.  The automatic size needs F (bytes per node of a
+        [T, Nc, F] buffer); once chosen it is kept, so forward and backward agree."""
+        if self.gather_chunk_nodes is None:
+            if F is None:
+                raise RuntimeError("gather_chunks: the chunk size has not been chosen yet")
+            self.gather_chunk_nodes = chunk_nodes_for(self.T, self.N, F)
+        nc = max(1, min(self.N, int(self.gather_chunk_nodes)))
+        return [(c0, min(self.N, c0 + nc)) for c0 in range(0, self.N, nc)]
+
+    def gather_buffers(self, F: int, dtype, device):
+        """The two alternating [T, Nc, F] chunk buffers (flat), allocated once per layer: they are
+        written on the side stream and read on the main one, so they never go back to the
+        allocator between passes."""
+        nc = self.gather_chunks(F)[0][1]
+        need = self.T * nc * F
+        if self._gbufs is None or self._gbufs[0].numel() < need or self._gbufs[0].dtype != dtype or \
+                self._gbufs[0].device != torch.device(device):
+            self._gbufs = [torch.empty(need, dtype=dtype, device=device) for _ in range(2)]
+        return self._gbufs
 
     def comm_stream(self):
         if self._comm_stream is None:
@@ -310,11 +486,16 @@ class ShardedTMGCNLayer:
                     W = _SharedWeight.apply(W, self.group)
                 return _PipelinedCore.apply(send, W, self, act)
             Xt = _NodeToSlice.apply(send, self.Tl, self.N, self.group)
-        else:
+        elif not self.apply_m:
+            Xt = X                                   # no M: a rank's own slices are all it needs — no exchange
+        elif self.gather_chunk_nodes == 0:
+            # the literal form: the whole [T,N,F] tensor on every rank (fits only for small N·F or G)
             Xf = _AllGatherSlices.apply(X, self.group)
             # own output slices only: rows [k0, k0+Tl) of M against all T input slices
-            Xt = ops.m_transform(Xf, self.Mop, row_off=self.k0, col_off=0, T_out=self.Tl) if self.apply_m \
-                else Xf[self.k0:self.k0 + self.Tl].contiguous()
+            Xt = ops.m_transform(Xf, self.Mop, row_off=self.k0, col_off=0, T_out=self.Tl)
+        else:
+            self.gather_chunks(X.shape[2])           # fixes the chunk size on first use
+            Xt = _ChunkedGatherTransform.apply(X, self)
         if shared_w and self.collective:
             W = _SharedWeight.apply(W, self.group)      # condensed_W: dW summed over ranks
         return ops.spmm_feature_gemm(self.A, Xt, W, act=act, fuse=self.fuse)

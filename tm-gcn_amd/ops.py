@@ -186,6 +186,17 @@ class HipKernels:
         return self._run("mtransform_T" if transpose else "mtransform", X.device, lambda: self.ops.mtransform(
             op.M, X, bool(transpose), row_off, col_off, -1 if T_out is None else T_out, lo, hi, x_group_rows, y_group_rows))
 
+    def mtransform_out(self, op: MOperator, X: torch.Tensor, Y: torch.Tensor, transpose=False, row_off=0, col_off=0,
+                       x_group_rows=0, y_group_rows=0, tag=None) -> torch.Tensor:
+        """The same product on a column window: X [T_in, n, F] and Y [T_out, n, F] may be views whose
+        slices lie further apart than n*F (Xt[:, c0:c1, :] of a resident tensor); written in place
+        into Y (tmgcn_mtransform_ld_f32).  The node-chunked all-gather of dist.py is built on it."""
+        lo, hi = (op.band_hi, op.band_lo) if transpose else (op.band_lo, op.band_hi)
+        tag = tag or ("mtransform_T" if transpose else "mtransform")
+        self._run(tag, X.device, lambda: self.ops.mtransform_out(
+            op.M, X, Y, bool(transpose), row_off, col_off, lo, hi, x_group_rows, y_group_rows))
+        return Y
+
     # P2 ---------------------------------------------------------------------------------
     def spmm(self, A: BatchedCSR, X: torch.Tensor, tag="spmm") -> torch.Tensor:
         return self._run(tag, X.device, lambda: self.ops.spmm_csr_batched(A.rowptr, A.col, A.val, X, A.N, A.avg_nnz_per_row))
