@@ -21,6 +21,10 @@ Rank 0 prints ONE JSON line (driver contract), the last line of the job's stdout
   epochs        training-epoch time of the reference-shaped configs S1-S3 (GPU eager / hipGraph /
                 untouched-script mode vs the CPU oracle; north_star's >= 10x Reddit-LP target), N = 1 only
   ranks         world size as RCCL itself reports it, and the device every rank ran on
+  verify        after the timed region every rank checks sampled rows of Y and dX and the all-reduced dW of
+                the last step against the CPU oracle, from regenerated seeded inputs (tools/bench_verify.py);
+                a miss makes the job exit non-zero
+  plan          per-rank HBM plan of both exchange modes, computed before anything is allocated
 Every rank carries a hard deadline (--deadline): stacks are dumped and the process exits non-zero,
 so a stalled multi-rank job ends instead of hanging until somebody's timeout.
 """
@@ -55,10 +59,15 @@ def parse(argv=None):
     p.add_argument("--no-epochs", action="store_true", help="skip the S1-S3 training-epoch block (N = 1 only)")
     p.add_argument("--no-compare-exchange", action="store_true",
                    help="skip the a2a / allgather side-by-side leg of multi-rank runs")
-    p.add_argument("--compare-full", action="store_true",
-                   help="also run the OTHER exchange mode at full N where it fits (the all-gather materialises [T,N,F] "
-                        "twice per GPU: only G = 2 at the S4 size); off by default so that a scaling run never risks its "
-                        "headline measurement on a 200 GB side experiment")
+    p.add_argument("--no-compare-full", action="store_true",
+                   help="skip the full-N run of the OTHER exchange mode (by default it runs whenever its memory plan fits: "
+                        "the all-gather is node-chunked, so it fits at every world size)")
+    p.add_argument("--gather-chunk-nodes", type=int, default=None,
+                   help="nodes per chunk of the chunked all-gather (default: ~8 GB chunk buffers; 0 = the literal "
+                        "unchunked form, which materialises [T,N,F] twice per GPU)")
+    p.add_argument("--no-verify", action="store_true",
+                   help="skip the verify leg (sampled rows of Y / dX and the all-reduced dW against the CPU oracle)")
+    p.add_argument("--verify-rows", type=int, default=128, help="sampled rows per slice (Y) and sampled nodes (dX) per rank")
     p.add_argument("--no-fuse", action="store_true", help="run P2 and P3 as separate kernels")
     p.add_argument("--no-pipeline", action="store_true", help="exchange all slices before computing")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
@@ -371,11 +380,12 @@ def epochs_block(args, configs=("S1", "S2", "S3"), modes=("eager", "graph", "fus
 # ---------------------------------------------------------------------------------------
 # the layer bench proper
 # ---------------------------------------------------------------------------------------
-def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_timer=True):
-    """Build this rank's shard of the S4 layer at N nodes and time `steps` fwd+bwd steps.
-    Returns a dict; every device tensor dies with this frame."""
+def build_problem(args, dev, rank, world, exchange, N, kernels_ok=True):
+    """This rank's shard of the S4 layer at N nodes: adjacency, M, layer, inputs — and the three
+    closures that REGENERATE any slice of the global inputs from its seed (the verify leg uses them
+    for data other ranks hold)."""
     import torch
-    from tmgcn_amd import ops, synth
+    from tmgcn_amd import synth
     from tmgcn_amd.dist import ShardedTMGCNLayer
 
     G, Tl, F = world, args.slices_per_gpu, args.feat
@@ -386,24 +396,52 @@ def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_tim
     M = synth.band_M(T, args.band, "matlab")
     layer = ShardedTMGCNLayer(A, M, T, group=None, exchange=exchange, fuse=False if args.no_fuse else None,
                               pipeline=not args.no_pipeline, force_collectives=args.force_collectives,
-                              grid_reserve=args.grid_reserve)
+                              grid_reserve=args.grid_reserve, gather_chunk_nodes=args.gather_chunk_nodes)
     shape = layer.input_shape(F)
-    if layer.collective and exchange == "a2a":
-        # node shard of the synthetic features: slice k seeded by k, columns of this rank's nodes
+    node_sharded = layer.collective and exchange == "a2a"
+    if node_sharded:
+        # node shard of the synthetic features: slice j of rank q's shard is seeded by 1000*q + j
         X = synth.device_features(T, shape[1], F, dev, first_slice=1000 * rank)
     else:
         X = synth.device_features(shape[0], N, F, dev, first_slice=k0)
     X.requires_grad_(True)
     g = torch.Generator(device=dev).manual_seed(1234)
     W = (torch.randn(F, F, device=dev, generator=g) * 0.1).requires_grad_(True)  # same on every rank
-    g.manual_seed(99 + rank)
-    dY = torch.randn(Tl, N, F, device=dev, generator=g)
+    dY = synth.device_normal(Tl, N, F, dev, first_slice=k0)
+
+    def x_slice(j):                       # [N, F] of global input slice j, whoever holds it
+        if node_sharded:
+            return torch.cat([synth.device_features(1, shape[1], F, dev, first_slice=1000 * q + j)[0] for q in range(G)], 0)
+        return synth.device_features(1, N, F, dev, first_slice=j)[0]
+
+    def dy_slice(k):                      # [N, F] of upstream-gradient slice k
+        return synth.device_normal(1, N, F, dev, first_slice=k)[0]
+
+    def a_slice(k):                       # one-slice CSR of adjacency slice k
+        return synth.device_er_csr(1, N, args.deg, dev, first_slice=k)
+
+    return dict(A=A, M=M, T=T, Tl=Tl, k0=k0, layer=layer, X=X, W=W, dY=dY, node_sharded=node_sharded,
+                x_slice=x_slice, dy_slice=dy_slice, a_slice=a_slice)
+
+
+def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_timer=True, verify=False):
+    """Build this rank's shard of the S4 layer at N nodes and time `steps` fwd+bwd steps.
+    Returns a dict; every device tensor dies with this frame."""
+    import torch
+    from tmgcn_amd import ops
+
+    pb = build_problem(args, dev, rank, world, exchange, N)
+    A, layer, X, W, dY = pb["A"], pb["layer"], pb["X"], pb["W"], pb["dY"]
+    F = args.feat
+    last = {}
 
     def step():
         X.grad = None
         W.grad = None
+        last.clear()                      # frees the previous Y before the next forward allocates
         Y = layer(X, W)
         Y.backward(dY)
+        last["Y"] = Y.detach()
 
     def fence():
         torch.cuda.synchronize()
@@ -435,9 +473,23 @@ def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_tim
     else:
         total_nnz = A.nnz
     stage(f"layer[{exchange}, N={N}]: {elapsed / steps * 1e3:.1f} ms/step")
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 1e9
+    ver = None
+    if verify:
+        # the checker: the results of the LAST TIMED step against the CPU oracle, from regenerated inputs
+        stage(f"layer[{exchange}, N={N}]: verify")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_verify import verify_layer
+        ver = verify_layer(dist=dist, rank=rank, world=world, dev=dev, node_sharded_input=pb["node_sharded"], A=A,
+                           M64=pb["M"], T=pb["T"], k0=pb["k0"], N=N, W=W, X=X, dY=dY, Y=last["Y"], dX=X.grad, dW=W.grad,
+                           x_slice=pb["x_slice"], dy_slice=pb["dy_slice"], a_slice=pb["a_slice"], rows=args.verify_rows)
+        stage(f"layer[{exchange}, N={N}]: verify {'ok' if ver['ok'] else 'FAILED'} in {ver['seconds']} s: "
+              f"Y {ver['max_rel_err_Y']:.2e} dX {ver['max_rel_err_dX']:.2e} dW {ver['max_rel_err_dW']}")
     return {"elapsed": elapsed, "kt": kt, "nnz_rank": A.nnz, "rows_rank": A.n_rows, "total_nnz": total_nnz,
-            "collective": layer.collective, "grid_reserve": layer.grid_reserve, "T": T,
-            "peak_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
+            "collective": layer.collective, "grid_reserve": layer.grid_reserve, "T": pb["T"],
+            "gather_chunks": len(layer.gather_chunks(F)) if (layer.collective and exchange == "allgather"
+                                                               and layer.gather_chunk_nodes != 0) else None,
+            "peak_gb": peak_gb, "verify": ver}
 
 
 def free_device_memory():
@@ -487,7 +539,11 @@ def worker(args):
     ranks_info = None
     if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:      # no launcher (--force-collectives at --gpus 1): any free port
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         # one node by contract: keep every bootstrap socket on loopback (the container hostname
         # may not resolve, and a resolver time-out looks exactly like a stalled first run)
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
@@ -515,32 +571,46 @@ def worker(args):
     _lib.load()  # fail loudly if the HIP library is missing
 
     N, F, Tl = args.nodes, args.feat, args.slices_per_gpu
-    res = run_layer(args, dist, dev, rank, world, args.exchange, N, args.steps, args.warmup)
+    from tmgcn_amd.dist import memory_plan
+    collective = world > 1 or args.force_collectives
+    nnz_rank = Tl * N * (args.deg + 1)
+
+    def plan_of(ex, n_nodes):
+        ex = ex if collective else "none"
+        return memory_plan(ex, Tl * world, world, n_nodes, F, F, Tl * n_nodes * (args.deg + 1),
+                           gather_chunk_nodes=args.gather_chunk_nodes)
+
+    def fits(ex, n_nodes, extra_bytes=0):
+        """Collective decision, BEFORE anything is allocated: does the plan of mode `ex` at n_nodes fit
+        on every rank (10 % headroom + the verify leg's fp64 buffer when asked for)?"""
+        need = plan_of(ex, n_nodes)["total"] + extra_bytes
+        free_b, _total = torch.cuda.mem_get_info(dev)
+        if args.single_device:
+            free_b //= world                     # every rank of the emulation allocates on the same device
+        ok = torch.tensor([1 if free_b > 1.10 * need else 0], device=dev)
+        if dist.is_initialized():
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return bool(int(ok.item())), need, free_b
+
+    plans = {ex: plan_of(ex, N) for ex in (("a2a", "allgather") if collective else ("none",))}
+    for ex, pl in plans.items():
+        stage(f"plan[{ex}, N={N}]: {pl['total_gb']} GB per rank (exchange: {pl['exchange'] / 1e9:.1f} GB, {pl['exchange_note']})")
+    ok, need, free_b = fits(args.exchange, N)
+    if not ok:
+        raise SystemExit(f"bench: the '{args.exchange}' plan needs {need / 1e9:.0f} GB per rank but only {free_b / 1e9:.0f} GB "
+                         f"are free (rank {rank}); nothing was allocated")
+    res = run_layer(args, dist, dev, rank, world, args.exchange, N, args.steps, args.warmup, verify=not args.no_verify)
     free_device_memory()
 
     compare = None
-    if (world > 1 or args.force_collectives) and not args.no_compare_exchange and res["collective"]:
+    if collective and not args.no_compare_exchange and res["collective"]:
         # a2a (node -> slice re-partition, the xGMI-first form) and the north-star's literal all-gather
-        # side by side.  The all-gather materialises [T,N,F] (forward) and again for the reduce-scatter
-        # input (backward) on every GPU, so at S4 size it only fits for small G: the pair is always
-        # measured at a reduced N, and at full N wherever it fits (decided collectively).
-        def fits(ex, n_nodes):
-            """Collective decision: does one more layer in mode `ex` at n_nodes fit on every rank?
-            The all-gather materialises [T,N,F] forward and again as the reduce-scatter input."""
-            slab = Tl * n_nodes * F * 4
-            nnz_b = Tl * n_nodes * (args.deg + 1) * 8
-            need = ((2 * world + 8) if ex == "allgather" else 10) * slab + 2 * nnz_b + (2 << 30)
-            free_b, _total = torch.cuda.mem_get_info(dev)
-            if args.single_device:
-                free_b //= world                     # every rank of the emulation allocates on the same device
-            ok = torch.tensor([1 if free_b > 1.15 * need else 0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            return bool(int(ok.item())), need
-
+        # (node-chunked, fused with its P1 consumer) side by side: at a reduced N, and at full N
+        # whenever the other mode's memory plan fits (decided collectively, before allocating).
         n_cmp = min(N, args.compare_nodes)
         compare = {"reduced_n": {"nodes": n_cmp}}
         for ex in ("a2a", "allgather"):
-            ok, need = fits(ex, n_cmp)
+            ok, need, _ = fits(ex, n_cmp)
             if ok:
                 r = run_layer(args, dist, dev, rank, world, ex, n_cmp, 3, 1, want_timer=False)
                 compare["reduced_n"][ex + "_ms_per_step"] = round(r["elapsed"] / 3 * 1e3, 3)
@@ -549,22 +619,24 @@ def worker(args):
                 compare["reduced_n"][ex + "_ms_per_step"] = None
                 compare["reduced_n"][ex + "_note"] = f"needs about {need / 1e9:.0f} GB per rank: does not fit here"
         other = "allgather" if args.exchange == "a2a" else "a2a"
-        ok, need = fits(other, N)
+        ok, need, _ = fits(other, N)
         compare["full_n"] = {"nodes": N, args.exchange + "_ms_per_step": round(res["elapsed"] / args.steps * 1e3, 3),
-                             other + "_needs_gb_per_gpu": round(need / 1e9, 1)}
-        if not args.compare_full and N != n_cmp:
-            compare["full_n"][other + "_ms_per_step"] = None
-            compare["full_n"]["note"] = "not run (pass --compare-full); " + ("it would fit" if ok else "it would not fit at this world size")
-        elif ok and N != n_cmp:
-            r = run_layer(args, dist, dev, rank, world, other, N, 3, 1, want_timer=False)
-            compare["full_n"][other + "_ms_per_step"] = round(r["elapsed"] / 3 * 1e3, 3)
-            free_device_memory()
-        elif N == n_cmp:
+                             other + "_plan_gb_per_gpu": round(need / 1e9, 1)}
+        if N == n_cmp:
             compare["full_n"][other + "_ms_per_step"] = compare["reduced_n"].get(other + "_ms_per_step")
+        elif args.no_compare_full:
+            compare["full_n"][other + "_ms_per_step"] = None
+            compare["full_n"]["note"] = "not run (--no-compare-full); " + ("it would fit" if ok else "it would not fit at this world size")
+        elif ok:
+            r = run_layer(args, dist, dev, rank, world, other, N, 3, 1, want_timer=False, verify=not args.no_verify)
+            compare["full_n"][other + "_ms_per_step"] = round(r["elapsed"] / 3 * 1e3, 3)
+            compare["full_n"][other + "_gather_chunks"] = r["gather_chunks"]
+            compare["full_n"][other + "_peak_hbm_gb_rank0"] = round(r["peak_gb"], 1)
+            compare["full_n"][other + "_verify"] = r["verify"]
+            free_device_memory()
         else:
             compare["full_n"][other + "_ms_per_step"] = None
-            compare["full_n"]["note"] = ("all-gather of [T,N,F] (+ its reduce-scatter input) does not fit beside the layer "
-                                         "at this world size")
+            compare["full_n"]["note"] = f"the {other} plan ({need / 1e9:.0f} GB per rank) does not fit beside what is resident"
 
     out = None
     if rank == 0:
@@ -605,24 +677,32 @@ def worker(args):
                          "avg_launch_ms": sp["avg_ms"]},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
             "peak_hbm_gb_rank0": round(res["peak_gb"], 1),
+            "plan": {ex: {"total_gb": pl["total_gb"], "exchange_gb": round(pl["exchange"] / 1e9, 2), "exchange": pl["exchange_note"]}
+                     for ex, pl in plans.items()},
+            "verify": res["verify"],
         }
+        if res["gather_chunks"] is not None:
+            out["config"]["gather_chunks"] = res["gather_chunks"]
         if ranks_info is not None:
             out["ranks"] = ranks_info
         if compare is not None:
             out["exchange_compare"] = compare
         if "gemm_dW" in kt:
             # the one GEMM that still runs as its own kernel (dW = AXᵀ·dY); the forward / dA GEMMs run
-            # inside the fused SpMM kernels, hidden under the gather.  It multiplies on the bf16 matrix
-            # cores after an exact 3-way split of the fp32 operands: 6 bf16 MFMA products per fp32 term.
+            # inside the fused SpMM kernels, hidden under the gather.  At 128x128 its arithmetic intensity
+            # (192 bf16-flop per byte streamed) is on the MEMORY side of the bf16 ridge (312 flop/B): HBM is
+            # its roof, the matrix-core figures are reported beside it.
             t_dw = kt["gemm_dW"]["avg_ms"] * 1e-3
             fp32_tf = 2.0 * res["rows_rank"] * F * F / t_dw / 1e12
-            out["mfma"] = {"kernel": "gemm_dw_bf16x3_kernel (dW)", "bound": "mfma", "achieved": 6.0 * fp32_tf,
-                           "peak": 2500.0, "unit": "TFLOP/s", "frac": 6.0 * fp32_tf / 2500.0,
-                           "dtype": "bf16 planes of an exact 3-way fp32 split (v_mfma_f32_32x32x16_bf16), fp32 accumulate",
-                           "fp32_equivalent_tflops": fp32_tf, "f32_mfma_peak_tflops": 157.3,
-                           "hbm_gbs": res["rows_rank"] * 2 * F * 4 / t_dw / 1e9,
-                           "bound_by": "board power: this kernel runs at the 1400 W cap with the shader clock pulled to "
-                                       "~1.9 GHz (profiles/r02t_power_probe.jsonl), neither the matrix pipes nor HBM are saturated"}
+            gbs = res["rows_rank"] * 2 * F * 4 / t_dw / 1e9
+            out["dw_roofline"] = {"kernel": "gemm_dw_bf16x3_kernel (dW)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": kt["gemm_dW"]["avg_ms"],
+                                  "bytes_per_row": 2 * F * 4,
+                                  "mfma_tflops_bf16": 6.0 * fp32_tf, "mfma_frac_of_2500": 6.0 * fp32_tf / 2500.0,
+                                  "fp32_equivalent_tflops": fp32_tf,
+                                  "dtype": "bf16 planes of an exact 3-way fp32 split (v_mfma_f32_32x32x16_bf16), fp32 accumulate",
+                                  "note": "6 bf16 MFMA products per fp32 term; runs at the 1400 W board cap with the shader clock "
+                                          "pulled down (profiles/r02t_power_probe.jsonl)"}
         if world == 1:  # the CPU legs are reported at N = 1 only
             if not args.no_epochs:
                 out["epochs"] = epochs_block(args)
@@ -644,6 +724,11 @@ def worker(args):
     if rank == 0:
         print(json.dumps(out), flush=True)
     stage("done")
+    bad = [v for v in (res.get("verify"), ((compare or {}).get("full_n") or {}).get(
+        ("allgather" if args.exchange == "a2a" else "a2a") + "_verify")) if v is not None and not v["ok"]]
+    if bad:
+        sys.stderr.write(f"[bench r{rank}] VERIFY FAILED: {json.dumps(bad)}\n")
+        sys.exit(3)
 
 
 def main():

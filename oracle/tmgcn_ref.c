@@ -8,7 +8,9 @@
  * as include/tmgcn.h so the HIP kernels can be compared call for call.
  *
  * Parity status: PINNED through tests/test_oracle_golden.py (checked against fixtures captured
- * from the real ehf, tests/golden/make_golden.py).
+ * from the real ehf, tests/golden/make_golden.py): ref_mtransform + ref_spmm against G1's AtXt,
+ * ref_gemm + ref_gemm_dw against G2's logits and dW (shared and per-slice W), ref_mtransform_rows
+ * against ref_mtransform.
  */
 #include <stdint.h>
 #include <stddef.h>
@@ -24,6 +26,24 @@ void ref_mtransform(const double* M, int T, int transpose, const float* X, float
         if (m != 0.0) s += m * (double)X[(size_t)j * C + c];
       }
       Y[(size_t)k * C + c] = (float)s;
+    }
+  }
+}
+
+/* The same statement for a WINDOW of output rows [row0, row0 + nrows) only (bench.py's verify leg
+ * needs one output slice of fibres that span all T input slices: computing all T rows would be
+ * T times the work).  Y is [nrows][C]. */
+void ref_mtransform_rows(const double* M, int T, int transpose, int row0, int nrows, const float* X, float* Y,
+                         int64_t C) {
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < C; ++c) {
+    for (int k = row0; k < row0 + nrows; ++k) {
+      double s = 0.0;
+      for (int j = 0; j < T; ++j) {
+        const double m = transpose ? M[(size_t)j * T + k] : M[(size_t)k * T + j];
+        if (m != 0.0) s += m * (double)X[(size_t)j * C + c];
+      }
+      Y[(size_t)(k - row0) * C + c] = (float)s;
     }
   }
 }

@@ -47,19 +47,8 @@ def assert_close(got, ref, tol=REL_TOL, what=""):
 
 
 def load_c_oracle():
-    path = os.path.join(ROOT, "oracle", "libtmgcn_ref.so")
-    if not os.path.exists(path):
-        import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
-    lib = C.CDLL(path)
-    p, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
-    lib.ref_mtransform.argtypes = [p, C.c_int, C.c_int, p, p, i64]
-    lib.ref_spmm.argtypes = [p, p, p, p, p, i64, i32, i32]
-    lib.ref_gemm.argtypes = [p, p, p, i64, i32, i32, i32, i64, i64]
-    lib.ref_gemm_dw.argtypes = [p, p, p, i64, i32, i32, i64]
-    for f in (lib.ref_mtransform, lib.ref_spmm, lib.ref_gemm, lib.ref_gemm_dw):
-        f.restype = None
-    return lib
+    from oracle import c_ref
+    return c_ref.load()
 
 
 def cptr(t):

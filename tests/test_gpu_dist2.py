@@ -16,14 +16,19 @@ ROOT = os.path.dirname(HERE)
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, exchange, F0, F1, condensed, act, pipeline, ret):
+def _worker(rank, world, port, exchange, F0, F1, condensed, act, pipeline, ret, backend="gloo"):
     try:
         for p in (ROOT, HERE):
             if p not in sys.path:
                 sys.path.insert(0, p)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        torch.cuda.set_device(0)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":               # one GPU per rank, RCCL over xGMI (tests/test_gpu_multi.py)
+            torch.cuda.set_device(rank)
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        else:                               # the ranks share cuda:0, gloo carries the device tensors
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         from tmgcn_amd import synth
         from tmgcn_amd.csr import BatchedCSR
         from tmgcn_amd.dist import ShardedTMGCNLayer, even_bounds

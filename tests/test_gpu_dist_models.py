@@ -35,14 +35,19 @@ def _build(ehf, kind, kw, i, group):
     return ehf.EmbeddingKWGCN(i["A"], i["X"], i["edges"], hidden_feat=[6, 5, 2], group=group, **kw)
 
 
-def _worker(rank, world, port, name, ret):
+def _worker(rank, world, port, name, ret, backend="gloo"):
     try:
         for p in (ROOT, HERE):
             if p not in sys.path:
                 sys.path.insert(0, p)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        torch.cuda.set_device(0)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":               # one GPU per rank, RCCL over xGMI (tests/test_gpu_multi.py)
+            torch.cuda.set_device(rank)
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        else:                               # the ranks share cuda:0, gloo carries the device tensors
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         from _util import coo_list, golden
         import tmgcn_amd.layers as ehf
         from tmgcn_amd import ops

@@ -55,6 +55,62 @@ def test_g1_c_oracle_and_dense_identity(name):
     assert_close(dense, d["AtXt"], REL_TOL, name + " einsum")
 
 
+@pytest.mark.parametrize("name", ["g2_gcn_condensed1", "g2_gcn_condensed0"])
+def test_g2_c_oracle_gemm_and_gemm_dw(name):
+    """Pins the GEMM half of the C oracle (ref_gemm, ref_gemm_dw: the checker of the P3 / dW kernel
+    tests and of the Y / dW legs of the bench-size test and of bench.py's verify block) on the
+    reference's own numbers: ehf:222 `t.matmul(AtXt, W)` through the edge head reproduces the
+    fixture's logits, and its autograd `dW = Σ AtXtᵀ·dY` reproduces the fixture's dW — for the
+    shared weight (condensed_W) and for one weight per slice."""
+    d = golden(name)
+    i = _inputs(d)
+    lib = load_c_oracle()
+    T, N, F0 = i["X"].shape
+    W0 = torch.from_numpy(d["W0"]).contiguous()
+    per_slice = W0.dim() == 3
+    F1 = W0.shape[-1]
+    AtXt = orc.compute_AtXt(i["M"], i["At"], i["X"]).contiguous()           # fp32 [T,N,F0], pinned by G1
+    assert AtXt.dtype == torch.float32
+    Y = torch.empty(T, N, F1)
+    lib.ref_gemm(cptr(AtXt), cptr(W0), cptr(Y), T * N, F0, F1, 0, N if per_slice else 0, F0 * F1 if per_slice else 0)
+    src, dst = orc.flat_edge_index(i["edges"], N)
+    U = torch.from_numpy(d["U0"]).clone().requires_grad_(True)
+    Yl = Y.clone().requires_grad_(True)
+    logits = orc.edge_head(Yl, src, dst, U)
+    assert_close(logits.detach(), d["logits"], 1e-6, name + " logits through ref_gemm")
+    loss = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1]))(logits, i["labels"])
+    assert abs(float(loss) - float(d["loss"])) <= 1e-6 * max(1.0, abs(float(d["loss"])))
+    loss.backward()
+    assert_close(U.grad, d["dU"], 1e-6, name + " dU")
+    dY = Yl.grad.contiguous()
+    dW = torch.empty_like(W0)
+    lib.ref_gemm_dw(cptr(AtXt), cptr(dY), cptr(dW), T * N, F0, F1, N if per_slice else 0)
+    assert_close(dW, d["dW"], 1e-6, name + " dW through ref_gemm_dw")
+    # the transposed-weight form (dA = dY·Wᵀ, what the backward GEMM tests use) against torch fp64
+    dA = torch.empty(T, N, F0)
+    lib.ref_gemm(cptr(dY), cptr(W0), cptr(dA), T * N, F1, F0, 1, N if per_slice else 0, F0 * F1 if per_slice else 0)
+    ref = torch.matmul(dY.double(), W0.double().transpose(-1, -2)) if not per_slice else \
+        torch.einsum("tnf,tkf->tnk", dY.double(), W0.double())
+    assert_close(dA, ref, 1e-6, name + " dA through ref_gemm(trans_w)")
+
+
+def test_c_oracle_row_window_is_the_full_product():
+    """ref_mtransform_rows (one window of output rows; used by bench.py's verify block) returns the
+    rows ref_mtransform returns, bit for bit, forward and transposed."""
+    lib = load_c_oracle()
+    T, C = 12, 37
+    g = torch.Generator().manual_seed(0)
+    M = torch.from_numpy(synth.band_M(T, 5, "matlab")).contiguous()
+    X = torch.randn(T, C, generator=g)
+    for tr in (0, 1):
+        full = torch.empty(T, C)
+        lib.ref_mtransform(cptr(M), T, tr, cptr(X), cptr(full), C)
+        for r0, n in ((0, T), (3, 1), (7, 5)):
+            part = torch.empty(n, C)
+            lib.ref_mtransform_rows(cptr(M), T, tr, r0, n, cptr(X), cptr(part), C)
+            assert torch.equal(part, full[r0:r0 + n])
+
+
 @pytest.mark.parametrize("name", golden_names("g2_"))
 def test_g2_gcn(name):
     d = golden(name)

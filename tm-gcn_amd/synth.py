@@ -237,3 +237,14 @@ def device_features(T: int, N: int, F: int, device, first_slice: int = 0) -> tor
         g.manual_seed(7919 * (first_slice + k) + 3)
         X[k].uniform_(0.0, 1.0, generator=g)
     return X
+
+
+def device_normal(T: int, N: int, F: int, device, first_slice: int = 0, salt: int = 99) -> torch.Tensor:
+    """~ N(0,1) fp32 [T,N,F], slice k seeded with (salt, first_slice + k): any rank can regenerate any
+    slice of it (bench.py's upstream gradient dY, which its verify leg rebuilds slice by slice)."""
+    Y = torch.empty(T, N, F, dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    for k in range(T):
+        g.manual_seed(104729 * (first_slice + k) + 31 * salt + 5)
+        Y[k].normal_(0.0, 1.0, generator=g)
+    return Y
