@@ -59,6 +59,9 @@ def _worker(rank, world, port, exchange, F0, F1, condensed, act, pipeline, ret, 
 
         def close(a, b, what, tol=2e-5):
             err = float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+            if rank == 0:
+                from _util import record_tolerance
+                record_tolerance(f"sharded {exchange} world={world} {what}", err, tol)
             assert err <= tol, f"{what}: {err:.2e}"
         close(Y.detach(), Yr.detach()[k0:k1], "Y")
         close(Xin.grad, Xr.grad[:, n0:n1] if exchange == "a2a" else Xr.grad[k0:k1], "dX")

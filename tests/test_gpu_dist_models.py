@@ -63,6 +63,9 @@ def _worker(rank, world, port, name, ret, backend="gloo"):
         def close(a, b, what, tol=1e-5):
             a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
             err = float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+            if rank == 0:
+                from _util import record_tolerance
+                record_tolerance(f"sharded model {name} world={world} {what}", err, tol)
             assert err <= tol, f"{what}: {err:.2e}"
 
         group = dist.group.WORLD
