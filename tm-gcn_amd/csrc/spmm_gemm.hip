@@ -36,6 +36,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef TMGCN_FUSED_LDS_PAD
 #define TMGCN_FUSED_LDS_PAD 0
 #endif
+// EXPERIMENT ("16-byte epilogue"): transpose each 4x4 accumulator block across its
+// lane quad (common.h quad_transpose4) so that a lane stores four consecutive COLUMNS of one row with
+// one 16-byte store instead of four 4-byte stores of one column of four rows.  A/B in
+// profiles/r3*_ab_fused_variants.txt; off by default unless it pays.
+#ifndef TMGCN_FUSED_QT
+#define TMGCN_FUSED_QT 0
+#endif
 
 constexpr int FBM = 64;         // rows per tile
 constexpr int FKC = 128;        // max K (feature width of X)
@@ -167,6 +174,25 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
         }
       }
       const int n = n0 + li;
+#if TMGCN_FUSED_QT
+      if (a.Nf % 4 == 0) {  // wave-uniform: whole column quads are in or out of range
+        const int j = li & 3, nq = n0 + 4 * (li >> 2);
+#pragma unroll
+        for (int mb = 0; mb < FBM / 32; ++mb) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v[4] = {acc[mb][4 * g], acc[mb][4 * g + 1], acc[mb][4 * g + 2], acc[mb][4 * g + 3]};
+            quad_transpose4(v, j);  // lane j of the quad now owns row 8g + 4lh + j, columns nq .. nq+3
+            const int64_t r = row0 + mb * 32 + 8 * g + 4 * lh + j;
+            if (r < row_end && nq < a.Nf) {
+              if (a.pre) store_f4(reinterpret_cast<float4*>(&a.pre[r * a.Nf + nq]), make_float4(v[0], v[1], v[2], v[3]));
+              store_f4(reinterpret_cast<float4*>(&a.Y[r * a.Nf + nq]),
+                       make_float4(act_apply(v[0], a.act), act_apply(v[1], a.act), act_apply(v[2], a.act), act_apply(v[3], a.act)));
+            }
+          }
+        }
+      } else
+#endif
       if (n < a.Nf) {
 #pragma unroll
         for (int mb = 0; mb < FBM / 32; ++mb) {

@@ -60,6 +60,18 @@ for which in ("spmm", "fused", "fused+ax"):
             e.record()
             torch.cuda.synchronize()
             res.setdefault((which, name), []).append(s.elapsed_time(e))
+# every variant computes the same thing: Y (and AX) bit for bit against the default library
+ref = None
+for name, lib in libs.items():
+    Y.zero_(); AX.zero_()
+    assert run(lib, "fused+ax") == 0
+    torch.cuda.synchronize()
+    if ref is None:
+        ref = (Y.clone(), AX.clone())
+    else:
+        print(f"check     {name:16s} Y bit-equal: {bool(torch.equal(Y, ref[0]))}  AX bit-equal: {bool(torch.equal(AX, ref[1]))}  "
+              f"max|dY| = {float((Y - ref[0]).abs().max()):.2e}")
+del ref
 by = A.nnz * (8 + F * 4 + (4 + F * 4) / (A.nnz / A.n_rows))
 for (which, name), ms in res.items():
     med = statistics.median(ms)

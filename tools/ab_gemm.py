@@ -66,6 +66,56 @@ for which in ("gemm", "gemm_bf16w", "gemm_dA", "gemm_dW"):
             e.record()
             torch.cuda.synchronize()
             res.setdefault((which, name), []).append(s.elapsed_time(e))
+# results of the variants agree with the default library (dW: bit for bit is not required — a variant may
+# change the summation order — but it must stay fp32-accurate)
+ref_dw = None
+for name, lib in libs.items():
+    dW.zero_()
+    assert run(lib, "gemm_dW") == 0
+    torch.cuda.synchronize()
+    if ref_dw is None:
+        ref_dw = dW.clone()
+        truth = A[:1_000_000].double().t() @ dY[:1_000_000].double() if R <= 1_000_000 else None
+    else:
+        d = float((dW.double() - ref_dw.double()).abs().max() / ref_dw.double().abs().max())
+        print(f"gemm_dW    {name:14s} max|dW - dW_default|/max|dW| = {d:.2e}  bit-equal: {bool(torch.equal(dW, ref_dw))}")
+        assert d <= 2e-6, "variant result differs from the default library"
+
+if os.environ.get("AB_POWER"):   # board power / shader clock while each library's dW runs back to back
+    import json, re, subprocess, threading, time
+
+    def smi():
+        try:
+            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+            card = next(iter(json.loads(out).values()))
+            power = next((float(v) for k, v in card.items() if "power" in k.lower() and re.match(r"^[0-9.]+$", str(v))), None)
+            return power, next((v for k, v in card.items() if k.lower().startswith("sclk")), None)
+        except Exception as e:  # noqa: BLE001
+            return None, str(e)
+
+    for name, lib in libs.items():
+        samples, stop = [], threading.Event()
+
+        def sampler():
+            while not stop.is_set():
+                samples.append(smi())
+                time.sleep(0.4)
+        th = threading.Thread(target=sampler)
+        th.start()
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 6.0:
+            for _ in range(10):
+                run(lib, "gemm_dW")
+            torch.cuda.synchronize()
+            n += 10
+        el = time.perf_counter() - t0
+        stop.set()
+        th.join()
+        pw = [q for q, _ in samples[2:] if q is not None]
+        print(json.dumps({"kernel": "gemm_dW", "lib": name, "ms": round(el / n * 1e3, 3),
+                          "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": max(pw) if pw else None,
+                          "sclk_samples": [c for _, c in samples[2:8]]}), flush=True)
+
 fl = 2.0 * R * K * Nf
 for (which, name), ms in res.items():
     med = statistics.median(ms)
