@@ -65,6 +65,9 @@ def parse(argv=None):
     p.add_argument("--gather-chunk-nodes", type=int, default=None,
                    help="nodes per chunk of the chunked all-gather (default: ~8 GB chunk buffers; 0 = the literal "
                         "unchunked form, which materialises [T,N,F] twice per GPU)")
+    p.add_argument("--no-measure-traffic", action="store_true",
+                   help="do not measure roofline.traffic in this run (two short child runs of this script under "
+                        "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, N = 1 only); the committed PMC record is quoted instead")
     p.add_argument("--no-verify", action="store_true",
                    help="skip the verify leg (sampled rows of Y / dX and the all-reduced dW against the CPU oracle)")
     p.add_argument("--verify-rows", type=int, default=128, help="sampled rows per slice (Y) and sampled nodes (dX) per rank")
@@ -498,6 +501,61 @@ def free_device_memory():
     torch.cuda.empty_cache()
 
 
+def measure_traffic(args):
+    """roofline.traffic MEASURED IN THIS RUN (N = 1): two short child runs of this script — the same
+    workload, 1 warm-up + 2 steps, no other legs — under `rocprofv3 --pmc FETCH_SIZE --kernel-trace`
+    and `--pmc WRITE_SIZE --kernel-trace` (separate passes, kernel trace only: what the guide's
+    HBM / rocprofv3 section prescribes and what gpurun allows), reduced by tools/pmc_traffic.py's
+    reader: fabric-side bytes per forward launch of the dominant kernel = FETCH_SIZE x 2 (gfx950
+    counts 16-B-per-lane reads at half their bytes; the factor is re-calibrated in the same pass on
+    the band M-transform, whose bytes are known exactly) + WRITE_SIZE.  The children are ordinary
+    child processes of a parent that has already released its device memory.  Returns
+    (bytes_per_launch, source_record) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--nodes", str(args.nodes), "--slices-per-gpu", str(args.slices_per_gpu),
+              "--deg", str(args.deg), "--feat", str(args.feat), "--band", str(args.band), "--no-epochs", "--no-cpu-baseline",
+              "--no-verify", "--no-measure-traffic", "--deadline", "400"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    with tempfile.TemporaryDirectory(prefix="tmgcn_pmc_", dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.abspath(__file__)] + common
+            stage(f"traffic: {' '.join(cmd[:8])} … (child run)")
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            except subprocess.TimeoutExpired:
+                return None, f"the {counter} pass timed out"
+            if r.returncode != 0:
+                return None, f"the {counter} pass exited {r.returncode}: {(r.stderr or '')[-300:]}"
+            got[counter] = pmc_traffic.read_pass(d, counter)
+    fused_f = [v for k, v in got["FETCH_SIZE"].items() if "spmm_gemm_kernel" in k]
+    fused_w = [v for k, v in got["WRITE_SIZE"].items() if "spmm_gemm_kernel" in k]
+    band_f = [v for k, v in got["FETCH_SIZE"].items() if "mtransform_band_kernel" in k]
+    if not fused_f or not fused_w:
+        return None, "no spmm_gemm_kernel dispatch in the counter output"
+    pairs = list(zip(fused_f[0], fused_w[0]))                       # dispatches alternate forward / backward
+    fwd = max(pairs, key=lambda q: q[1])                            # forward also stores AX and Y
+    bwd = min(pairs, key=lambda q: q[1])
+    slab = args.slices_per_gpu * args.nodes * args.feat * 4
+    cal = round(slab / (band_f[0][0] * 1024), 4) if band_f and band_f[0] else None
+    total = int(fwd[0] * 1024 * 2.0 + fwd[1] * 1024)
+    return total, {"kind": "measured in this run", "how": "two child runs of bench.py (1 warm-up + 2 steps) under rocprofv3 --pmc FETCH_SIZE / "
+                   "--pmc WRITE_SIZE with --kernel-trace (separate passes); FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, KiB units",
+                   "fetch_size_kib_raw": fwd[0], "write_size_kib": fwd[1], "dispatches": len(pairs),
+                   "fetch_x2_calibration_on_band_mtransform": cal,
+                   "backward_launch_bytes": int(bwd[0] * 1024 * 2.0 + bwd[1] * 1024),
+                   "meaning": "fabric-side bytes between L2 and the Infinity Fabric, Infinity-Cache hits included: an upper bound on "
+                              "what HBM itself moved"}
+
+
 def traffic_record(N, F, Tl):
     """HBM-side traffic of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py);
     None when the passes were taken at another problem size."""
@@ -506,7 +564,7 @@ def traffic_record(N, F, Tl):
         rec = json.load(open(pmc))
         if rec.get("nodes") == N and rec.get("feat") == F and rec.get("slices_per_gpu") == Tl:
             return rec["spmm_hbm_bytes_per_launch"], {
-                "file": "profiles/pmc_traffic.json", "profile": rec.get("profile"),
+                "kind": "committed file", "file": "profiles/pmc_traffic.json", "profile": rec.get("profile"),
                 "derived_by": rec.get("derived_by", "tools/pmc_traffic.py"),
                 "meaning": "fabric-side bytes (L2 <-> Infinity Fabric: FETCH_SIZE x2 on gfx950 + WRITE_SIZE) from separate "
                            "rocprofv3 --pmc passes of this workload, NOT measured in this run; Infinity-Cache hits are "
@@ -652,9 +710,16 @@ def worker(args):
         # one launch per step at N = 1; the pipelined multi-GPU path launches slice by slice
         units_per_launch = res["nnz_rank"] * args.steps / sp["launches"]
         achieved = bytes_per_unit * units_per_launch / (sp["avg_ms"] * 1e-3) / 1e9
-        traffic, traffic_source = traffic_record(N, F, Tl)
-        if sp["launches"] != args.steps:
-            traffic, traffic_source = None, None
+        traffic, traffic_source = None, None
+        if world == 1 and not args.no_measure_traffic and sp["launches"] == args.steps:
+            traffic, traffic_source = measure_traffic(args)
+            if traffic is None:
+                stage(f"traffic: not measured ({traffic_source}); quoting the committed PMC record")
+                why, (traffic, traffic_source) = traffic_source, traffic_record(N, F, Tl)
+                if traffic_source is not None:
+                    traffic_source["not_measured_because"] = why
+        elif sp["launches"] == args.steps:
+            traffic, traffic_source = traffic_record(N, F, Tl)
         out = {
             "metric": "TM-GCN layer fwd+bwd throughput (edges x T)/s",
             "value": res["total_nnz"] * args.steps / elapsed,

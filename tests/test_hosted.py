@@ -1,10 +1,23 @@
 """hosted.DeviceResult mechanics that do not need a device (the cross-device behaviour is covered
 on the MI355X in test_gpu_experiment.py)."""
+import warnings
+
 import numpy as np
+import pytest
 import torch
 import torch.nn as nn
 
+from tmgcn_amd import hosted
 from tmgcn_amd.hosted import DeviceResult, _fused_cross_entropy
+
+
+@pytest.fixture(params=["documented guard", "public API only"], autouse=True)
+def scope(request):
+    """Every test runs twice: with torch._C.DisableTorchFunctionSubclass (the guard PyTorch's own
+    extension note uses) and with the module's flag scope, which needs public API only."""
+    hosted._FORCE_FLAG_SCOPE = request.param == "public API only"
+    yield
+    hosted._FORCE_FLAG_SCOPE = False
 
 
 def test_subclass_carries_through_the_scripts_operations_and_autograd():
@@ -41,3 +54,17 @@ def test_fused_cross_entropy_declines_what_the_kernel_does_not_cover():
     for kw in (dict(reduction="sum"), dict(label_smoothing=0.1), dict(ignore_index=1), dict(size_average=True)):
         assert _fused_cross_entropy(z, t, **kw) is None
     assert _fused_cross_entropy(z, t.float()) is None and _fused_cross_entropy(torch.randn(4, 9), t) is None
+
+
+def test_repeated_upload_warns_once_per_tensor_and_keeps_no_module_state():
+    """The count lives on the host tensor that is being uploaded; nothing process-wide."""
+    assert not any(n in vars(hosted) for n in ("_UPLOADS", "_warned"))
+    big = torch.zeros(300_000)                                              # 1.2 MB > the 1 MB threshold
+    small = torch.zeros(10)
+    with warnings.catch_warnings(record=True) as got:
+        warnings.simplefilter("always")
+        for _ in range(5):
+            hosted._note_upload(big)
+            hosted._note_upload(small)
+    assert len([w for w in got if issubclass(w.category, RuntimeWarning)]) == 1
+    assert big._tmgcn_uploads == 5 and not hasattr(small, "_tmgcn_uploads")
