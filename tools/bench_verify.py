@@ -92,9 +92,19 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
     input slice j, dy_slice(k) -> [N,F] of upstream-gradient slice k, a_slice(k) -> one-slice
     BatchedCSR of adjacency slice k — all REGENERATED from seeds, for any rank's data.
     Returns the `verify` record (errors are MAX over ranks); `ok` is the collective verdict."""
+    # all ranks of a node check at the same time on the same host cores: give each its share
+    # (libgomp reads OMP_NUM_THREADS when the oracle library is first loaded)
+    share = max(1, (os.cpu_count() or 1) // max(1, world))
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(share, 32)))
     from oracle import c_ref
     lib, cptr = c_ref.load(), c_ref.cptr
     t_start = time.perf_counter()
+    lap = {}
+
+    def mark(name):
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        lap[name] = round(time.perf_counter() - t_start - sum(lap.values()), 1)
     Tl, F = A.T, X.shape[-1]
     F1 = W.shape[1]
     M = torch.as_tensor(M64).double().contiguous()
@@ -136,6 +146,7 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
         worst = max(worst, _rel(Y[kk][ids[kk]], y_ref))
         fib[kk] = None
     errs["max_rel_err_Y"] = worst
+    mark("Y_and_regenerated_P1")
 
     # ------------------------------------------------------------------ dX
     if node_sharded_input:
@@ -168,6 +179,7 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
         errs["max_rel_err_dX"] = _rel(dX[:, loc.to(dev)], dX_ref)
     else:
         errs["max_rel_err_dX"] = _rel(dX[:, nodes], dX_ref[k0:k0 + Tl])
+    mark("dX")
 
     # ------------------------------------------------------------------ dW
     def allsum(t):
@@ -197,6 +209,8 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
     else:
         errs["max_rel_err_dW"] = None
 
+    mark("dW_fp64_and_identities")
+
     # ------------------------------------------------------------------ collective verdict
     keys = sorted(k for k, v in errs.items() if v is not None)
     vec = torch.tensor([errs[k] for k in keys], dtype=torch.float64, device=dev)
@@ -211,5 +225,6 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
                 if out.get("max_rel_err_dW") is not None else "skipped: not enough free memory for the fp64 [T/G,N,F] buffer",
                 "reference": "oracle/tmgcn_ref.c (ref_mtransform_rows, ref_spmm, ref_gemm, ref_mtransform) on inputs regenerated "
                              "from their seeds; errors are max|Δ|/max|ref|, MAX over ranks",
-                "seconds": round(time.perf_counter() - t_start, 1)})
+                "seconds": round(time.perf_counter() - t_start, 1), "seconds_by_part": lap,
+                "slices_regenerated": {"input_X": len(needed_j), "adjacency_and_dY": len(needed_k)}})
     return out
