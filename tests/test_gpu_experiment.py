@@ -176,8 +176,6 @@ def test_repeated_large_host_uploads_are_announced_once():
     epoch (the scripts' targets) it says so — once — instead of silently paying PCIe each time."""
     import warnings
     from tmgcn_amd import hosted
-    hosted._warned = False
-    hosted._UPLOADS.clear()
     out = torch.zeros(300_000, 2, device="cuda").as_subclass(hosted.DeviceResult)
     big = torch.ones(300_000, 2)                                     # 2.4 MB on the host
     small = torch.ones(2)
@@ -189,3 +187,4 @@ def test_repeated_large_host_uploads_are_announced_once():
     assert r.is_cuda
     mine = [w for w in seen if "uploaded each time" in str(w.message)]
     assert len(mine) == 1 and issubclass(mine[0].category, RuntimeWarning)
+    assert big._tmgcn_uploads == 6 and not hasattr(small, "_tmgcn_uploads")     # the count lives on the tensor, not in the module

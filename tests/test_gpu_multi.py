@@ -19,7 +19,9 @@ import torch.multiprocessing as mp
 NGPU = torch.cuda.device_count()          # counting devices does not initialise the GPU
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(NGPU < 2, reason=f"needs >= 2 GPUs for RCCL ranks on distinct devices (found {NGPU})")]
-WORLDS = [w for w in (2, 4, 8) if w <= NGPU]
+# world 2 and the largest power of two the node offers (each case starts fresh ranks and a fresh RCCL
+# communicator: ~10-15 s apiece, so the matrix is kept to what distinguishes code paths)
+WORLDS = sorted({2, max([w for w in (2, 4, 8) if w <= NGPU] or [2])})
 
 
 def _run(worker, world, args):
@@ -31,9 +33,13 @@ def _run(worker, world, args):
 
 
 @pytest.mark.parametrize("world", WORLDS)
-@pytest.mark.parametrize("exchange,F0,F1,pipeline", [("a2a", 16, 32, True), ("a2a", 16, 32, False), ("a2a", 6, 6, True),
-                                                      ("a2a", 5, 7, True), ("allgather", 16, 32, True)])
-@pytest.mark.parametrize("condensed,act", [(True, None), (False, "selu")])
+@pytest.mark.parametrize("exchange,F0,F1,pipeline,condensed,act", [
+    ("a2a", 16, 32, True, True, None),          # fused MFMA kernel, per-slice all-to-all pipelined beside it
+    ("a2a", 16, 32, False, False, "selu"),      # same kernels, exchange first; one weight per slice
+    ("a2a", 6, 6, True, False, "selu"),         # fused small-F kernel
+    ("a2a", 5, 7, True, True, None),            # widths without a fused kernel
+    ("allgather", 16, 32, True, True, None),    # node-chunked all-gather (+ literal form and ragged chunkings, bit for bit)
+    ("allgather", 16, 32, True, False, "selu")])
 def test_sharded_layer_over_rccl(world, exchange, F0, F1, pipeline, condensed, act):
     from test_gpu_dist2 import _worker
     _run(_worker, world, (exchange, F0, F1, condensed, act, pipeline))

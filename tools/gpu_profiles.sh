@@ -5,7 +5,7 @@ TAG=${1:-run}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-B="--no-cpu-baseline --no-epochs"
+B="--no-cpu-baseline --no-epochs --no-verify --no-measure-traffic"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- python3 bench.py --steps 10 --warmup 3 $B > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 $B > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 2 --warmup 1 $B > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
