@@ -638,10 +638,11 @@ def worker(args):
         return memory_plan(ex, Tl * world, world, n_nodes, F, F, Tl * n_nodes * (args.deg + 1),
                            gather_chunk_nodes=args.gather_chunk_nodes)
 
-    def fits(ex, n_nodes, extra_bytes=0):
+    def fits(ex, n_nodes):
         """Collective decision, BEFORE anything is allocated: does the plan of mode `ex` at n_nodes fit
-        on every rank (10 % headroom + the verify leg's fp64 buffer when asked for)?"""
-        need = plan_of(ex, n_nodes)["total"] + extra_bytes
+        on every rank with 10 % headroom?  (The verify leg sizes its own fp64 buffer against what is
+        free when it runs, and does without it otherwise.)"""
+        need = plan_of(ex, n_nodes)["total"]
         free_b, _total = torch.cuda.mem_get_info(dev)
         if args.single_device:
             free_b //= world                     # every rank of the emulation allocates on the same device

@@ -50,3 +50,46 @@ def test_single_rank_form_rejects_a_world_size_mismatch():
     env.update(RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def test_traffic_leg_reduces_the_counter_passes(tmp_path, monkeypatch):
+    """bench.measure_traffic: two child passes under `rocprofv3 --pmc …`, reduced to fabric-side bytes
+    per FORWARD launch of the dominant kernel (FETCH_SIZE x 2 + WRITE_SIZE, KiB).  Here a stand-in
+    `rocprofv3` on PATH writes the counter CSVs a real pass produces (values of profiles/pmc_traffic.json),
+    so the pairing of forward / backward dispatches, the unit handling and the in-pass calibration
+    are checked without a GPU; a failing pass must come back as (None, reason)."""
+    import stat
+    import bench
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    script = fake / "rocprofv3"
+    script.write_text('''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+counter, out = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+if os.environ.get("FAKE_ROCPROF_FAIL"):
+    sys.exit(7)
+os.makedirs(os.path.join(out, "host", "1"), exist_ok=True)
+rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value,Grid_Size"]
+fused = "void tmgcn::spmm_gemm_kernel<32, 4, 16>(tmgcn::FusedArgs)"
+band = "void tmgcn::mtransform_band_kernel<16, 4, 4, false>(tmgcn::MtArgs)"
+vals = {"FETCH_SIZE": {fused: [270883771.9, 271501397.5] * 3, band: [8001143.5, 8112556.4] * 3},
+        "WRITE_SIZE": {fused: [32031017.0, 16031017.2] * 3, band: [16000000.2] * 6}}[counter]
+i = 0
+for step in range(3):
+    for name in (band, fused, fused, band):
+        i += 1
+        rows.append(f'{i},"{name}",{counter},{vals[name].pop(0)},1024')
+open(os.path.join(out, "host", "1", "x_counter_collection.csv"), "w").write("\\n".join(rows) + "\\n")
+''')
+    script.chmod(script.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(fake) + os.pathsep + os.environ["PATH"])
+    args = bench.parse([])
+    total, src = bench.measure_traffic(args)
+    assert total == int(270883771.9 * 1024 * 2 + 32031017.0 * 1024)              # the forward launch (larger WRITE_SIZE)
+    assert src["kind"] == "measured in this run" and src["dispatches"] == 6
+    assert abs(src["fetch_x2_calibration_on_band_mtransform"] - 2.0) < 1e-3        # 16.384 GB read exactly / raw counter
+    assert src["backward_launch_bytes"] == int(271501397.5 * 1024 * 2 + 16031017.2 * 1024)
+    monkeypatch.setenv("FAKE_ROCPROF_FAIL", "1")
+    total, why = bench.measure_traffic(args)
+    assert total is None and "exited 7" in why

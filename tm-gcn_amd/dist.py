@@ -30,6 +30,7 @@ covered by world_size-2 CPU tests with the kernels substituted by the oracle.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -283,8 +284,11 @@ class _PipelinedCore(torch.autograd.Function):
     the fused P2+P3 kernel works through the slices that have already arrived (forward), and
     the slices the backward kernel has finished leave while it works on the next ones.
     One slice of S4 is ~6 ms of gather and ~2 GB of exchange, so after the first slice the
-    exchange is hidden behind compute.  On CPU tensors (gloo tests) the same code runs
-    without streams."""
+    exchange is hidden behind compute.  Consecutive one-slice launches alternate between two
+    compute streams (`compute_lanes`): the persistent kernel of slice k+1 becomes resident block by
+    block as the blocks of slice k run out of tiles, so the tail of one launch overlaps the head of
+    the next instead of draining the chip sixteen times per pass (measured at world size 1:
+    DESIGN.md §6).  On CPU tensors (gloo tests) the same code runs without streams."""
 
     @staticmethod
     def forward(ctx, send, W, layer, act):
@@ -312,15 +316,25 @@ class _PipelinedCore(torch.autograd.Function):
                     ev = torch.cuda.Event()
                     ev.record(comm)
                     evs.append(ev)
+            lanes = layer.compute_lanes(main)   # consecutive one-slice launches alternate between two streams
+            for s2 in lanes[1:]:
+                s2.wait_stream(main)            # W and the output allocations are ordered before the first launch there
         for kk in range(Tl):
+            Wk = W[kk:kk + 1] if per_slice_w else W
+            outs = (Y[kk:kk + 1], AX[kk:kk + 1] if need_w else None, pre[kk:kk + 1] if act_on else None)
             if use_streams:
-                main.wait_event(evs[kk])
+                lane = lanes[kk % len(lanes)]
+                lane.wait_event(evs[kk])
+                with torch.cuda.stream(lane):
+                    K.spmm_gemm(layer.A_views[kk], Xt[kk:kk + 1], Wk, act=act, want_ax=need_w, want_pre=act_on, out=outs,
+                                grid_reserve=layer.grid_reserve)
             else:
                 dist.all_to_all_single(Xt[kk].view(G, Nl, F), send[kk], group=layer.group)
-            Wk = W[kk:kk + 1] if per_slice_w else W
-            K.spmm_gemm(layer.A_views[kk], Xt[kk:kk + 1], Wk, act=act, want_ax=need_w, want_pre=act_on,
-                        out=(Y[kk:kk + 1], AX[kk:kk + 1] if need_w else None, pre[kk:kk + 1] if act_on else None),
-                        grid_reserve=layer.grid_reserve)
+                K.spmm_gemm(layer.A_views[kk], Xt[kk:kk + 1], Wk, act=act, want_ax=need_w, want_pre=act_on, out=outs,
+                            grid_reserve=layer.grid_reserve)
+        if use_streams:
+            for s2 in lanes[1:]:
+                main.wait_stream(s2)
         ctx.layer, ctx.act, ctx.shape = layer, (act if act_on else None), (Tl, G, Nl, F)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(W, AX if need_w else empty, pre if act_on else empty)
@@ -346,18 +360,28 @@ class _PipelinedCore(torch.autograd.Function):
                 main = torch.cuda.current_stream(dev)
                 comm = layer.comm_stream()
                 comm.wait_stream(main)  # dsend/dXt allocations and earlier work are ordered before the exchange
+                lanes = layer.compute_lanes(main)
+                for s2 in lanes[1:]:
+                    s2.wait_stream(main)    # dY (and its activation gradient) is complete
             for kk in range(Tl):
                 Wk = W[kk:kk + 1] if per_slice_w else W
-                K.spmm_gemm(layer.At_views[kk], dY[kk:kk + 1], Wk, trans_w=True, tag="spmm_gemm_T",
-                            out=(dXt[kk:kk + 1], None, None), grid_reserve=layer.grid_reserve)
                 if use_streams:
+                    lane = lanes[kk % len(lanes)]
+                    with torch.cuda.stream(lane):
+                        K.spmm_gemm(layer.At_views[kk], dY[kk:kk + 1], Wk, trans_w=True, tag="spmm_gemm_T",
+                                    out=(dXt[kk:kk + 1], None, None), grid_reserve=layer.grid_reserve)
                     ev = torch.cuda.Event()
-                    ev.record(main)
+                    ev.record(lane)
                     comm.wait_event(ev)
                     with torch.cuda.stream(comm):
                         dist.all_to_all_single(dsend[kk], dXt[kk].view(G, Nl, F), group=layer.group)
                 else:
+                    K.spmm_gemm(layer.At_views[kk], dY[kk:kk + 1], Wk, trans_w=True, tag="spmm_gemm_T",
+                                out=(dXt[kk:kk + 1], None, None), grid_reserve=layer.grid_reserve)
                     dist.all_to_all_single(dsend[kk], dXt[kk].view(G, Nl, F), group=layer.group)
+            if use_streams:
+                for s2 in lanes[1:]:
+                    main.wait_stream(s2)
         if ctx.needs_input_grad[1]:
             # dW does not depend on the exchange: it runs while the last slices are still leaving
             dW = K.gemm_dw(AX, dY, per_slice=per_slice_w)
@@ -401,6 +425,8 @@ class ShardedTMGCNLayer:
         # [T, Nc, F] chunk buffer stays near GATHER_CHUNK_BYTES; 0: the unchunked literal form)
         self.gather_chunk_nodes = gather_chunk_nodes
         self._gbufs = None
+        self._lane2 = None
+        self.pipeline_lanes = int(os.environ.get("TMGCN_PIPELINE_LANES", "2"))   # A/B knob; 2 = alternate two compute streams
         self._comm_stream = None
         self._views = None
         self.group = group
@@ -442,6 +468,15 @@ class ShardedTMGCNLayer:
                 self._gbufs[0].device != torch.device(device):
             self._gbufs = [torch.empty(need, dtype=dtype, device=device) for _ in range(2)]
         return self._gbufs
+
+    def compute_lanes(self, main):
+        """Streams the one-slice launches of the pipelined path alternate between: the caller's
+        stream and one more (`pipeline_lanes` = 1 keeps everything on the caller's stream)."""
+        if self.pipeline_lanes <= 1:
+            return [main]
+        if self._lane2 is None:
+            self._lane2 = torch.cuda.Stream(device=self.A.device)
+        return [main, self._lane2]
 
     def comm_stream(self):
         if self._comm_stream is None:

@@ -121,18 +121,21 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
         segs.append((sub, A.col[off].long(), A.val[off].cpu()))
     local_rows = M[k0:k0 + Tl]                                         # this rank's rows of M
     needed_j = torch.nonzero((local_rows != 0).any(0)).reshape(-1).tolist()
-    fib = [torch.zeros(T, int(s[0][-1]), F, dtype=torch.float32) for s in segs]
+    # fibres of the neighbour columns, only the input slices M actually mixes into this rank's
+    # output slices (band-M: Tl + b - 1 of T), in `needed_j` order
+    Tn = len(needed_j)
+    fib = [torch.zeros(Tn, int(s[0][-1]), F, dtype=torch.float32) for s in segs]
     want64 = fp64_dw
     if want64 and dev.type == "cuda":
         free_b, _ = torch.cuda.mem_get_info(dev)
         want64 = free_b > Tl * N * F * 8 + (16 << 30)
     Xt64 = torch.zeros(Tl, N, F, dtype=torch.float64, device=dev) if want64 else None
-    for j in needed_j:
+    for jj, j in enumerate(needed_j):
         Xj = x_slice(j)
         for kk in range(Tl):
             m = float(local_rows[kk, j])
             if m != 0.0:
-                fib[kk][j] = Xj[segs[kk][1]].cpu()
+                fib[kk][jj] = Xj[segs[kk][1]].cpu()
                 if Xt64 is not None:
                     Xt64[kk].add_(Xj.double(), alpha=m)
         del Xj
@@ -141,7 +144,9 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
         sub, _cols, val = segs[kk]
         nnz = int(sub[-1])
         xt = torch.empty(1, nnz, F, dtype=torch.float32)
-        lib.ref_mtransform_rows(cptr(M), T, 0, k0 + kk, 1, cptr(fib[kk]), cptr(xt), nnz * F)
+        Mrow = torch.zeros(Tn, Tn, dtype=torch.float64)             # row 0 = row k0+kk of M restricted to `needed_j`
+        Mrow[0] = local_rows[kk, needed_j]
+        lib.ref_mtransform_rows(cptr(Mrow), Tn, 0, 0, 1, cptr(fib[kk]), cptr(xt), nnz * F)
         y_ref = _oracle_rows(lib, cptr, sub, val, xt[0], Wc, False)
         worst = max(worst, _rel(Y[kk][ids[kk]], y_ref))
         fib[kk] = None
