@@ -55,7 +55,7 @@ def _worker(rank, world, port, exchange, condensed, act, F0, ret):
         # unsharded answer, computed redundantly on every rank
         dist.barrier()
         Yr, dXr, dWr = _reference_local(g, X, W, dY, act)
-        tol = 2e-5
+        tol = 1e-5
         def close(a, b, what):
             err = float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
             assert err <= tol, f"{what}: {err:.2e}"

@@ -70,7 +70,7 @@ def _worker(rank, world, port, name, ret):
         held = m.AtXt if kind != "kw" else m.AX
         assert held.shape[0] == sh.Tl
 
-        def close(a, b, what, tol=2e-5):
+        def close(a, b, what, tol=1e-5):
             a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
             err = float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
             assert err <= tol, f"{what}: {err:.2e}"

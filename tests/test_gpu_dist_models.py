@@ -87,9 +87,9 @@ def _worker(rank, world, port, name, ret, backend="gloo"):
                 loss.backward()
                 opt.step()
                 losses.append(float(loss.detach()))
-            close(torch.tensor(losses), d["losses"], "SGD loss trajectory", 1e-4)
+            close(torch.tensor(losses), d["losses"], "SGD loss trajectory", 1e-5)
             for n, q in m.named_parameters():
-                close(q.detach(), d[n + "_final"], "final " + n, 1e-4)
+                close(q.detach(), d[n + "_final"], "final " + n, 1e-5)
             for n, q in m.named_parameters():            # replicas stay bit-identical: same all-reduced gradients
                 mine = q.detach().cpu().contiguous()
                 others = [torch.empty_like(mine) for _ in range(world)]

@@ -55,21 +55,21 @@ def test_link_prediction_script_flow(no_layers):
         optimizer.step()
         losses.append(float(loss_train.detach()))
     pre = f"exp{no_layers}_"
-    assert_close(np.array(losses), g9[pre + "loss"], 1e-4, "loss trajectory")
+    assert_close(np.array(losses), g9[pre + "loss"], 1e-5, "loss trajectory")
 
     with torch.no_grad():
         output_train = gcn()
         output_val = gcn(Ct_val_2[:-1], X_val[:-1], e_val)
         output_test = gcn(Ct_test_2[:-1], X_test[:-1], e_test)
-        assert_close(output_train, g9[pre + "out_train"], 1e-4, "train logits")
-        assert_close(output_val, g9[pre + "out_val"], 1e-4, "val logits")
-        assert_close(output_test, g9[pre + "out_test"], 1e-4, "test logits")
+        assert_close(output_train, g9[pre + "out_train"], 1e-5, "train logits")
+        assert_close(output_val, g9[pre + "out_val"], 1e-5, "val logits")
+        assert_close(output_test, g9[pre + "out_test"], 1e-5, "test logits")
         loss_val = criterion(output_val[-K_val:], target_val[-K_val:])
         loss_test = criterion(output_test[-K_test:], target_test[-K_test:])
         for nm, got_l in (("loss_val", loss_val), ("loss_test", loss_test)):
             e = abs(float(got_l) - float(g9[pre + nm])) / abs(float(g9[pre + nm]))
-            record_tolerance(f"G9 {pre}{nm}", e, 1e-4, kind="relative")
-            assert e <= 1e-4, (nm, float(got_l), float(g9[pre + nm]))
+            record_tolerance(f"G9 {pre}{nm}", e, 1e-5, kind="relative")
+            assert e <= 1e-5, (nm, float(got_l), float(g9[pre + nm]))
 
         guess_val = torch.argmax(output_val, dim=1)
         f1_val = ehf.compute_f1(guess_val[-K_val:], target_val[-K_val:])
@@ -85,8 +85,8 @@ def test_link_prediction_script_flow(no_layers):
             ref = g9[pre + "mapmrr_" + name]
             # rank metrics move by 1/E-sized steps when two nearly equal scores swap
             for nm, got_m, want_m in (("MAP", MAP, ref[0]), ("MRR", MRR, ref[1])):
-                record_tolerance(f"G9 {pre}{name} {nm}", abs(float(got_m) - want_m), 2e-3, kind="absolute")
-            assert abs(float(MAP) - ref[0]) <= 2e-3 and abs(float(MRR) - ref[1]) <= 2e-3, (name, float(MAP), float(MRR), ref)
+                record_tolerance(f"G9 {pre}{name} {nm}", abs(float(got_m) - want_m), 5e-4, kind="absolute")
+            assert abs(float(MAP) - ref[0]) <= 5e-4 and abs(float(MRR) - ref[1]) <= 5e-4, (name, float(MAP), float(MRR), ref)
 
 
 def _small_model(cls_module, **attrs):
@@ -147,8 +147,8 @@ def test_device_result_takes_host_operands_the_way_the_scripts_use_them():
                            (nn.CrossEntropyLoss(label_smoothing=0.1), nn.CrossEntropyLoss(label_smoothing=0.1))):
         for tg in (target, tgt_ign):
             got, want = crit(out, tg), crit_ref(ref, tg)
-            record_tolerance(f"hosted criterion {crit}", abs(float(got) - float(want)) / abs(float(want)), 2e-5, kind="relative")
-            assert got.is_cuda and abs(float(got) - float(want)) <= 2e-5 * abs(float(want)), (crit, float(got), float(want))
+            record_tolerance(f"hosted criterion {crit}", abs(float(got) - float(want)) / abs(float(want)), 1e-5, kind="relative")
+            assert got.is_cuda and abs(float(got) - float(want)) <= 1e-5 * abs(float(want)), (crit, float(got), float(want))
 
     # metrics and bookkeeping idioms of the scripts
     guess = torch.argmax(out, dim=1)

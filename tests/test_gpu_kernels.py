@@ -65,9 +65,10 @@ def test_spmm_transpose_is_adjoint():
     csr = rand_csr(T, N, 6.0, seed=3).to(DEV)
     X = torch.randn(T, N, F, device=DEV)
     Yb = torch.randn(T, N, F, device=DEV)
-    lhs = (ops.kernels.spmm(csr, X) * Yb).sum()
-    rhs = (X * ops.kernels.spmm(csr.transpose(), Yb)).sum()
-    assert abs(float(lhs - rhs)) <= 1e-4 * max(1.0, abs(float(lhs)))
+    lhs = (ops.kernels.spmm(csr, X).double() * Yb.double()).sum()      # fp64 inner products: the identity, not fp32 summation noise
+    rhs = (X.double() * ops.kernels.spmm(csr.transpose(), Yb).double()).sum()
+    scale = float((ops.kernels.spmm(csr, X).double() * Yb.double()).abs().sum())
+    assert abs(float(lhs - rhs)) <= 1e-5 * scale
 
 
 def test_spmm_empty_matrix():
@@ -107,12 +108,12 @@ def test_mtransform_dense_and_inverse_roundtrip(T):
     Y = ops.kernels.mtransform(op, X.to(DEV))
     assert_close(Y, ref_mt(M, X), REL_TOL, "dense M")
     back = ops.kernels.mtransform(op.inverse(), Y)
-    assert_close(back, X, 1e-4, "Minv∘M = I")
+    assert_close(back, X, 1e-5, "Minv∘M = I")
     # the reference's band M (read_data.m:116-124) has a dense lower-triangular inverse
     Mb = torch.from_numpy(synth.band_M(T, 20, "matlab"))
     opb = ops.MOperator(Mb, DEV)
     back = ops.kernels.mtransform(opb.inverse(), ops.kernels.mtransform(opb, X.to(DEV)))
-    assert_close(back, X, 1e-4, "band Minv∘M = I")
+    assert_close(back, X, 1e-5, "band Minv∘M = I")
 
 
 @pytest.mark.parametrize("T,N,F,transpose", [(128, 301, 4, False), (128, 301, 4, True), (100, 77, 8, False),
