@@ -660,6 +660,14 @@ def worker(args):
                          f"are free (rank {rank}); nothing was allocated")
     res = run_layer(args, dist, dev, rank, world, args.exchange, N, args.steps, args.warmup, verify=not args.no_verify)
     free_device_memory()
+    if rank == 0:
+        # the headline measurement, on stderr, BEFORE the side legs (exchange comparison, epochs, CPU baseline):
+        # should one of those die, the record of the run's purpose survives in the log (the JSON line on
+        # stdout is printed once, at the end, as the driver's contract wants it)
+        stage("headline: " + json.dumps({"n_gpus": world, "exchange": args.exchange if res["collective"] else "none",
+                                         "ms_per_step": round(res["elapsed"] / args.steps * 1e3, 3),
+                                         "edge_slices_per_s": res["total_nnz"] * args.steps / res["elapsed"],
+                                         "verify_ok": (res["verify"] or {}).get("ok")}))
 
     compare = None
     if collective and not args.no_compare_exchange and res["collective"]:
