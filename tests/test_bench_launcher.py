@@ -93,3 +93,37 @@ open(os.path.join(out, "host", "1", "x_counter_collection.csv"), "w").write("\\n
     monkeypatch.setenv("FAKE_ROCPROF_FAIL", "1")
     total, why = bench.measure_traffic(args)
     assert total is None and "exited 7" in why
+
+
+def test_timeline_gaps_tool_unions_overlapping_kernels(tmp_path):
+    """tools/timeline_gaps.py on a synthetic kernel trace: two steps, kernels of two streams overlapping,
+    one idle gap — busy time is the UNION of the intervals, the gap is attributed to its neighbours."""
+    import json
+    import subprocess
+    import sys
+    rows = ['"Kind","Stream_Id","Kernel_Name","Start_Timestamp","End_Timestamp"']
+    t = 1_000_000
+
+    def k(name, start_us, dur_us, stream=0):
+        rows.append(f'"KERNEL_DISPATCH",{stream},"{name}",{t + start_us * 1000},{t + (start_us + dur_us) * 1000}')
+
+    for step in range(3):
+        o = step * 10_000
+        k("void tmgcn::mtransform_band_kernel<16, 4, 4, false>(tmgcn::MtArgs)", o + 0, 1000)
+        k("void tmgcn::spmm_gemm_kernel<32, 4, 16>(tmgcn::FusedArgs)", o + 1000, 3000)
+        k("rcclGenericKernel(x)", o + 2000, 1500, stream=1)                       # fully inside the previous kernel
+        k("void tmgcn::spmm_gemm_kernel<32, 4, 16>(tmgcn::FusedArgs)", o + 3800, 3000, stream=2)   # overlaps its tail
+        k("void tmgcn::mtransform_band_kernel<16, 4, 4, false>(tmgcn::MtArgs)", o + 7300, 1000)    # after a 500 us gap
+        k("tmgcn::gemm_dw_bf16x3_kernel(tmgcn::DwArgs)", o + 8300, 1700)
+    p = tmp_path / "x_kernel_trace.csv"
+    p.write_text("\n".join(rows) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "timeline_gaps.py"), str(p), "--steps", "2"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    steps = json.loads(r.stdout)
+    assert len(steps) == 2
+    s = steps[-1]
+    assert s["wall_ms"] == 10.0 and s["busy_union_ms"] == 9.5 and s["idle_ms"] == 0.5
+    assert s["kernel_ms_sum"] == 11.2                                             # 1 + 3 + 1.5 + 3 + 1 + 1.7: overlaps counted twice
+    assert s["largest_gaps_ms"][0] == {"ms": 0.5, "after": "spmm_gemm_kernel", "before": "mtransform_band_kernel"}
+    assert s["by_kernel"]["spmm_gemm_kernel"] == {"launches": 2, "ms": 6.0}
