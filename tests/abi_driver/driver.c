@@ -198,9 +198,28 @@ int main(void) {
   /* the backward pair as ONE fused launch: A^T (dY W^T) = (A^T dY) W^T */
   if (tmgcn_spmm_gemm_supported(NF, F))
     ABI(tmgcn_spmm_gemm_f32(d_trowptr, d_tcol, d_tval, d_dY, R, N, NF, dWt, F, 1, 0, 0, TMGCN_ACT_NONE, d_dXt2, NULL, NULL, 0, st));
+  /* ABI 3: the column-window form — P1 in two unequal column chunks written into a second buffer must
+   * reproduce the one-shot result (the consumer of the node-chunked all-gather) */
+  float* dXt_w = NULL;
+  HIP(hipMalloc((void**)&dXt_w, R * F * 4));
+  HIP(hipMemsetAsync(dXt_w, 0xff, R * F * 4, st));
+  {
+    const int64_t C = (int64_t)N * F, c_split = (int64_t)(N / 3) * F;
+    ABI(tmgcn_mtransform_ld_f32(dM, T, T, 0, 0, 0, T, T, BAND - 1, 0, dX_in, C, dXt_w, C, c_split, 0, 0, st));
+    ABI(tmgcn_mtransform_ld_f32(dM, T, T, 0, 0, 0, T, T, BAND - 1, 0, dX_in + c_split, C, dXt_w + c_split, C, C - c_split, 0, 0, st));
+  }
   HIP(hipStreamSynchronize(st));
 
   compare("M-transform", from_dev(dXt, R * F), Xt_r, R * F);
+  {
+    float* whole = from_dev(dXt, R * F);
+    float* win = from_dev(dXt_w, R * F);
+    if (memcmp(whole, win, (size_t)R * F * 4) != 0) {
+      fprintf(stderr, "column-window M-transform differs from the one-shot product\n");
+      return 1;
+    }
+    printf("%-28s bit-equal to the one-shot product\n", "M-transform, column windows");
+  }
   compare("batched CSR SpMM", from_dev(dAX, R * F), AX_r, R * F);
   compare("GEMM", from_dev(dYo, R * NF), Y_r, R * NF);
   compare("fused SpMM+GEMM: Y", from_dev(dYf, R * NF), Y_r, R * NF);
