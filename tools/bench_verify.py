@@ -192,16 +192,24 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
             dist.all_reduce(t)
         return t
 
-    dots = torch.zeros(3, dtype=torch.float64, device=dev)           # <Y,dY>, <X,dX>, (unused)
+    # adjoint identities <Y,dY> = <W,dW> = <X,dX>, summed over the ranks.  dY is random-sign, so the
+    # inner products themselves are small against the norms of their factors (cancellation): the
+    # differences are measured against ||W||·||dW|| and ||X||·||dX|| (what an error of relative size
+    # eps in dW / dX can move them by), not against the inner product.
+    dots = torch.zeros(4, dtype=torch.float64, device=dev)           # <Y,dY>, <X,dX>, ||X||^2, ||dX||^2
     for kk in range(Tl):
         dots[0] += (Y[kk].double() * dY[kk].double()).sum()
     for j in range(X.shape[0]):
-        dots[1] += (X[j].detach().double() * dX[j].double()).sum()
+        xj, dxj = X[j].detach().double(), dX[j].double()
+        dots[1] += (xj * dxj).sum()
+        dots[2] += (xj * xj).sum()
+        dots[3] += (dxj * dxj).sum()
     dots = allsum(dots)
     ydy, xdx = float(dots[0]), float(dots[1])
-    wdw = float((W.detach().double() * dW.double()).sum())
-    errs["identity_YdY_vs_WdW"] = abs(ydy - wdw) / max(abs(ydy), 1e-30)
-    errs["identity_YdY_vs_XdX"] = abs(ydy - xdx) / max(abs(ydy), 1e-30)
+    Wd, dWd = W.detach().double(), dW.double()
+    wdw = float((Wd * dWd).sum())
+    errs["identity_YdY_vs_WdW"] = abs(ydy - wdw) / max(float(Wd.norm() * dWd.norm()), 1e-300)
+    errs["identity_YdY_vs_XdX"] = abs(ydy - xdx) / max(float(dots[2].sqrt() * dots[3].sqrt()), 1e-300)
     if Xt64 is not None:
         P = torch.zeros(F, F1, dtype=torch.float64, device=dev)
         for kk in range(Tl):
