@@ -79,6 +79,8 @@ def parse(argv=None):
                    help="diagnostic: all ranks share cuda:0 (needs --backend gloo; RCCL refuses it)")
     p.add_argument("--grid-reserve", type=int, default=None,
                    help="block slots the fused kernel leaves free for RCCL's kernels (default: the layer's choice)")
+    p.add_argument("--cu-reserve", type=int, default=None,
+                   help="CUs the pipelined path's compute streams leave free for RCCL's kernels (CU-masked streams; default: the layer's choice)")
     p.add_argument("--force-collectives", action="store_true",
                    help="run the exchange (RCCL) code path even at --gpus 1 (diagnostic)")
     p.add_argument("--cpu-nodes", type=int, default=250_000, help="N of the repeated CPU-baseline sample")
@@ -399,7 +401,7 @@ def build_problem(args, dev, rank, world, exchange, N, kernels_ok=True):
     M = synth.band_M(T, args.band, "matlab")
     layer = ShardedTMGCNLayer(A, M, T, group=None, exchange=exchange, fuse=False if args.no_fuse else None,
                               pipeline=not args.no_pipeline, force_collectives=args.force_collectives,
-                              grid_reserve=args.grid_reserve, gather_chunk_nodes=args.gather_chunk_nodes)
+                              grid_reserve=args.grid_reserve, gather_chunk_nodes=args.gather_chunk_nodes, cu_reserve=args.cu_reserve)
     shape = layer.input_shape(F)
     node_sharded = layer.collective and exchange == "a2a"
     if node_sharded:
@@ -489,7 +491,7 @@ def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_tim
         stage(f"layer[{exchange}, N={N}]: verify {'ok' if ver['ok'] else 'FAILED'} in {ver['seconds']} s: "
               f"Y {ver['max_rel_err_Y']:.2e} dX {ver['max_rel_err_dX']:.2e} dW {ver['max_rel_err_dW']}")
     return {"elapsed": elapsed, "kt": kt, "nnz_rank": A.nnz, "rows_rank": A.n_rows, "total_nnz": total_nnz,
-            "collective": layer.collective, "grid_reserve": layer.grid_reserve, "T": pb["T"],
+            "collective": layer.collective, "grid_reserve": layer.grid_reserve, "cu_reserve": layer.cu_reserve, "T": pb["T"],
             "gather_chunks": len(layer.gather_chunks(F)) if (layer.collective and exchange == "allgather"
                                                                and layer.gather_chunk_nodes != 0) else None,
             "peak_gb": peak_gb, "verify": ver}
@@ -740,6 +742,7 @@ def worker(args):
             "config": {"workload": f"S4 TM-GCN layer fwd+bwd: {Tl} slices/GPU (T={res['T']}), N={N}, "
                                    f"deg={args.deg}+self, F={F}->{F}, band-M b={args.band}, fp32",
                        "exchange": args.exchange if res["collective"] else "none", "grid_reserve": res["grid_reserve"],
+                       "cu_reserve": res["cu_reserve"],
                        "edge_slices_per_step": res["total_nnz"]},
             "roofline": {"kernel": "spmm_gemm_kernel (forward P2 + fused P3)" if dom == "spmm_gemm" else "spmm_vec4_kernel (forward P2)",
                          "bound": "hbm", "achieved": achieved,

@@ -56,6 +56,45 @@ def test_world1_rccl_paths_match_unsharded(pg, exchange, pipeline, F0, chunk, co
         assert_close(a, b, REL_TOL, f"{exchange} pipeline={pipeline} {what}")
 
 
+def test_cu_masked_streams_run_the_pipelined_path(pg):
+    """The pipelined a2a path on CU-masked compute streams (what every real multi-GPU run uses: 32 CUs
+    left to RCCL's kernels): same bits as on ordinary streams, and the stream really is a distinct,
+    usable HIP stream."""
+    from tmgcn_amd.dist import cu_masked_stream
+    T, N, F0, F1 = 6, 120, 16, 32
+    g = synth.dynamic_graph(T, N, edges_per_slice=300, seed=2, no_diag=4, F0=F0)
+    A = BatchedCSR.from_scipy_list(g.Ct, device="cuda")
+    gen = torch.Generator().manual_seed(4)
+    X0 = torch.from_numpy(g.X).float().cuda()
+    W0 = (torch.randn(F0, F1, generator=gen) * 0.3).cuda()
+    dY = torch.randn(T, N, F1, generator=gen).cuda()
+    res = []
+    for cu in (0, 32):
+        layer = ShardedTMGCNLayer(A, g.M, T, exchange="a2a", force_collectives=True, cu_reserve=cu)
+        assert layer.cu_reserve == cu
+        X, W = X0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+        for _ in range(2):
+            X.grad = W.grad = None
+            Y = layer(X, W, act="relu")
+            Y.backward(dY)
+        torch.cuda.synchronize()
+        if cu:
+            lanes = layer.compute_lanes(torch.cuda.current_stream())
+            assert len(lanes) == 2 and all(s.cuda_stream != torch.cuda.current_stream().cuda_stream for s in lanes)
+        res.append((Y.detach(), X.grad, W.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    s = cu_masked_stream("cuda", 250)                    # nearly everything masked away still runs (6 CUs)
+    with torch.cuda.stream(s):
+        z = torch.arange(1 << 20, device="cuda").float().sum()
+    s.synchronize()
+    assert float(z) == float(sum(range(1 << 20)))
+    # the multi-GPU defaults: CU mask on, slot reserve off
+    import inspect
+    src = inspect.getsource(ShardedTMGCNLayer.__init__)
+    assert '"32" if real_exchange else "0"' in src and "grid_reserve = 0" in src
+
+
 MODEL_CASES = {
     "gcn2_twice_selu": ("gcn2", dict(condensed_W=True, use_Minv=False, apply_M_twice=True, nonlin2="selu")),
     "gcn2_three_relu_per_slice_W": ("gcn2", dict(condensed_W=False, use_Minv=False, apply_M_twice=True,

@@ -103,6 +103,35 @@ def memory_plan(exchange: str, T: int, G: int, N: int, F: int, F1: int, nnz_rank
     return plan
 
 
+def cu_masked_stream(device, cus_free: int):
+    """A HIP stream whose kernels may run on all CUs of `device` but the last `cus_free`
+    (hipExtStreamCreateWithCUMask), as a torch stream.  The pipelined sharded layer launches its
+    persistent kernels on such streams so that RCCL's kernels — 256-thread workgroups of 132 VGPRs
+    and 20 KB of LDS each (rocprofv3, RCCL 2.26): one does NOT fit beside three 128-VGPR blocks of
+    the fused kernel on a CU, so leaving a block slot per CU free gives them nothing — always find
+    whole CUs to become resident on.  The gather is bound by requests in flight, not by CUs: giving
+    up 16 of 256 CUs costs it about 1 %."""
+    import ctypes as C
+    device = torch.device(device)
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    cus_free = max(0, min(int(cus_free), n_cu - 1))
+    words = (n_cu + 31) // 32
+    mask = [0xFFFFFFFF] * words
+    if n_cu % 32:
+        mask[-1] = (1 << (n_cu % 32)) - 1
+    for b in range(n_cu - cus_free, n_cu):
+        mask[b // 32] &= ~(1 << (b % 32))
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+    hip.hipExtStreamCreateWithCUMask.restype = C.c_int
+    handle = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(handle), words, (C.c_uint32 * words)(*mask))
+    if rc != 0 or not handle.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed (status {rc})")
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
 def _world(group):
     if not dist.is_available() or not dist.is_initialized():
         return 0, 1
@@ -317,8 +346,9 @@ class _PipelinedCore(torch.autograd.Function):
                     ev.record(comm)
                     evs.append(ev)
             lanes = layer.compute_lanes(main)   # consecutive one-slice launches alternate between two streams
-            for s2 in lanes[1:]:
-                s2.wait_stream(main)            # W and the output allocations are ordered before the first launch there
+            for s2 in lanes:
+                if s2 is not main:
+                    s2.wait_stream(main)        # W and the output allocations are ordered before the first launch there
         for kk in range(Tl):
             Wk = W[kk:kk + 1] if per_slice_w else W
             outs = (Y[kk:kk + 1], AX[kk:kk + 1] if need_w else None, pre[kk:kk + 1] if act_on else None)
@@ -333,8 +363,9 @@ class _PipelinedCore(torch.autograd.Function):
                 K.spmm_gemm(layer.A_views[kk], Xt[kk:kk + 1], Wk, act=act, want_ax=need_w, want_pre=act_on, out=outs,
                             grid_reserve=layer.grid_reserve)
         if use_streams:
-            for s2 in lanes[1:]:
-                main.wait_stream(s2)
+            for s2 in lanes:
+                if s2 is not main:
+                    main.wait_stream(s2)
         ctx.layer, ctx.act, ctx.shape = layer, (act if act_on else None), (Tl, G, Nl, F)
         empty = torch.empty(0, device=dev)
         ctx.save_for_backward(W, AX if need_w else empty, pre if act_on else empty)
@@ -361,8 +392,9 @@ class _PipelinedCore(torch.autograd.Function):
                 comm = layer.comm_stream()
                 comm.wait_stream(main)  # dsend/dXt allocations and earlier work are ordered before the exchange
                 lanes = layer.compute_lanes(main)
-                for s2 in lanes[1:]:
-                    s2.wait_stream(main)    # dY (and its activation gradient) is complete
+                for s2 in lanes:
+                    if s2 is not main:
+                        s2.wait_stream(main)    # dY (and its activation gradient) is complete
             for kk in range(Tl):
                 Wk = W[kk:kk + 1] if per_slice_w else W
                 if use_streams:
@@ -380,8 +412,9 @@ class _PipelinedCore(torch.autograd.Function):
                                 out=(dXt[kk:kk + 1], None, None), grid_reserve=layer.grid_reserve)
                     dist.all_to_all_single(dsend[kk], dXt[kk].view(G, Nl, F), group=layer.group)
             if use_streams:
-                for s2 in lanes[1:]:
-                    main.wait_stream(s2)
+                for s2 in lanes:
+                    if s2 is not main:
+                        main.wait_stream(s2)
         if ctx.needs_input_grad[1]:
             # dW does not depend on the exchange: it runs while the last slices are still leaving
             dW = K.gemm_dw(AX, dY, per_slice=per_slice_w)
@@ -406,7 +439,7 @@ class ShardedTMGCNLayer:
     def __init__(self, A_local: BatchedCSR, M, T: int, group=None, exchange: str = "a2a",
                  apply_m: bool = True, fuse: Optional[bool] = None, pipeline: bool = True,
                  force_collectives: bool = False, local_only: bool = False, grid_reserve: Optional[int] = None,
-                 gather_chunk_nodes: Optional[int] = None):
+                 gather_chunk_nodes: Optional[int] = None, cu_reserve: Optional[int] = None):
         # local_only: ignore any initialised process group (an unsharded layer inside a
         # distributed job, e.g. to cross-check a sharded result)
         self.rank, self.G = (0, 1) if local_only else _world(group)
@@ -414,17 +447,30 @@ class ShardedTMGCNLayer:
         # a single GPU; needs an initialised process group)
         self.collective = self.G > 1 or (force_collectives and dist.is_initialized())
         self.pipeline = pipeline
-        # RCCL's exchange kernels run on the side stream while the persistent fused kernel works;
-        # they can only become resident if that kernel does not hold every block slot.  One slot
-        # per CU (256 blocks; costs ~4 % of the gather with dynamic tile scheduling, measured at
-        # world size 1) is left free whenever a real exchange runs beside it.
+        # RCCL's exchange kernels run on the side stream while the persistent fused kernel works; they
+        # can only become resident if that kernel does not hold the whole chip.  Two mechanisms:
+        #   cu_reserve    the one-slice launches go to CU-MASKED streams that leave that many CUs
+        #                 alone (hipExtStreamCreateWithCUMask).  Default 32 whenever a real exchange
+        #                 runs beside the kernel: measured at world size 1, 16 / 32 CUs cost the gather
+        #                 nothing measurable (209.9 / 212.1 vs 211.6 ms per step), 64 cost 7.5 %.
+        #   grid_reserve  block slots the persistent grid leaves free (a per-launch argument of the
+        #                 C-ABI).  Round 2's default of one slot per CU is now 0: an RCCL workgroup
+        #                 (256 threads, 132 VGPRs, 20 KB LDS: rocprofv3) does not fit beside three
+        #                 128-VGPR blocks of the fused kernel on a CU (3 x 128 + 136 > 512), so the
+        #                 free slot could not host it, and it cost 8 % at world size 1
+        #                 (profiles/r3i_cu_mask_rccl_world1.txt).
+        real_exchange = self.G > 1 and pipeline and exchange == "a2a"
         if grid_reserve is None:
-            grid_reserve = 256 if (self.G > 1 and pipeline and exchange == "a2a") else 0
+            grid_reserve = 0
         self.grid_reserve = int(grid_reserve)   # passed with every fused launch of THIS layer; nothing process-wide
+        if cu_reserve is None:
+            cu_reserve = int(os.environ.get("TMGCN_CU_RESERVE", "32" if real_exchange else "0"))
+        self.cu_reserve = int(cu_reserve)
         # "allgather" mode: nodes per chunk of the chunked gather (None: sized so that one
         # [T, Nc, F] chunk buffer stays near GATHER_CHUNK_BYTES; 0: the unchunked literal form)
         self.gather_chunk_nodes = gather_chunk_nodes
         self._gbufs = None
+        self._lanes = None
         self._lane2 = None
         self.pipeline_lanes = int(os.environ.get("TMGCN_PIPELINE_LANES", "2"))   # A/B knob; 2 = alternate two compute streams
         self._comm_stream = None
@@ -472,6 +518,10 @@ class ShardedTMGCNLayer:
     def compute_lanes(self, main):
         """Streams the one-slice launches of the pipelined path alternate between: the caller's
         stream and one more (`pipeline_lanes` = 1 keeps everything on the caller's stream)."""
+        if self.cu_reserve > 0:              # CU-masked streams (never the caller's own stream)
+            if self._lanes is None:
+                self._lanes = [cu_masked_stream(self.A.device, self.cu_reserve) for _ in range(max(1, self.pipeline_lanes))]
+            return self._lanes
         if self.pipeline_lanes <= 1:
             return [main]
         if self._lane2 is None:
