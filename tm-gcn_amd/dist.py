@@ -520,7 +520,16 @@ class ShardedTMGCNLayer:
         stream and one more (`pipeline_lanes` = 1 keeps everything on the caller's stream)."""
         if self.cu_reserve > 0:              # CU-masked streams (never the caller's own stream)
             if self._lanes is None:
-                self._lanes = [cu_masked_stream(self.A.device, self.cu_reserve) for _ in range(max(1, self.pipeline_lanes))]
+                try:
+                    self._lanes = [cu_masked_stream(self.A.device, self.cu_reserve) for _ in range(max(1, self.pipeline_lanes))]
+                except (RuntimeError, OSError, AttributeError) as e:
+                    # a performance device, not a correctness one: without it the exchange merely overlaps
+                    # less.  The choice is local to this rank (no collective depends on it).
+                    import warnings
+                    warnings.warn(f"tmgcn_amd: CU-masked streams are not available ({e}); the pipelined exchange runs on "
+                                  "ordinary streams", RuntimeWarning)
+                    self.cu_reserve = 0
+                    return self.compute_lanes(main)
             return self._lanes
         if self.pipeline_lanes <= 1:
             return [main]
