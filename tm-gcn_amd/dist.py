@@ -103,6 +103,18 @@ def memory_plan(exchange: str, T: int, G: int, N: int, F: int, F1: int, nnz_rank
     return plan
 
 
+def _loaded_hip_runtime() -> str:
+    """Path of the HIP runtime THIS process already uses (torch ships its own copy: a stream must be
+    created by the runtime that will launch on it, not by another libamdhip64 found on the search path)."""
+    try:
+        for line in open("/proc/self/maps"):
+            if "libamdhip64" in line:
+                return line.split()[-1]
+    except OSError:
+        pass
+    return "libamdhip64.so"
+
+
 def cu_masked_stream(device, cus_free: int):
     """A HIP stream whose kernels may run on all CUs of `device` but the last `cus_free`
     (hipExtStreamCreateWithCUMask), as a torch stream.  The pipelined sharded layer launches its
@@ -121,7 +133,7 @@ def cu_masked_stream(device, cus_free: int):
         mask[-1] = (1 << (n_cu % 32)) - 1
     for b in range(n_cu - cus_free, n_cu):
         mask[b // 32] &= ~(1 << (b % 32))
-    hip = C.CDLL("libamdhip64.so")
+    hip = C.CDLL(_loaded_hip_runtime())
     hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
     hip.hipExtStreamCreateWithCUMask.restype = C.c_int
     handle = C.c_void_p()
