@@ -52,3 +52,27 @@ def test_sharded_models_over_rccl(world, name):
     from test_gpu_dist_models import CASES, _worker
     assert name in CASES
     _run(_worker, world, (name,))
+
+
+@pytest.mark.parametrize("world", WORLDS)
+@pytest.mark.parametrize("exchange", ["a2a", "allgather"])
+def test_bench_over_rccl_verifies_itself(world, exchange, tmp_path):
+    """bench.py as the driver runs it (self-launched ranks, RCCL, one GPU each) at a reduced N: rc 0, the
+    JSON line reports the world size RCCL itself counted, and the verify leg accepted the sharded step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from _util import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--exchange", exchange,
+                        "--nodes", "200000", "--steps", "2", "--warmup", "1", "--gather-chunk-nodes", "60000",
+                        "--no-compare-exchange", "--deadline", "600"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    assert line["n_gpus"] == world and line["ranks"]["rccl_ranks"] == world
+    assert len({d["pci_bus_id"] for d in line["ranks"]["devices"]}) == world          # distinct devices
+    assert line["verify"]["ok"], line["verify"]
+    assert line["config"]["exchange"] == exchange
+    if exchange == "allgather":
+        assert line["config"]["gather_chunks"] == 4
