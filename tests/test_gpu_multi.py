@@ -71,7 +71,7 @@ def test_bench_over_rccl_verifies_itself(world, exchange, tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads(r.stdout.strip().split("\n")[-1])
     assert line["n_gpus"] == world and line["ranks"]["rccl_ranks"] == world
-    assert len({d["pci_bus_id"] for d in line["ranks"]["devices"]}) == world          # distinct devices
+    assert len({(d["pci_bus_id"], d["uuid"], d["device"]) for d in line["ranks"]["devices"]}) == world   # distinct devices
     assert line["verify"]["ok"], line["verify"]
     assert line["config"]["exchange"] == exchange
     if exchange == "allgather":
