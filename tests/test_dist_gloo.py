@@ -161,3 +161,71 @@ def test_memory_plan_of_the_headline_config():
     assert memory_plan("none", 16, 1, N, F, F, nnz)["exchange"] == 0
     # equal-sized chunks, never more than the target, never more than N
     assert chunk_nodes_for(8, 30, 4) == 30 and chunk_nodes_for(128, 2_000_000, 128, target=1 << 30) * 128 * 128 * 4 <= 1 << 30
+
+
+def _fuzz_worker(rank, world, port, n_cases, ret):
+    try:
+        _setup(rank, world, port)
+        import numpy as np
+        from tmgcn_amd import synth
+        from tmgcn_amd.csr import BatchedCSR
+        from tmgcn_amd.dist import ShardedTMGCNLayer, even_bounds
+        rng = np.random.default_rng(1234)                       # the same stream on every rank: same cases
+        for case in range(n_cases):
+            Tl = int(rng.integers(1, 4))
+            T = Tl * world
+            N = int(rng.integers(world, 6)) * world             # divisible by the world size (a2a)
+            F0, F1 = int(rng.choice([1, 3, 4, 8])), int(rng.choice([1, 2, 5]))
+            b = int(rng.integers(1, T + 1))
+            dense_m = bool(rng.integers(0, 2))
+            chunk = int(rng.integers(1, N + 1))
+            g = synth.dynamic_graph(T, N, edges_per_slice=3 * N, seed=int(rng.integers(1 << 30)), no_diag=b, F0=F0)
+            M = g.M
+            if dense_m:                                          # a dense lower-triangular mixing matrix (the Minv shape)
+                M = np.tril(rng.standard_normal((T, T))) + 2.0 * np.eye(T)
+            gen = torch.Generator().manual_seed(case)
+            X = torch.from_numpy(g.X).float()
+            W = torch.randn(F0, F1, generator=gen)
+            dY = torch.randn(T, N, F1, generator=gen)
+            k0, k1 = even_bounds(T, world)[rank]
+            n0, n1 = even_bounds(N, world)[rank]
+            A_local = BatchedCSR.from_scipy_list(g.Ct).slices(k0, k1)
+            g.M = M
+            Yr, dXr, dWr = _reference_local(g, X, W, dY, None)
+            outs = {}
+            for name, kw, xin in (("a2a", dict(exchange="a2a"), X[:, n0:n1]),
+                                  ("literal", dict(exchange="allgather", gather_chunk_nodes=0), X[k0:k1]),
+                                  ("chunked", dict(exchange="allgather", gather_chunk_nodes=chunk), X[k0:k1])):
+                layer = ShardedTMGCNLayer(A_local, M, T, group=None, **kw)
+                Xi = xin.contiguous().clone().requires_grad_(True)
+                Wi = W.clone().requires_grad_(True)
+                Y = layer(Xi, Wi)
+                Y.backward(dY[k0:k1].contiguous())
+                outs[name] = (Y.detach(), Xi.grad, Wi.grad)
+                what = f"case {case} (T={T} N={N} F={F0}->{F1} b={b} dense={dense_m} chunk={chunk}) {name}"
+                for got, ref, q in ((Y.detach(), Yr[k0:k1], "Y"), (Xi.grad, dXr[:, n0:n1] if name == "a2a" else dXr[k0:k1], "dX"),
+                                    (Wi.grad, dWr, "dW")):
+                    err = float((got.double() - ref).abs().max() / max(float(ref.abs().max()), 1e-30))
+                    assert err <= 1e-5, f"{what} {q}: {err:.2e}"
+            for a, c in zip(outs["literal"], outs["chunked"]):
+                assert torch.equal(a, c), f"case {case}: chunked all-gather differs from the literal form (chunk={chunk})"
+        dist.barrier()
+        ret[rank] = "ok"
+    except Exception as e:
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_layer_fuzz_shapes_bands_and_chunkings(world):
+    """Seeded random cases (slices per rank, nodes, widths, band width or a dense triangular M, chunk
+    size) through all three exchange forms: each reproduces the unsharded fp64 layer — forward, dX, dW —
+    and the node-chunked all-gather reproduces the literal one bit for bit."""
+    from _util import free_port
+    ret = mp.Manager().dict()
+    mp.spawn(_fuzz_worker, args=(world, free_port(), 12, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", f"rank {r}:\n{ret.get(r)}"
