@@ -127,6 +127,47 @@ def test_mtransform_random_shapes_misaligned(seed):
         assert max_rel_err(ops.kernels.mtransform(op, Xd, transpose=True), ref_t) <= REL_TOL, ("Mt", T, N, F, b, dense, k)
 
 
+@pytest.mark.parametrize("seed", range(30))
+def test_mtransform_column_windows_random_shapes_misaligned(seed):
+    """tmgcn_mtransform_ld_f32 under random shapes: a random split of the columns into windows, a random
+    row window of a band or dense M, grouped row storage on either side, operands that start 1..3
+    floats into their allocation — every window written must carry the bits of the one-shot product
+    (same kernel, same arithmetic per element), forward and adjoint; columns outside stay untouched."""
+    rng = np.random.default_rng(900 + seed)
+    G = int(rng.choice([1, 2, 4]))
+    Tl = int(rng.integers(1, 9))
+    T = G * Tl
+    N, F = int(rng.integers(2, 50)), int(rng.choice([1, 2, 3, 4, 8, 16]))
+    b = int(rng.integers(1, T + 1))
+    dense = bool(rng.integers(2))
+    M = torch.tril(torch.randn(T, T, generator=torch.Generator().manual_seed(seed), dtype=torch.float64))
+    if not dense:
+        M = M - torch.tril(M, -b)
+    op = ops.MOperator(M, DEV)
+    k0 = Tl * int(rng.integers(0, G))
+    K = ops.kernels
+    X = torch.randn(T, N, F, generator=torch.Generator().manual_seed(seed + 1))
+    dY = torch.randn(Tl, N, F, generator=torch.Generator().manual_seed(seed + 2))
+    pos = torch.tensor([(k % Tl) * (T // Tl) + k // Tl for k in range(T)], device=DEV)   # grouped storage, group = Tl rows
+    cuts = sorted(set([0, N] + [int(c) for c in rng.integers(1, N, size=int(rng.integers(0, 4)))]))
+    for k in (0, int(rng.integers(1, 4))):
+        Xd, dYd = off(X, k), off(dY, k)
+        whole = K.mtransform(op, Xd, row_off=k0, col_off=0, T_out=Tl)
+        whole_T = K.mtransform(op, dYd, transpose=True, row_off=0, col_off=k0, T_out=T)
+        assert max_rel_err(whole, torch.einsum("kj,jnf->knf", M[k0:k0 + Tl], X.double())) <= REL_TOL
+        Xg = torch.empty_like(Xd)
+        Xg[pos] = Xd
+        out = off(torch.full((Tl, N, F), 7.0), k)
+        out_T = torch.full((T, N, F), 7.0, device=DEV)
+        for c0, c1 in zip(cuts[:-1], cuts[1:]):
+            K.mtransform_out(op, off(Xg[:, c0:c1].contiguous().cpu(), k), out[:, c0:c1], row_off=k0, col_off=0, x_group_rows=Tl)
+            buf = off(torch.zeros(T, c1 - c0, F), k)
+            K.mtransform_out(op, dYd[:, c0:c1], buf, transpose=True, row_off=0, col_off=k0, y_group_rows=Tl)
+            out_T[:, c0:c1] = buf[pos]
+        assert torch.equal(out, whole), ("window fwd", T, Tl, N, F, b, dense, k, cuts)
+        assert torch.equal(out_T, whole_T), ("window adj", T, Tl, N, F, b, dense, k, cuts)
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_edge_head_and_loss_random_shapes_misaligned(seed):
     rng = np.random.default_rng(300 + seed)
