@@ -164,8 +164,16 @@ def test_mtransform_column_windows_random_shapes_misaligned(seed):
             buf = off(torch.zeros(T, c1 - c0, F), k)
             K.mtransform_out(op, dYd[:, c0:c1], buf, transpose=True, row_off=0, col_off=k0, y_group_rows=Tl)
             out_T[:, c0:c1] = buf[pos]
-        assert torch.equal(out, whole), ("window fwd", T, Tl, N, F, b, dense, k, cuts)
-        assert torch.equal(out_T, whole_T), ("window adj", T, Tl, N, F, b, dense, k, cuts)
+        # the band kernel's float4 and scalar forms do the same arithmetic per element: bit-equal always.  A
+        # dense M takes the bf16-split kernel only for 16-byte aligned operands with C % 4 == 0 and the
+        # exact-f32 one otherwise, so windows and whole agree bit for bit when F % 4 == 0 and the operands
+        # are aligned (the chunked all-gather's case) and to fp32 accuracy otherwise.
+        same_kernel = (op.band_lo + op.band_hi + 1 <= 20) or (F % 4 == 0 and k == 0)
+        if same_kernel:
+            assert torch.equal(out, whole), ("window fwd", T, Tl, N, F, b, dense, k, cuts)
+            assert torch.equal(out_T, whole_T), ("window adj", T, Tl, N, F, b, dense, k, cuts)
+        else:
+            assert max_rel_err(out, whole) <= REL_TOL and max_rel_err(out_T, whole_T) <= REL_TOL, (T, Tl, N, F, b, dense, k)
 
 
 @pytest.mark.parametrize("seed", range(40))

@@ -21,7 +21,10 @@ the backward pass.  Two exchange modes (DESIGN.md §6 has the byte counts):
                transforms chunk c-1 straight into columns of the resident [T/G, N, F] result
                (tmgcn_mtransform_ld_f32) — the replicated tensor never exists, the bytes on the
                links are the same, and per output element the arithmetic is that of the
-               unchunked form (bit-equal; `gather_chunk_nodes=0` keeps the unchunked form).
+               unchunked form: bit-equal whenever both take the same M-transform kernel — always
+               for a banded M, and for a dense one when F is a multiple of 4 (chunk boundaries
+               then keep the 16-byte alignment the bf16-split kernel asks for) —, fp32-equal
+               otherwise (`gather_chunk_nodes=0` keeps the unchunked form).
 
 condensed_W (one shared weight) adds an all-reduce of dW — F0·F1 floats.
 The collectives used (all_to_all_single, all_gather_into_tensor, reduce_scatter_tensor,
