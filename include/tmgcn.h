@@ -44,7 +44,7 @@ typedef enum {
 /* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
 enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
 
-/* ABI version 3 = version 2 + tmgcn_mtransform_ld_f32 (column-window M-transform).
+/* ABI version 3 = version 2 + tmgcn_mtransform_ld_f32 (column-window M-transform) + tmgcn_adj_mproduct_merge_* (segmented-merge M-product).
  * ABI version 2: no process-wide settings.  What used to be tmgcn_config_set() knobs are
  * per-call arguments (grid_reserve of tmgcn_spmm_gemm_f32, algo of tmgcn_gemm_dw_f32): two callers
  * in one process never see each other's choices. */
@@ -282,6 +282,20 @@ int tmgcn_adj_mproduct_expand(const uint64_t* key, const float* val, int64_t n, 
                               const float* M, int32_t ldm, int32_t band_lo, int32_t band_hi,
                               uint64_t* okey, float* oval, void* stream);
 /* sorted keys -> rowptr[TN+1] (binary search of r*N) and col[n] (key mod N) */
+/* The same product as a SEGMENTED MERGE of the column-sorted CSR rows (ABI 3): output row (k, r) is the
+ * W-way merge of rows r of the slices the band of M reaches from k, contributions to one column
+ * summed in fp64 in a fixed order and rounded once.  No expansion, no sort: the only memory is the
+ * output.  Two passes: _count writes the output row lengths as out_count[r+1] (out_count[0] = 0;
+ * the caller's inclusive prefix sum of it IS the output rowptr), _fill writes columns and values.
+ * Needs band_lo + band_hi + 1 <= 64 (wider: tmgcn_adj_mproduct_expand + tmgcn_coo_sort_reduce).
+ *   read_data.py:204-223 func_MProduct, SBM_our.py:78-86, read_data.m:207-209 */
+int tmgcn_adj_mproduct_merge_count(const int64_t* rowptr, const int32_t* col, int64_t TN, int32_t N, int32_t T,
+                                   const float* M, int32_t ldm, int32_t band_lo, int32_t band_hi,
+                                   int64_t* out_count, void* stream);
+int tmgcn_adj_mproduct_merge_fill(const int64_t* rowptr, const int32_t* col, const float* val, int64_t TN,
+                                  int32_t N, int32_t T, const float* M, int32_t ldm, int32_t band_lo,
+                                  int32_t band_hi, const int64_t* out_rowptr, int32_t* out_col, float* out_val,
+                                  void* stream);
 int tmgcn_adj_keys_to_csr(const uint64_t* key, int64_t n, int64_t N, int64_t TN, int64_t* rowptr,
                           int32_t* col, void* stream);
 /* keys (slice, col, row) of every entry of a batched CSR: sort them to get the per-slice transpose */

@@ -74,3 +74,60 @@ def test_native_transpose_matches_host_side_transpose():
 def test_bad_edges_raise():
     with pytest.raises(RuntimeError, match="out of range"):
         adjacency.build_adjacency([0, 5], [0, 1], [1, 2], [1.0, 1.0], T=3, N=4)
+
+
+@pytest.mark.parametrize("T,N,deg,lo,hi", [(12, 70, 4.0, 5, 0),      # lower band, half-wave groups
+                                           (40, 33, 2.0, 19, 0),     # the reference's 20 diagonals
+                                           (40, 25, 3.0, 0, 7),      # upper band (Mᵀ-shaped operator)
+                                           (50, 20, 2.0, 30, 9),     # 40 slices reached: full-wave groups
+                                           (6, 15, 0.3, 5, 5),       # band wider than T, mostly empty rows
+                                           (3, 8, 0.0, 1, 1)])       # empty tensor
+def test_mproduct_segmented_merge_matches_expand_sort_and_scipy(T, N, deg, lo, hi):
+    """The hand-written segmented merge (tmgcn_adj_mproduct_merge_count / _fill) against the expand + sort
+    + reduce form it replaces and against scipy: same sparsity pattern entry for entry, values within
+    fp32 rounding of each other (the merge sums in fp64 and rounds once), bit-reproducible."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(T * 1000 + N)
+    nnz = int(T * N * deg)
+    k, i, j = rng.integers(0, T, nnz), rng.integers(0, N, nnz), rng.integers(0, N, nnz)
+    v = rng.standard_normal(nnz).astype(np.float32)
+    A = adjacency.DeviceCOO.from_edges(k, i, j, v, T, N).sort_reduce().to_csr()
+    M = np.zeros((T, T))
+    for a in range(T):
+        for b in range(max(0, a - lo), min(T, a + hi + 1)):
+            M[a, b] = rng.uniform(0.2, 1.0) * (1 if rng.random() < 0.9 else 0)    # a few exact zeros inside the band
+    merged = adjacency.m_product_csr(A, M, algo="merge")
+    expanded = adjacency.m_product_csr(A, M, algo="expand")
+    assert torch.equal(merged.rowptr, expanded.rowptr) and torch.equal(merged.col, expanded.col)
+    if merged.nnz:
+        scale = float(expanded.val.abs().max())
+        assert float((merged.val - expanded.val).abs().max()) <= 2e-6 * scale
+    again = adjacency.m_product_csr(A, M, algo="merge")
+    assert torch.equal(again.val, merged.val) and torch.equal(again.col, merged.col)
+    dense = A.to_dense().cpu().double().numpy()
+    ref = np.einsum("kj,jab->kab", M, dense)
+    assert_close(merged.to_dense(), ref, 2e-6, "merge vs dense einsum")
+    # columns ascending inside every row (the CSR contract the SpMM's fixed summation order rests on)
+    if merged.nnz > 1:
+        rid = merged.row_ids()
+        same_row = rid[1:] == rid[:-1]
+        assert bool((merged.col[1:][same_row] > merged.col[:-1][same_row]).all())
+
+
+def test_mproduct_merge_sums_duplicate_columns_and_refuses_wide_bands():
+    """Input rows with repeated columns (a CSR built without coalescing) are summed, not emitted twice;
+    a band reaching more than 64 slices is refused by the merge entry point and taken by the expand form."""
+    T, N = 4, 6
+    rowptr = torch.zeros(T * N + 1, dtype=torch.int64)
+    rowptr[1:] = 3                                                   # row 0 of slice 0 holds everything
+    A = BatchedCSR(rowptr.cuda(), torch.tensor([2, 2, 5], dtype=torch.int32).cuda(), torch.tensor([1.0, 2.0, 4.0]).cuda(), T, N)
+    M = np.eye(T) * 2.0
+    out = adjacency.m_product_csr(A, M, algo="merge")
+    assert out.nnz == 2 and out.col.tolist() == [2, 5] and out.val.tolist() == [6.0, 8.0]
+    Tw = 80
+    Aw = adjacency.DeviceCOO.from_edges([0, 79], [1, 2], [3, 4], [1.0, 1.0], Tw, 5).sort_reduce().to_csr()
+    Mw = np.tril(np.ones((Tw, Tw)))
+    with pytest.raises(RuntimeError, match="wider than 64"):
+        adjacency.m_product_csr(Aw, Mw, algo="merge")
+    auto = adjacency.m_product_csr(Aw, Mw)                            # auto: falls back to expand + sort
+    assert_close(auto.to_dense(), np.einsum("kj,jab->kab", Mw, Aw.to_dense().cpu().double().numpy()), 1e-6, "wide band")

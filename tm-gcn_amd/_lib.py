@@ -57,6 +57,8 @@ SIGNATURES = {
     "tmgcn_adj_identity": (C.c_int, [_i64, _i64, _p, _p, _p]),
     "tmgcn_adj_normalise": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "tmgcn_adj_mproduct_expand": (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _i32, _i32, _i32, _p, _p, _p]),
+    "tmgcn_adj_mproduct_merge_count": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p, _p]),
+    "tmgcn_adj_mproduct_merge_fill": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _i32, _i32, _i32, _p, _p, _p, _p]),
     "tmgcn_adj_keys_to_csr": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p]),
     "tmgcn_adj_transpose_keys": (C.c_int, [_p, _p, _i64, _i64, _p, _p]),
     "tmgcn_act_fwd_f32": (C.c_int, [_p, _p, _i64, _i32, _p]),

@@ -161,6 +161,68 @@ __global__ void adj_transpose_keys_kernel(const int64_t* __restrict__ rowptr, co
   for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) okey[p] = (t * N + (uint64_t)col[p]) * N + i;
 }
 
+// ---- M-product as a segmented merge (no expansion, no sort) -------------------------------------
+// Output row (k, r) = Σ_j M[k][j] · A_j[r, :] over the slices j the band of M reaches from k.  The
+// input rows are column-sorted CSR rows, so the output row is their W-way merge: a group of L lanes
+// (32: two rows per wave, or 64) owns one output row, lane l walks the row of slice j = k - lo + l;
+// every step the group takes the smallest head column (wave-shuffle min), the lanes standing on it
+// contribute m·val (summed in fp64 in a fixed lane order, rounded once) and advance.  Two passes over
+// the same walk: COUNT (row lengths -> the caller's prefix sum gives rowptr) and FILL.  Memory: the
+// output itself; the expand + sort form (kept as the fallback for bands wider than 64) needs
+// W x nnz x 12 B of keys and values plus the sort's double buffer.
+template <int L, bool FILL>
+__global__ __launch_bounds__(256) void adj_mproduct_merge_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    int64_t TN, int32_t N, int32_t T, const float* __restrict__ M, int32_t ldm, int32_t lo, int32_t hi,
+    int64_t* __restrict__ out_count, const int64_t* __restrict__ out_rowptr, int32_t* __restrict__ out_col,
+    float* __restrict__ out_val) {
+  constexpr int kNone = 0x7fffffff;
+  const int lane = threadIdx.x & (L - 1);
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / L;   // output row k*N + r
+  if (row >= TN) return;                                                       // whole groups leave together
+  const int64_t k = row / N, r = row - k * N;
+  const int64_t j = k - lo + lane;
+  float m = 0.f;
+  if (lane <= lo + hi && j >= 0 && j < T) m = M[k * ldm + j];
+  int64_t p = 0, e = 0;
+  if (m != 0.f) {
+    p = rowptr[j * N + r];
+    e = rowptr[j * N + r + 1];
+  }
+  int c = p < e ? col[p] : kNone;
+  int64_t o = FILL ? out_rowptr[row] : 0;
+  int64_t n_out = 0;
+  for (;;) {
+    int cmin = c;
+#pragma unroll
+    for (int s = L >> 1; s > 0; s >>= 1) {
+      const int other = __shfl_xor(cmin, s, L);
+      cmin = other < cmin ? other : cmin;
+    }
+    if (cmin == kNone) break;
+    double acc = 0.0;
+    if (c == cmin) {                                 // (duplicate columns inside an input row are summed too)
+      do {
+        if (FILL) acc += (double)m * (double)val[p];
+        ++p;
+        c = p < e ? col[p] : kNone;
+      } while (c == cmin);
+    }
+    if (FILL) {
+#pragma unroll
+      for (int s = L >> 1; s > 0; s >>= 1) acc += __shfl_xor(acc, s, L);   // fixed butterfly: reproducible
+      if (lane == 0) {
+        out_col[o] = cmin;
+        out_val[o] = (float)acc;
+      }
+      ++o;
+    }
+    ++n_out;
+  }
+  if (!FILL && lane == 0) out_count[row + 1] = n_out;
+  if (!FILL && row == 0 && lane == 0) out_count[0] = 0;
+}
+
 static inline unsigned blocks(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -284,6 +346,50 @@ extern "C" int tmgcn_adj_mproduct_expand(const uint64_t* key, const float* val, 
   hipLaunchKernelGGL(adj_mproduct_kernel, dim3(blocks(n * W)), dim3(256), 0, (hipStream_t)stream, key, val, n, N,
                      T, M, ldm, band_lo, band_hi, okey, oval);
   return check_launch("adj_mproduct");
+}
+
+// M-product of a batched CSR by segmented merge: pass 1 (row lengths), pass 2 (columns and values)
+template <bool FILL>
+static int mproduct_merge_launch(const int64_t* rowptr, const int32_t* col, const float* val, int64_t TN, int32_t N,
+                                 int32_t T, const float* M, int32_t ldm, int32_t lo, int32_t hi, int64_t* out_count,
+                                 const int64_t* out_rowptr, int32_t* out_col, float* out_val, hipStream_t st) {
+  TMGCN_REQUIRE(TN >= 0 && N > 0 && T > 0 && lo >= 0 && hi >= 0, "adj_mproduct_merge: bad size");
+  TMGCN_REQUIRE(TN == (int64_t)T * N, "adj_mproduct_merge: TN=%lld is not T*N", (long long)TN);
+  if (lo > T - 1) lo = T - 1;
+  if (hi > T - 1) hi = T - 1;
+  const int W = lo + hi + 1;
+  TMGCN_REQUIRE(W <= 64, "adj_mproduct_merge: band of %d slices is wider than 64 (use tmgcn_adj_mproduct_expand)", W);
+  if (TN == 0) return TMGCN_OK;
+  TMGCN_REQUIRE(rowptr && M && ldm >= T, "adj_mproduct_merge: null pointer / bad M");
+  if (W <= 32)
+    hipLaunchKernelGGL((adj_mproduct_merge_kernel<32, FILL>), dim3(blocks(TN * 32)), dim3(256), 0, st, rowptr, col, val, TN,
+                       N, T, M, ldm, lo, hi, out_count, out_rowptr, out_col, out_val);
+  else
+    hipLaunchKernelGGL((adj_mproduct_merge_kernel<64, FILL>), dim3(blocks(TN * 64)), dim3(256), 0, st, rowptr, col, val, TN,
+                       N, T, M, ldm, lo, hi, out_count, out_rowptr, out_col, out_val);
+  return check_launch("adj_mproduct_merge");
+}
+
+extern "C" int tmgcn_adj_mproduct_merge_count(const int64_t* rowptr, const int32_t* col, int64_t TN, int32_t N, int32_t T,
+                                               const float* M, int32_t ldm, int32_t band_lo, int32_t band_hi,
+                                               int64_t* out_count, void* stream) {
+  TMGCN_REQUIRE(out_count, "adj_mproduct_merge_count: null output");
+  if (TN == 0) {
+    (void)hipMemsetAsync(out_count, 0, sizeof(int64_t), (hipStream_t)stream);
+    return check_launch("adj_mproduct_merge_count memset");
+  }
+  return mproduct_merge_launch<false>(rowptr, col, nullptr, TN, N, T, M, ldm, band_lo, band_hi, out_count, nullptr, nullptr,
+                                      nullptr, (hipStream_t)stream);
+}
+
+extern "C" int tmgcn_adj_mproduct_merge_fill(const int64_t* rowptr, const int32_t* col, const float* val, int64_t TN,
+                                              int32_t N, int32_t T, const float* M, int32_t ldm, int32_t band_lo,
+                                              int32_t band_hi, const int64_t* out_rowptr, int32_t* out_col, float* out_val,
+                                              void* stream) {
+  // col / val / out_col / out_val may be null when the tensor has no stored entry at all (never dereferenced then)
+  TMGCN_REQUIRE(TN == 0 || out_rowptr, "adj_mproduct_merge_fill: null out_rowptr");
+  return mproduct_merge_launch<true>(rowptr, col, val, TN, N, T, M, ldm, band_lo, band_hi, nullptr, out_rowptr, out_col,
+                                     out_val, (hipStream_t)stream);
 }
 
 // sorted keys -> CSR arrays
