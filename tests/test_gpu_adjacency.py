@@ -131,3 +131,16 @@ def test_mproduct_merge_sums_duplicate_columns_and_refuses_wide_bands():
         adjacency.m_product_csr(Aw, Mw, algo="merge")
     auto = adjacency.m_product_csr(Aw, Mw)                            # auto: falls back to expand + sort
     assert_close(auto.to_dense(), np.einsum("kj,jab->kab", Mw, Aw.to_dense().cpu().double().numpy()), 1e-6, "wide band")
+
+
+@pytest.mark.parametrize("T,N,E,window", [(12, 40, 300, 10), (7, 25, 60, 3), (5, 9, 0, 4), (30, 15, 200, 40)])
+def test_edge_life_as_a_merge_matches_the_expand_form(T, N, E, window):
+    """B'[t] = B[t] + … + B[t-window+1] is the mode-1 product with a lower band of ones: the segmented
+    merge gives the pattern of the expand + sort form entry for entry and its values to fp32 rounding."""
+    rng = np.random.default_rng(7 * T + N)
+    coo = adjacency.DeviceCOO.from_edges(rng.integers(0, T, E), rng.integers(0, N, E), rng.integers(0, N, E),
+                                         rng.uniform(0.5, 2.0, E).astype(np.float32), T, N).sort_reduce()
+    a, b = coo.edge_life(window, algo="merge"), coo.edge_life(window, algo="expand")
+    assert torch.equal(a.key, b.key)
+    if a.n:
+        assert float((a.val - b.val).abs().max()) <= 2e-6 * float(b.val.abs().max())

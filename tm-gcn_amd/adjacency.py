@@ -26,6 +26,7 @@ from .csr import BatchedCSR
 from .ops import MOperator, _ptr, _stream
 
 SENTINEL = -1  # ~0 as int64
+MERGE_MAX_BAND = 64   # slices the band of M may reach from one output slice in the merge kernel
 
 
 class DeviceCOO:
@@ -87,10 +88,25 @@ class DeviceCOO:
         """(A + Aᵀ)/2 per slice — read_data.py:88-111."""
         return self._expand("tmgcn_adj_symmetrise", 2).sort_reduce()
 
-    def edge_life(self, window: int) -> "DeviceCOO":
-        """B'[t] = B[t] + B[t-1] + … + B[t-window+1] — read_data.py:116-125."""
+    @staticmethod
+    def from_csr(A: BatchedCSR) -> "DeviceCOO":
+        """Batched CSR -> sorted, reduced COO keys (slice*N + row)*N + col."""
+        return DeviceCOO((A.row_ids() * A.N + A.col.long()).contiguous(), A.val, A.T, A.N)
+
+    def edge_life(self, window: int, algo: str = "auto") -> "DeviceCOO":
+        """B'[t] = B[t] + B[t-1] + … + B[t-window+1] — read_data.py:116-125.  That is the mode-1 product
+        with a lower band of ones, so it runs as the same segmented merge as the M-product (no
+        `window`-fold expansion, no sort) whenever the window fits the merge kernel; `algo="expand"`
+        keeps the expand + sort + reduce form.  The input must be sorted and reduced (it is, after
+        `sort_reduce` / `symmetrise`)."""
         if window <= 1:
             return self
+        if algo == "auto":
+            algo = "merge" if window <= MERGE_MAX_BAND else "expand"
+        if algo == "merge":
+            import numpy as np
+            ones = np.tril(np.ones((self.T, self.T))) - np.tril(np.ones((self.T, self.T)), -min(window, self.T))
+            return DeviceCOO.from_csr(m_product_csr(self.to_csr(), ones, algo="merge"))
         return self._expand("tmgcn_adj_edge_life", window, self.T, window).sort_reduce()
 
     def add_identity_and_normalise(self) -> "DeviceCOO":
@@ -126,9 +142,6 @@ class DeviceCOO:
         _lib.check(lib.tmgcn_adj_keys_to_csr(_ptr(self.key), self.n, self.N, TN, _ptr(rowptr), _ptr(col),
                                              _stream(self.val)), "tmgcn_adj_keys_to_csr")
         return BatchedCSR(rowptr, col, self.val, self.T, self.N)
-
-
-MERGE_MAX_BAND = 64   # slices the band of M may reach from one output slice in the merge kernel
 
 
 def m_product_csr(A: BatchedCSR, M, algo: str = "auto") -> BatchedCSR:
