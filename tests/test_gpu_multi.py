@@ -24,10 +24,27 @@ pytestmark = [pytest.mark.gpu,
 WORLDS = sorted({2, max([w for w in (2, 4, 8) if w <= NGPU] or [2])})
 
 
+CASE_DEADLINE_S = 420      # a stalled collective must end as a failed test, not as a hung suite
+
+
 def _run(worker, world, args):
+    """Start `world` fresh ranks and wait for them WITH A DEADLINE: ranks still alive after it are
+    killed and the case fails with what every rank had reported so far."""
+    import time
     from _util import free_port
     ret = mp.Manager().dict()
-    mp.spawn(worker, args=(world, free_port(), *args, ret, "nccl"), nprocs=world, join=True)
+    ctx = mp.spawn(worker, args=(world, free_port(), *args, ret, "nccl"), nprocs=world, join=False)
+    t_end = time.monotonic() + CASE_DEADLINE_S
+    done = False
+    try:
+        while not done and time.monotonic() < t_end:
+            done = ctx.join(timeout=5)
+    finally:
+        if not done:
+            for p in ctx.processes:
+                if p.is_alive():
+                    p.kill()
+    assert done, f"ranks still running after {CASE_DEADLINE_S} s (killed); reports so far: {dict(ret)}"
     for r in range(world):
         assert ret.get(r) == "ok", f"rank {r}:\n{ret.get(r)}"
 
