@@ -43,6 +43,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef TMGCN_FUSED_QT
 #define TMGCN_FUSED_QT 0
 #endif
+// EXPERIMENT (round 3): software prefetch of the index stream in phase 1 — the row pointers of the row
+// after next and the first 64 (col, val) pairs of the next row are requested before the current row's
+// gathers, so that the rowptr -> (col, val) -> gather dependency chain of a row overlaps the gathers
+// of the row before it.  A/B in profiles/r3*_ab_fused_prefetch.txt.
+#ifndef TMGCN_FUSED_PREFETCH
+#define TMGCN_FUSED_PREFETCH 0
+#endif
 
 constexpr int FBM = 64;         // rows per tile
 constexpr int FKC = 128;        // max K (feature width of X)
@@ -128,6 +135,53 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
     }
 
     // ---- phase 1: gather 16 rows per wave into the LDS tile
+#if TMGCN_FUSED_PREFETCH
+    {
+      // two-deep software pipeline over this wave's rows rr = wave, wave+4, …: (b1, e1, c1, v1) belong to
+      // the row being gathered, (b2, e2) to the next one; rows past the tile / the matrix are empty
+      auto bounds = [&](int rr, int64_t& b, int64_t& e) {
+        const int64_t r = row0 + rr;
+        b = e = 0;
+        if (rr < FBM && r < row_end) {
+          b = a.rowptr[r];
+          e = a.rowptr[r + 1];
+        }
+      };
+      auto first = [&](int64_t b, int64_t e, int& c, float& v) {
+        c = 0;
+        v = 0.f;
+        if (b + lane < e) {
+          c = a.col[b + lane];
+          v = a.val[b + lane];
+        }
+      };
+      int64_t b1, e1, b2, e2;
+      int c1;
+      float v1;
+      bounds(wave, b1, e1);
+      bounds(wave + 4, b2, e2);
+      first(b1, e1, c1, v1);
+      for (int rr = wave; rr < FBM; rr += 4) {
+        const int64_t r = row0 + rr;
+        int64_t b3, e3;
+        bounds(rr + 8, b3, e3);                       // row pointers two rows ahead
+        int c2;
+        float v2;
+        first(b2, e2, c2, v2);                        // index pairs one row ahead
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < row_end) {
+          const int64_t slice = r / a.N;
+          acc = gather_row<LPR, U, true>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, b1, e1, F4, lane, c1, v1);
+        }
+        if (lane < LPR && lane < F4) {
+          *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
+          if (a.AX && r < row_end) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
+        }
+        b1 = b2; e1 = e2; c1 = c2; v1 = v2;
+        b2 = b3; e2 = e3;
+      }
+    }
+#else
     for (int rr = wave; rr < FBM; rr += 4) {
       const int64_t r = row0 + rr;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -141,6 +195,7 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
         if (a.AX && r < row_end) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
       }
     }
+#endif
     __syncthreads();
 
     // ---- phase 2: tile · Wop on the matrix cores

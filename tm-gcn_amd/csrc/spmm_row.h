@@ -38,11 +38,13 @@ __device__ __forceinline__ void store_f1(float* p, float v) {
 // non-zeros; the row's (col,val) pairs are fetched 64 at a time with one coalesced load per
 // array and handed to the streams with ds_bpermute (__shfl); U 16-B gathers in flight per lane.
 // On return every lane of stream 0 (sub == 0) holds the full sum (fixed butterfly order).
-template <int LPR, int U>
+// PRE: the row's first 64 (col, val) pairs were fetched by the caller one row ahead (c0, v0: lane i
+// holds entry beg + i, anything for i >= end - beg) — the fused kernel's software prefetch.
+template <int LPR, int U, bool PRE = false>
 __device__ __forceinline__ float4 gather_row(const int32_t* __restrict__ col,
                                              const float* __restrict__ val,
                                              const float4* __restrict__ Xs, int64_t beg,
-                                             int64_t end, int F4, int lane) {
+                                             int64_t end, int F4, int lane, int c0 = 0, float v0 = 0.f) {
   constexpr int S = kWave / LPR;
   const int sub = lane / LPR;
   const int fl = lane % LPR;
@@ -52,7 +54,10 @@ __device__ __forceinline__ float4 gather_row(const int32_t* __restrict__ col,
     const int n = (int)((end - base) < kWave ? (end - base) : kWave);
     int c = 0;
     float v = 0.f;
-    if (lane < n) {
+    if (PRE && base == beg) {
+      c = c0;
+      v = v0;
+    } else if (lane < n) {
 #if TMGCN_NT_COLVAL
       c = __builtin_nontemporal_load(col + base + lane);
       v = __builtin_nontemporal_load(val + base + lane);
