@@ -441,12 +441,22 @@ def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_tim
     F = args.feat
     last = {}
 
-    def step():
+    phase_events = []                     # (start, after forward, after backward) per timed step, on the main stream
+
+    def step(record=False):
         X.grad = None
         W.grad = None
         last.clear()                      # frees the previous Y before the next forward allocates
+        if record:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
         Y = layer(X, W)
+        if record:
+            ev[1].record()
         Y.backward(dY)
+        if record:
+            ev[2].record()
+            phase_events.append(ev)
         last["Y"] = Y.detach()
 
     def fence():
@@ -464,9 +474,21 @@ def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_tim
     stage(f"layer[{exchange}, N={N}]: timing {steps} steps")
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        step(record=True)
     fence()
     elapsed = time.perf_counter() - t0
+    # forward / backward split of the step (main-stream events; side streams are joined before each ends):
+    # against the N = 1 figures it shows which pass an exchange is exposed in
+    fwd = sum(e[0].elapsed_time(e[1]) for e in phase_events) / len(phase_events)
+    bwd = sum(e[1].elapsed_time(e[2]) for e in phase_events) / len(phase_events)
+    phases = torch.tensor([fwd, bwd], device=dev, dtype=torch.float64)
+    if world > 1:
+        pmax = phases.clone()
+        dist.all_reduce(pmax, op=dist.ReduceOp.MAX)
+        phases_rec = {"forward_ms_rank0": round(fwd, 3), "backward_ms_rank0": round(bwd, 3),
+                      "forward_ms_max": round(float(pmax[0]), 3), "backward_ms_max": round(float(pmax[1]), 3)}
+    else:
+        phases_rec = {"forward_ms": round(fwd, 3), "backward_ms": round(bwd, 3)}
     kt = ops.kernels.timer.summary() if want_timer else {}
     ops.kernels.timer = None
     if world > 1:
@@ -495,7 +517,7 @@ def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_tim
             "collective": layer.collective, "grid_reserve": layer.grid_reserve, "cu_reserve": layer.cu_reserve, "T": pb["T"],
             "gather_chunks": len(layer.gather_chunks(F)) if (layer.collective and exchange == "allgather"
                                                                and layer.gather_chunk_nodes != 0) else None,
-            "peak_gb": peak_gb, "verify": ver}
+            "peak_gb": peak_gb, "verify": ver, "phases": phases_rec}
 
 
 def free_device_memory():
@@ -767,6 +789,7 @@ def worker(args):
                          "frac_forward_only": achieved_fwd / HBM_PEAK_GBS,
                          "traffic_is_for": "the forward launch (the larger of the two: it also stores AX and Y)"},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
+            "phases_ms": res["phases"],
             "peak_hbm_gb_rank0": round(res["peak_gb"], 1),
             "plan": {ex: {"total_gb": pl["total_gb"], "exchange_gb": round(pl["exchange"] / 1e9, 2), "exchange": pl["exchange_note"]}
                      for ex, pl in plans.items()},
