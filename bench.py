@@ -787,7 +787,11 @@ def worker(args):
                          "avg_launch_ms": avg_ms, "launches_averaged": sum(x["launches"] for x in both),
                          "forward_launch_ms": sp["avg_ms"], "backward_launch_ms": spT["avg_ms"] if spT else None,
                          "frac_forward_only": achieved_fwd / HBM_PEAK_GBS,
-                         "traffic_is_for": "the forward launch (the larger of the two: it also stores AX and Y)"},
+                         "traffic_is_for": "the forward launch (the larger of the two: it also stores AX and Y)",
+                         "note": None if sp["launches"] == args.steps else
+                         "pipelined multi-GPU path: one-slice launches alternate between two streams and are enqueued ahead, so a "
+                         "launch's event-to-event time includes waiting for residency: achieved / frac are LOWER bounds here; "
+                         "the N = 1 line carries the kernel's own figure"},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kt.items()},
             "phases_ms": res["phases"],
             "peak_hbm_gb_rank0": round(res["peak_gb"], 1),

@@ -151,6 +151,12 @@ class KernelTimer:
         return rc
 
     def summary(self):
+        """Per tag: launches, avg_ms, total_ms — each launch from its start event to its end event on the
+        stream it ran on.  Where launches of one tag are enqueued on two streams at once (the pipelined
+        sharded layer's one-slice launches) a launch's start event precedes its residency, so its time
+        includes waiting for the previous launch's blocks to leave: an UPPER bound on the kernel's own
+        time there.  (Charging only end-to-end gaps across streams was tried and is not usable: event
+        timestamps of different HIP streams did not reproduce rocprofv3's kernel intervals.)"""
         torch.cuda.synchronize()
         out = {}
         for tag, spans in self.spans.items():
