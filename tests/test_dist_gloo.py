@@ -47,6 +47,9 @@ def _worker(rank, world, port, exchange, condensed, act, F0, ret):
         A_local = BatchedCSR.from_scipy_list(g.Ct).slices(k0, k1)
         layer = ShardedTMGCNLayer(A_local, g.M, T, group=None, exchange=exchange)
         assert layer.G == world and layer.k0 == k0
+        # multi-GPU defaults: the pipelined a2a leaves 32 CUs to RCCL through CU-masked streams (device
+        # tensors only; nothing of it is touched on the CPU), no block-slot reserve; the all-gather form needs neither
+        assert layer.grid_reserve == 0 and layer.cu_reserve == (32 if exchange == "a2a" else 0)
         Xin = (X[:, n0:n1] if exchange == "a2a" else X[k0:k1]).contiguous().clone().requires_grad_(True)
         Wl = (W if condensed else W[k0:k1]).contiguous().clone().requires_grad_(True)
         Y = layer(Xin, Wl, act=act)
