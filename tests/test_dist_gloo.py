@@ -232,3 +232,16 @@ def test_sharded_layer_fuzz_shapes_bands_and_chunkings(world):
     mp.spawn(_fuzz_worker, args=(world, free_port(), 12, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", f"rank {r}:\n{ret.get(r)}"
+
+
+def test_cu_mask_words():
+    """The CU mask handed to hipExtStreamCreateWithCUMask: every CU but the last `cus_free`."""
+    from tmgcn_amd.dist import cu_mask_words
+    assert cu_mask_words(256, 0) == [0xFFFFFFFF] * 8
+    m = cu_mask_words(256, 32)
+    assert m == [0xFFFFFFFF] * 7 + [0] and sum(bin(w).count("1") for w in m) == 224
+    m = cu_mask_words(256, 16)
+    assert m[-1] == 0x0000FFFF and sum(bin(w).count("1") for w in m) == 240
+    m = cu_mask_words(304, 40)                           # a CU count that is not a multiple of 32 (MI300X)
+    assert len(m) == 10 and sum(bin(w).count("1") for w in m) == 264 and m[-1] == 0
+    assert sum(bin(w).count("1") for w in cu_mask_words(8, 100)) == 1      # never the empty mask

@@ -118,6 +118,19 @@ def _loaded_hip_runtime() -> str:
     return "libamdhip64.so"
 
 
+def cu_mask_words(n_cu: int, cus_free: int) -> List[int]:
+    """The CU mask of hipExtStreamCreateWithCUMask as 32-bit words: bit b set = CU b may be used.
+    All n_cu CUs but the last `cus_free` (at least one CU always stays enabled)."""
+    cus_free = max(0, min(int(cus_free), n_cu - 1))
+    words = (n_cu + 31) // 32
+    mask = [0xFFFFFFFF] * words
+    if n_cu % 32:
+        mask[-1] = (1 << (n_cu % 32)) - 1
+    for b in range(n_cu - cus_free, n_cu):
+        mask[b // 32] &= ~(1 << (b % 32)) & 0xFFFFFFFF
+    return mask
+
+
 def cu_masked_stream(device, cus_free: int):
     """A HIP stream whose kernels may run on all CUs of `device` but the last `cus_free`
     (hipExtStreamCreateWithCUMask), as a torch stream.  The pipelined sharded layer launches its
@@ -128,14 +141,8 @@ def cu_masked_stream(device, cus_free: int):
     up 16 of 256 CUs costs it about 1 %."""
     import ctypes as C
     device = torch.device(device)
-    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-    cus_free = max(0, min(int(cus_free), n_cu - 1))
-    words = (n_cu + 31) // 32
-    mask = [0xFFFFFFFF] * words
-    if n_cu % 32:
-        mask[-1] = (1 << (n_cu % 32)) - 1
-    for b in range(n_cu - cus_free, n_cu):
-        mask[b // 32] &= ~(1 << (b % 32))
+    mask = cu_mask_words(torch.cuda.get_device_properties(device).multi_processor_count, cus_free)
+    words = len(mask)
     hip = C.CDLL(_loaded_hip_runtime())
     hip.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
     hip.hipExtStreamCreateWithCUMask.restype = C.c_int
