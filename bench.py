@@ -96,7 +96,7 @@ def parse(argv=None):
     p.add_argument("--selftest-stall", action="store_true",
                    help="diagnostic (tests/test_bench_launcher.py): every rank stops making progress before it touches "
                         "the GPU, so that the deadline path can be exercised on a CPU-only machine")
-    p.add_argument("--deadline", type=int, default=1500,
+    p.add_argument("--deadline", type=int, default=900,
                    help="hard limit: after this many seconds every rank dumps its stacks and exits non-zero (0 disables)")
     return p.parse_args(argv)
 
