@@ -10,7 +10,9 @@ the backward pass.  Two exchange modes (DESIGN.md §6 has the byte counts):
                nodes).  P1 runs locally on full tube fibres (any M, dense or banded) and writes
                its output in the all-to-all send layout; one all-to-all per local slice
                re-partitions it to SLICE-sharded [T/G, N, F]; P2 and P3 are local.  Each rank
-               moves (G-1)/G of ITS OWN shard, spread over all 7 xGMI links.
+               moves (G-1)/G of ITS OWN shard, spread over all 7 xGMI links.  The exchange is
+               pipelined slice by slice beside the fused kernel, whose one-slice launches
+               alternate between two CU-MASKED streams that leave 32 CUs to RCCL's kernels.
   "allgather"  the layer input arrives SLICE-sharded ([T/G, N, F]); an all-gather replicates
                it, every rank transforms only its own output slices (row window of M), P2 and
                P3 are local.  Backward is a reduce-scatter.  This is the north-star's literal
