@@ -546,7 +546,11 @@ def measure_traffic(args):
     common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--nodes", str(args.nodes), "--slices-per-gpu", str(args.slices_per_gpu),
               "--deg", str(args.deg), "--feat", str(args.feat), "--band", str(args.band), "--no-epochs", "--no-cpu-baseline",
               "--no-verify", "--no-measure-traffic", "--deadline", "400"]
-    env = dict(os.environ, TMPDIR="/tmp")
+    # a clean environment for the children: should THIS process itself run under a profiler, its preload /
+    # tool variables must not leak into the nested rocprofv3 (which sets its own)
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCTX", "HSA_TOOLS_", "ROCPROFILER_"))}
+    env["TMPDIR"] = "/tmp"
     got = {}
     with tempfile.TemporaryDirectory(prefix="tmgcn_pmc_", dir="/tmp") as tmp:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
