@@ -239,8 +239,9 @@ def gpu_epochs(g, spec, epochs, mode):
     on the device; five timed passes of `epochs` epochs each.
     mode: "eager"   device targets + nn.CrossEntropyLoss on device logits
           "graph"   the same epoch captured into one hipGraph and replayed
-          "fused"   eager with tmgcn_amd.WeightedCrossEntropy (the opt-in fused loss)
-          "graph_fused"  the fused-loss epoch captured into one hipGraph and replayed
+          "fused"   eager with `gcn.loss(criterion, target)`: edge head + weighted CE + all their gradients in
+                    one launch (csrc/head_loss.hip; the 1-layer model folds its AtXt·W into it as well)
+          "graph_fused"  the fused epoch captured into one hipGraph and replayed
           "script"  what an untouched reference script does: `import tmgcn_amd.ehf as ehf`,
                     host-side targets, class weights and criterion (hosted.DeviceResult)"""
     import torch
@@ -271,9 +272,11 @@ def gpu_epochs(g, spec, epochs, mode):
     else:
         crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1], device="cuda"))
 
+    fused = mode in ("fused", "graph_fused")
+
     def epoch():
         opt.zero_grad(set_to_none=True)
-        loss = crit(m(), labels)
+        loss = m.loss(crit, labels) if fused else crit(m(), labels)   # fused: head + criterion + gradients in one launch
         loss.backward()
         opt.step()
         return loss
@@ -283,7 +286,7 @@ def gpu_epochs(g, spec, epochs, mode):
         epoch()
     if mode in ("graph", "graph_fused"):
         from tmgcn_amd.graphs import GraphedTrainStep
-        step = GraphedTrainStep(m, crit, opt, labels)
+        step = GraphedTrainStep(m, crit, opt, labels, fused_loss=fused)
         for _ in range(3):
             step()
         run = step

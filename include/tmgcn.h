@@ -44,7 +44,8 @@ typedef enum {
 /* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
 enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
 
-/* ABI version 3 = version 2 + tmgcn_mtransform_ld_f32 (column-window M-transform) + tmgcn_adj_mproduct_merge_* (segmented-merge M-product).
+/* ABI version 4 = version 3 + tmgcn_head_loss_f32 / tmgcn_scale2_f32 (one-pass edge head + loss + gradients).
+ * ABI version 3 = version 2 + tmgcn_mtransform_ld_f32 (column-window M-transform) + tmgcn_adj_mproduct_merge_* (segmented-merge M-product).
  * ABI version 2: no process-wide settings.  What used to be tmgcn_config_set() knobs are
  * per-call arguments (grid_reserve of tmgcn_spmm_gemm_f32, algo of tmgcn_gemm_dw_f32): two callers
  * in one process never see each other's choices. */
@@ -248,6 +249,37 @@ int tmgcn_wce_fwd_f32(const float* logits, const int64_t* target, const float* w
 int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* weight,
                       const double* stats, const float* grad_loss, int64_t E, int32_t C,
                       int64_t ignore_index, float* dlogits, void* stream);
+
+/* ---- one-pass edge head + weighted cross entropy + all gradients (ABI 4) ----------------
+ * loss = nn.CrossEntropyLoss(weight=w)(  [Z[src], Z[dst]] · U ,  target )  and, when dU != NULL, the
+ * gradients autograd derives for it (upstream gradient 1), in ONE launch — the per-epoch statements
+ *   ehf:228-232 / 351-355 / 491-495 (gather, cat, ·U),
+ *   experiment_reddit_our_link_prediction.py:69, 79 (criterion, loss.backward())
+ * for the narrow heads of the reference's experiments: even F <= 8, C <= 4, 32-bit indices
+ * (tmgcn_head_loss_supported).  Row-centric over the inverted edge index; no logits / dlogits arrays,
+ * no atomics, the tail reduction done by the last block: bitwise reproducible.
+ *   eptr[R+1], ent[2E]   the inverted edge index of tmgcn_edge_head_bwd_i32_f32 (entry = 2*edge + role)
+ *   other[2E]            row index of the OTHER endpoint of each entry's edge
+ *   tgt[2E]              target class of each entry's edge (0..C-1), 255 = ignored (no weight, no gradient)
+ *   class_count[C]       number of labelled edges per class: Σ_e w[t_e] = Σ_c class_count[c]·w[c]
+ *   logits               [E][C] or NULL: the logits as a by-product
+ *   dZ [R][F], dU [2F][C]   or both NULL (loss only)
+ *   K = 2 ("fold", the 1-layer model ehf:222): Z is AtXt [R][2] and W_fold [2][F] the shared weight;
+ *       Z = AtXt·W is recomputed per row, dZ is not stored and dW [2][F] = Σ_r AtXt[r]ᵀ·dZ[r] is returned.
+ *   workspace            tmgcn_head_loss_workspace_bytes(F, C, K) bytes
+ *   sync                 one int32, ZERO before the first launch; the kernel leaves it zero.  Launches
+ *                        that share a sync word must not overlap.
+ */
+int tmgcn_head_loss_supported(int32_t F, int32_t C, int32_t K);
+int64_t tmgcn_head_loss_workspace_bytes(int32_t F, int32_t C, int32_t K);
+int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t K, const float* U,
+                        const int32_t* eptr, const int32_t* ent, const int32_t* other, const uint8_t* tgt,
+                        const int64_t* class_count, const float* weight, int64_t R, int64_t E, int32_t F,
+                        int32_t C, float* logits, float* loss, float* dZ, float* dU, float* dW,
+                        void* workspace, int64_t workspace_bytes, int32_t* sync, void* stream);
+/* out_a = g·a, out_b = g·b (g: one float on the device — the upstream gradient of a scalar loss) */
+int tmgcn_scale2_f32(const float* g, const float* a, float* out_a, int64_t na, const float* b, float* out_b,
+                     int64_t nb, void* stream);
 
 /* ---- adjacency pipeline on the device ----------------------------------
  * Replaces the reference's offline preprocessing loops: read_data.py:88-111 (symmetrise),

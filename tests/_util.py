@@ -84,3 +84,23 @@ def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def unpack_sym(d, name, T, N):
+    """Inverse of tests/golden/make_golden.py:_pack_sym — the compact upper-triangle form of fixture G10
+    back to every stored entry of the reference's coalesced sparse tensor: (slice, row, col, value) arrays
+    sorted by (slice, row, col), values as fp32 (the reference's fp64 values rounded once; the generator
+    asserted that the pattern is symmetric and the rounded values exactly so)."""
+    cnt = d[name + "_cnt"].astype(np.int64)
+    col = d[name + "_col"].astype(np.int64)
+    val = d[name + "_val"]
+    rows = np.repeat(np.arange(T * N, dtype=np.int64), cnt)          # slice*N + row of every upper entry
+    k, i = rows // N, rows % N
+    off = i != col
+    K = np.concatenate((k, k[off]))
+    I = np.concatenate((i, col[off]))
+    J = np.concatenate((col, i[off]))
+    V = np.concatenate((val, val[off]))
+    order = np.argsort((K * N + I) * N + J, kind="stable")
+    assert len(order) == int(d[name + "_nnz"])
+    return K[order], I[order], J[order], V[order]

@@ -267,8 +267,123 @@ def g8():
              **p0, **grads, **base)
 
 
+# ------------------------------------------------------------------------------ G10
+def _pack_sym(S, N):
+    """A coalesced, pattern-symmetric sparse [T,N,N] tensor -> compact arrays: entries with row <= col only
+    (per-(slice,row) counts, uint16 columns, the reference's fp64 values ROUNDED TO fp32) plus fp64 slice sums
+    of the unrounded values.  Asserted here, on the reference's real output: the pattern is symmetric and
+    the fp32-rounded values are exactly symmetric, so tests/_util.unpack_sym() restores every entry."""
+    idx, v = S._indices().numpy(), S._values().numpy()
+    T = int(S.shape[0])
+    key = (idx[0].astype(np.int64) * N + idx[1]) * N + idx[2]
+    assert (np.diff(key) > 0).all(), "coalesced tensors are sorted"
+    keyT = (idx[0].astype(np.int64) * N + idx[2]) * N + idx[1]
+    o = np.argsort(keyT, kind="stable")
+    v32 = v.astype(np.float32)
+    assert (keyT[o] == key).all() and (v32[o] == v32).all()
+    up = idx[1] <= idx[2]
+    counts = np.bincount(idx[0][up] * N + idx[1][up], minlength=T * N)
+    assert counts.max() < 2 ** 16 and N < 2 ** 16
+    sums = np.bincount(idx[0], weights=v, minlength=T)
+    return {"cnt": counts.astype(np.uint16), "col": idx[2][up].astype(np.uint16), "val": v32[up], "nnz": np.int64(len(v)),
+            "slice_sum": sums}
+
+
+def g10():
+    """The reference's OWN preprocessing on the whole chess data set it ships — all 7 301 players, all 100
+    monthly slices, read_data.py's 'Chess' settings (edge life 10, 20 diagonals, symmetric; 80 / 10 / 10
+    train / val / test slices) — then experiment_chess_our.py's models on the 80-slice training block
+    (T = 80 > no_diag = 20: the band of M is truncated, which fixture G5 at T = 16 never was)."""
+    import time
+    import warnings
+    warnings.simplefilter("ignore")
+    raw = np.loadtxt(os.path.join(REF, "data/chess/out.chess.csv"), comments="%")
+    dates = np.unique(raw[:, 3])                                        # read_data.py:46-47
+    TT, N = len(dates), int(max(raw[:, 0].max(), raw[:, 1].max()))      # :51
+    S_train, S_val, S_test = 80, 10, 10                                  # :36-38, experiment_chess_our.py:32
+    T = S_train
+    t_idx = np.searchsorted(dates, raw[:, 3])                           # :74-83 (one slice per distinct date)
+    tidx = torch.tensor(np.stack([t_idx, raw[:, 0] - 1, raw[:, 1] - 1]), dtype=torch.long)
+    A = torch.sparse.DoubleTensor(tidx, torch.ones(tidx.shape[1], dtype=torch.double), torch.Size([TT, N, N])).coalesce()
+    A_labels = torch.sparse.DoubleTensor(tidx, torch.tensor(raw[:, 2]), torch.Size([TT, N, N])).coalesce()   # :85-86
+    env = {"torch": torch, "np": np, "edge_life_window": 10, "no_diag": 20}
+    extract_functions(os.path.join(REF, "read_data.py"),
+                      {"func_make_symmetric", "func_edge_life", "func_laplacian_transformation", "func_create_sparse",
+                       "func_MProduct"}, env)
+    M = np.zeros((T, T))                                                 # :55-62
+    for i in range(20):
+        np.fill_diagonal(M[i:, :T - i], 1)
+    M = M / M.sum(axis=1)[:, None]
+    t0 = time.time()
+    B = env["func_edge_life"](env["func_make_symmetric"](A, N, TT), N, TT)
+    Cn = env["func_laplacian_transformation"](B, N, TT)
+    C_train = env["func_create_sparse"](Cn, N, TT, T, 0, T)              # :186-188
+    C_val = env["func_create_sparse"](Cn, N, TT, T, S_val, T + S_val)
+    Ct_train = env["func_MProduct"](C_train, torch.tensor(M))            # :225-227
+    Ct_val = env["func_MProduct"](C_val, torch.tensor(M))
+    print(f"g10: reference preprocessing {time.time() - t0:.0f} s; nnz A {A._nnz()}, C {Cn._nnz()}, Ct_train {Ct_train._nnz()}")
+
+    def slices(S):       # experiment_chess_our.py:54-57 — per-slice matrices WITHOUT an explicit size (ehf:564)
+        i, v = S._indices(), S._values()
+        return [torch.sparse.DoubleTensor(i[1:3, i[0] == j], v[i[0] == j]) for j in range(T)]
+
+    # experiment_chess_our.py:66-92 (features, edge sets, 3-class targets)
+    li, lv = A_labels._indices(), A_labels._values()
+    A1 = torch.sparse.FloatTensor(li, torch.ones(lv.shape), torch.Size([TT, N, N])).coalesce()   # :51 — the 0/1 pattern
+    X = torch.zeros(TT, N, 2)
+    X[:, :, 0] = torch.sparse.sum(A1, 1).to_dense()
+    X[:, :, 1] = torch.sparse.sum(A1, 2).to_dense()
+    X_train, X_val = X[0:S_train].double(), X[S_val:S_train + S_val].double()
+    edges_train = li[:, li[0] < S_train]
+    target_train = (torch.sign(lv[li[0] < S_train]) + 1).long()
+    sv = (li[0] >= S_val) & (li[0] < S_train + S_val)
+    edges_val = li[:, sv].clone()
+    edges_val[0] -= S_val
+    eval_val = edges_val[0] >= S_train - S_val
+    At_train, At_val = slices(Ct_train), slices(Ct_val)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([.33, .33, .33]))     # experiment_chess_our.py:23, 99
+    out = {}
+    models = {
+        "gcn": lambda: ehf.EmbeddingGCN(At_train, X_train, edges_train, torch.tensor(M), hidden_feat=[6, 3],
+                                        condensed_W=True, use_Minv=False),                      # :94 (no_layers == 1)
+        "gcn2": lambda: ehf.EmbeddingGCN2(At_train, X_train, edges_train, torch.tensor(M), hidden_feat=[6, 6, 3],
+                                          condensed_W=True, use_Minv=False, nonlin2="selu"),    # :92 (no_layers == 2)
+        "gcn2_twice": lambda: ehf.EmbeddingGCN2(At_train, X_train, edges_train, torch.tensor(M), hidden_feat=[6, 6, 3],
+                                                condensed_W=True, use_Minv=False, nonlin2="selu", apply_M_twice=True),
+    }
+    for name, ctor in models.items():
+        torch.manual_seed(71)
+        m = ctor()
+        for n, p in m.named_parameters():
+            out[f"{name}_{n}0"] = p.detach().numpy().copy()
+        logits = m()
+        loss = crit(logits, target_train)
+        m.zero_grad()
+        loss.backward()
+        out[f"{name}_logits"] = logits.detach().numpy()
+        out[f"{name}_loss"] = float(loss)
+        for n, p in m.named_parameters():
+            out[f"{name}_d{n}"] = p.grad.detach().numpy().copy()
+        if name != "gcn2_twice":
+            with torch.no_grad():    # :112-115 — the validation call; the script scores the last S_val slices only
+                lv_ = m(At_val, X_val, edges_val)
+                out[f"{name}_logits_val_eval"] = lv_[eval_val].numpy()
+                out[f"{name}_loss_val"] = float(crit(lv_[eval_val], (torch.sign(lv[sv]) + 1).long()[eval_val]))
+        print(f"g10: {name} loss {float(loss):.6f}")
+    packed = {}
+    for nm, S in (("C", Cn), ("Ct", Ct_train)):
+        packed.update({f"{nm}_{k}": v for k, v in _pack_sym(S, N).items()})
+    # Ct_val is not stored (the device pipeline and the CPU restatement rebuild it from the raw edges / from C);
+    # its slice sums are, so that a test can tell a wrong validation block from a wrong model
+    packed["Ct_val_slice_sum"] = np.bincount(Ct_val._indices()[0].numpy(), weights=Ct_val._values().numpy(), minlength=T)
+    packed["Ct_val_nnz"] = np.int64(Ct_val._nnz())
+    save("g10_chess_full", seed=71, TT=TT, N=N, S_train=S_train, S_val=S_val, S_test=S_test, M=M,
+         raw_k=t_idx.astype(np.uint8), raw_i=(raw[:, 0] - 1).astype(np.uint16), raw_j=(raw[:, 1] - 1).astype(np.uint16),
+         raw_label=raw[:, 2].astype(np.int8), **packed, **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:]
-    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g8", g8)):
+    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g8", g8), ("g10", g10)):
         if not which or name in which:
             fn()

@@ -1,0 +1,219 @@
+"""GPU: the one-pass edge head + class-weighted cross entropy + gradients (csrc/head_loss.hip, ops.head_loss,
+`model.loss(criterion, target)`) against (a) a torch fp64 restatement of the scripts' statements
+(ehf:228-232 + nn.CrossEntropyLoss(weight=...), autograd), (b) the unfused kernels it replaces, (c) the
+reference's own numbers (fixtures G2, G3, G10)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import REL_TOL, assert_close, coo_list, golden
+import tmgcn_amd.layers as ehf
+from tmgcn_amd import ops
+from tmgcn_amd.losses import WeightedCrossEntropy, weighted_ce
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(T, N, F, C, E, seed, ignore_frac=0.0, K=0):
+    g = torch.Generator().manual_seed(seed)
+    Z = torch.randn(T, N, K if K else F, generator=g).cuda()
+    W = (torch.randn(K, F, generator=g) * 0.7).cuda() if K else None
+    U = torch.randn(2 * F, C, generator=g).cuda()
+    edges = torch.stack([torch.randint(0, T, (E,), generator=g), torch.randint(0, N, (E,), generator=g),
+                         torch.randint(0, N, (E,), generator=g)])
+    target = torch.randint(0, C, (E,), generator=g)
+    if ignore_frac:
+        target[torch.rand(E, generator=g) < ignore_frac] = -100
+    weight = torch.rand(C, generator=g) + 0.1
+    return Z, W, U, edges, target.cuda(), weight.cuda()
+
+
+def _fp64(Z, W, U, edges, target, weight, N):
+    """The scripts' statements in fp64 on the device with stock torch ops + autograd."""
+    Zd = Z.double().requires_grad_(True)
+    Ud = U.double().requires_grad_(True)
+    Wd = W.double().requires_grad_(True) if W is not None else None
+    Y = (Zd @ Wd if W is not None else Zd).reshape(-1, U.shape[0] // 2)
+    e = edges.cuda()
+    logits = torch.cat((Y[e[0] * N + e[1]], Y[e[0] * N + e[2]]), dim=1) @ Ud
+    loss = torch.nn.functional.cross_entropy(logits, target, weight=weight.double())
+    loss.backward()
+    return logits.detach(), loss.detach(), Zd.grad, Ud.grad, (Wd.grad if W is not None else None)
+
+
+@pytest.mark.parametrize("T,N,F,C,E,ign", [(5, 40, 6, 2, 3000, 0.0),     # the reference's head, ~30 entries per row
+                                           (3, 500, 6, 2, 700, 0.1),     # most rows without an entry; ignored labels
+                                           (7, 33, 2, 1, 900, 0.0), (4, 64, 4, 3, 5000, 0.05), (2, 17, 8, 4, 2500, 0.0),
+                                           (1, 9, 6, 3, 1, 0.0),         # one edge
+                                           (6, 300, 6, 2, 200000, 0.0)])  # hub-free, 220 entries per row: 32-lane groups
+def test_head_loss_vs_fp64_and_unfused(T, N, F, C, E, ign):
+    Z, _, U, edges, target, weight = _problem(T, N, F, C, E, seed=T * 100 + F * 10 + C, ignore_frac=ign)
+    idx = ops.EdgeIndex(edges, N, "cuda", T=T)
+    Zr, Ur = Z.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    loss, logits = ops.head_loss(Zr, idx, Ur, target, weight, want_logits=True)
+    loss.backward()
+    ref_logits, ref_loss, ref_dZ, ref_dU, _ = _fp64(Z, None, U, edges, target, weight, N)
+    assert_close(logits, ref_logits, 1e-6, "logits")
+    assert abs(float(loss) - float(ref_loss)) <= 1e-6 * max(1.0, abs(float(ref_loss)))
+    assert_close(Zr.grad, ref_dZ, 2e-6, "dZ")
+    assert_close(Ur.grad, ref_dU, 2e-6, "dU")
+    # the kernels it replaces: same logits bit for bit (same fmaf chain), same loss / gradients to rounding
+    Z2, U2 = Z.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    lg2 = ops.edge_head(Z2, idx, U2)
+    l2 = weighted_ce(lg2, target, weight)
+    l2.backward()
+    assert torch.equal(logits, lg2.detach())
+    assert abs(float(loss) - float(l2)) <= 2e-6 * max(1.0, abs(float(l2)))
+    assert_close(Zr.grad, Z2.grad, 5e-6, "dZ vs unfused")
+    assert_close(Ur.grad, U2.grad, 5e-6, "dU vs unfused")
+    # reproducible bit for bit, and the hand-off word is left zero
+    Z3, U3 = Z.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    l3 = ops.head_loss(Z3, idx, U3, target, weight)
+    l3.backward()
+    assert torch.equal(l3.detach(), loss.detach()) and torch.equal(Z3.grad, Zr.grad) and torch.equal(U3.grad, Ur.grad)
+    assert int(ops.head_loss_plan(idx, T * N, target, C).sync.item()) == 0
+    # loss only (no_grad): the same value
+    with torch.no_grad():
+        assert torch.equal(ops.head_loss(Z, idx, U, target, weight), loss.detach())
+
+
+@pytest.mark.parametrize("T,N,F,C,E", [(5, 40, 6, 2, 3000), (3, 200, 6, 3, 900), (4, 31, 8, 4, 4000), (2, 50, 2, 2, 100)])
+def test_head_loss_fold_layer1_gemm(T, N, F, C, E):
+    """K = 2: Z = AtXt·W recomputed in the kernel, dW returned; nothing of size [T,N,F] stored."""
+    X, W, U, edges, target, weight = _problem(T, N, F, C, E, seed=7 * T + F, K=2)
+    idx = ops.EdgeIndex(edges, N, "cuda", T=T)
+    Wr, Ur = W.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    loss, logits = ops.head_loss(X, idx, Ur, target, weight, want_logits=True, fold_W=Wr)
+    loss.backward()
+    ref_logits, ref_loss, _, ref_dU, ref_dW = _fp64(X, W, U, edges, target, weight, N)
+    assert_close(logits, ref_logits, 2e-6, "logits")
+    assert abs(float(loss) - float(ref_loss)) <= 2e-6 * max(1.0, abs(float(ref_loss)))
+    assert_close(Wr.grad, ref_dW, 3e-6, "dW")
+    assert_close(Ur.grad, ref_dU, 3e-6, "dU")
+    # the unfused route: standalone small GEMM, head, loss — same logits bit for bit
+    W2, U2 = W.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    lg2 = ops.edge_head(ops.feature_gemm(X, W2), idx, U2)
+    weighted_ce(lg2, target, weight).backward()
+    assert torch.equal(logits, lg2.detach())
+    assert_close(Wr.grad, W2.grad, 5e-6, "dW vs unfused")
+
+
+def test_upstream_gradient_scales_and_bad_labels_raise():
+    Z, _, U, edges, target, weight = _problem(4, 30, 6, 2, 800, seed=3)
+    idx = ops.EdgeIndex(edges, 30, "cuda", T=4)
+    Za, Ua = Z.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    ops.head_loss(Za, idx, Ua, target, weight).backward()
+    Zb, Ub = Z.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    (ops.head_loss(Zb, idx, Ub, target, weight) * -2.5).backward()
+    assert_close(Zb.grad, -2.5 * Za.grad, 1e-7, "scaled dZ")
+    assert_close(Ub.grad, -2.5 * Ua.grad, 1e-7, "scaled dU")
+    bad = target.clone()
+    bad[5] = 7
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.head_loss(Z, idx, U, bad, weight)
+    # a target edited in place is noticed (version counter), not served from the cached plan
+    t2 = target.clone()
+    l1 = float(ops.head_loss(Z, idx, U, t2, weight))
+    t2[:400] = 1 - t2[:400]
+    l2 = float(ops.head_loss(Z, idx, U, t2, weight))
+    assert abs(l2 - float(weighted_ce(ops.edge_head(Z, idx, U), t2, weight))) <= 2e-6 * max(1.0, abs(l2)) and l1 != l2
+
+
+def test_wide_head_falls_back_to_the_unfused_kernels():
+    Z, _, U, edges, target, weight = _problem(3, 50, 16, 2, 600, seed=5)
+    idx = ops.EdgeIndex(edges, 50, "cuda", T=3)
+    assert not ops.head_loss_supported(16, 2)
+    Zr = Z.clone().requires_grad_(True)
+    loss, logits = ops.head_loss(Zr, idx, U, target, weight, want_logits=True)
+    loss.backward()
+    ref_logits, ref_loss, ref_dZ, _, _ = _fp64(Z, None, U, edges, target, weight, 50)
+    assert_close(logits, ref_logits, 1e-5, "logits")
+    assert_close(Zr.grad, ref_dZ, 1e-5, "dZ")
+
+
+def _grads(model, loss):
+    model.zero_grad()
+    loss.backward()
+    return {n: p.grad.clone() for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("name", ["g2_gcn_condensed1", "g2_gcn_condensed0", "g3_gcn2_default_selu_condensed1",
+                                  "g3_gcn2_twice_relu_condensed1"])
+@pytest.mark.parametrize("crit_kind", ["torch", "fused", "tensor"])
+def test_model_loss_reproduces_the_reference(name, crit_kind):
+    """`gcn.loss(criterion, target)` == the reference's `criterion(gcn(), target)` and its gradients (G2: the
+    folded 1-layer form and the per-slice-W form that cannot fold; G3: 2-layer)."""
+    d = golden(name)
+    X = torch.from_numpy(d["X"])
+    T, N = X.shape[0], X.shape[1]
+    At, M, edges, labels = coo_list(d, "At", T, N), torch.from_numpy(d["M"]), torch.from_numpy(d["edges"]), torch.from_numpy(d["labels"])
+    torch.manual_seed(int(d["seed"]))
+    if name.startswith("g2"):
+        m = ehf.EmbeddingGCN(At, X, edges, M, hidden_feat=[6, 2], condensed_W=d["W0"].ndim == 2, use_Minv=False)
+    else:
+        _, _, branch, nl, cond = name.split("_")
+        m = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False,
+                              apply_M_twice=branch == "twice", nonlin2=nl)
+    w = torch.tensor([0.9, 0.1])
+    crit = {"torch": torch.nn.CrossEntropyLoss(weight=w), "fused": WeightedCrossEntropy(w), "tensor": w}[crit_kind]
+    loss, logits = m.loss(crit, labels.cuda(), want_logits=True)
+    g = _grads(m, loss)
+    assert_close(logits, d["logits"], REL_TOL, name + " logits")
+    assert abs(float(loss) - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    for n in g:
+        assert_close(g[n], d["d" + n], REL_TOL, f"{name} d{n}")
+
+
+def test_model_loss_on_full_chess_three_classes():
+    """G10 (C = 3, E = 52 k, R = 584 k rows — most without a labelled edge): the reference's loss and gradients."""
+    from _g10 import G10
+    from tmgcn_amd import adjacency
+    g = G10()
+    k, i, j = g.raw
+    Chat, _ = adjacency.build_adjacency(k, i, j, np.ones(len(k), np.float32), g.TT, g.N, M=None, window=10)
+    A = adjacency.m_product_csr(Chat.slices(0, g.T), g.M)
+    for name, ctor in (("gcn", lambda: ehf.EmbeddingGCN(A, torch.from_numpy(g.X_train), torch.from_numpy(g.edges_train),
+                                                        torch.from_numpy(g.M), hidden_feat=[6, 3], condensed_W=True, use_Minv=False)),
+                       ("gcn2", lambda: ehf.EmbeddingGCN2(A, torch.from_numpy(g.X_train), torch.from_numpy(g.edges_train),
+                                                          torch.from_numpy(g.M), hidden_feat=[6, 6, 3], condensed_W=True,
+                                                          use_Minv=False, nonlin2="selu"))):
+        torch.manual_seed(int(g.d["seed"]))
+        m = ctor()
+        crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(g.class_weights))
+        loss, logits = m.loss(crit, torch.from_numpy(g.target_train).cuda(), want_logits=True)
+        gr = _grads(m, loss)
+        assert_close(logits, g.d[name + "_logits"], REL_TOL, name + " logits")
+        assert abs(float(loss) - float(g.d[name + "_loss"])) <= 1e-5 * max(1.0, abs(float(g.d[name + "_loss"])))
+        for n in gr:
+            assert_close(gr[n], g.d[f"{name}_d{n}"], REL_TOL, f"{name} d{n}")
+
+
+def test_graphed_step_with_fused_loss_follows_the_eager_trajectory():
+    from tmgcn_amd.graphs import GraphedTrainStep
+    d = golden("g6_sgd_gcn2")
+    X = torch.from_numpy(d["X"])
+    T, N = X.shape[0], X.shape[1]
+    At, M, edges = coo_list(d, "At", T, N), torch.from_numpy(d["M"]), torch.from_numpy(d["edges"])
+    tgt = torch.from_numpy(d["labels"]).cuda()
+    w = torch.tensor([0.9, 0.1])
+
+    def make():
+        torch.manual_seed(int(d["seed"]))
+        m = ehf.EmbeddingGCN2(At, X, edges, M, hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False, nonlin2="selu")
+        return m, torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+
+    m1, o1 = make()
+    crit = torch.nn.CrossEntropyLoss(weight=w.cuda())
+    losses = []
+    for _ in range(10):
+        o1.zero_grad()
+        l = crit(m1(), tgt)
+        l.backward()
+        o1.step()
+        losses.append(float(l))
+    assert_close(np.array(losses), d["losses"], REL_TOL, "eager trajectory vs the reference")
+    m2, o2 = make()
+    step = GraphedTrainStep(m2, WeightedCrossEntropy(w).cuda(), o2, tgt, warmup=3)
+    assert step.fused
+    got = [float(step()) for _ in range(7)]
+    assert_close(np.array(got), d["losses"][3:], REL_TOL, "graph + fused loss, steps 4-10")

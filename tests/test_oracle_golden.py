@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import REL_TOL, assert_close, coo_list, cptr, golden, golden_names, load_c_oracle
+from _util import REL_TOL, assert_close, coo_list, cptr, golden, golden_names, load_c_oracle, unpack_sym
 from oracle import tmgcn_oracle as orc
 import tmgcn_amd
 from tmgcn_amd import synth
@@ -279,3 +279,75 @@ def test_g8_gcn_reg(name):
     assert_close(W.grad, d["dW"], 2e-6, name + " dW")
     assert_close(lw.grad, d["dlin1_weight"], 2e-6, name + " dlin1.weight")
     assert_close(lb.grad, d["dlin1_bias"], 2e-6, name + " dlin1.bias")
+
+
+def test_g10_full_chess_pipeline_and_models():
+    """Fixture G10: the reference's own read_data.py functions on the WHOLE chess data set (7 301 players, 100
+    slices, T = 80 training slices > the 20 diagonals of M, so the band is truncated — G5 at T = 16 never was),
+    then experiment_chess_our.py's models.  Pins (a) synth's restated preprocessing — pattern entry for entry,
+    values to fp32 rounding of the stored fp64->fp32 values, fp64 slice sums — and (b) the oracle's 1- and
+    2-layer models incl. the `apply_M_twice` branch and the script's validation call, at real scale."""
+    import scipy.sparse as sp
+    from _g10 import G10
+    g = G10()
+    d, TT, T, N = g.d, g.TT, g.T, g.N
+    k, i, j = g.raw
+    raw = [sp.coo_matrix((np.ones(int((k == t).sum())), (i[k == t], j[k == t])), shape=(N, N)).tocsr() for t in range(TT)]
+    C = synth.normalise(synth.edge_life(synth.symmetrise(raw), 10))
+    M = synth.band_M(T, 20, "python")
+    assert_close(M, g.M, 1e-15, "band M (read_data.py:55-62)")
+    assert (np.count_nonzero(M, axis=1) == np.minimum(np.arange(T) + 1, 20)).all() and T > 20   # truncated band
+
+    def check(mats, name, Tn):
+        rk, ri, rj, rv = unpack_sym(d, name, Tn, N)
+        coo = [m.tocsr().sorted_indices().tocoo() for m in mats]
+        mk = np.concatenate([np.full(c.nnz, t, np.int64) for t, c in enumerate(coo)])
+        mi, mj = np.concatenate([c.row for c in coo]).astype(np.int64), np.concatenate([c.col for c in coo]).astype(np.int64)
+        mv = np.concatenate([c.data for c in coo])
+        assert len(mv) == len(rv) == int(d[name + "_nnz"]), name + ": number of stored entries"
+        assert np.array_equal(mk, rk) and np.array_equal(mi, ri) and np.array_equal(mj, rj), name + ": pattern"
+        assert float(np.abs(mv - rv).max()) <= 1e-7 * float(np.abs(rv).max()), name + ": values (fixture holds fp32)"
+        sums = np.bincount(mk, weights=mv, minlength=Tn)
+        assert np.allclose(sums, d[name + "_slice_sum"], rtol=1e-12, atol=0), name + ": fp64 slice sums"
+
+    check(C, "C", TT)
+    Ct = synth.m_product(C[:T], M)                                    # func_create_sparse(0, T) then func_MProduct
+    check(Ct, "Ct", T)
+    Ct_val = synth.m_product(C[g.S_val:g.S_val + T], M)               # the validation block (read_data.py:187, 226)
+    assert sum(c.nnz for c in Ct_val) == int(d["Ct_val_nnz"])
+    assert np.allclose([c.sum() for c in Ct_val], d["Ct_val_slice_sum"], rtol=1e-12, atol=0)
+
+    # the models (experiment_chess_our.py:92-103): 3 classes, weights .33
+    At, At_val = synth.to_coo_list(Ct), synth.to_coo_list(Ct_val)
+    Mt = torch.from_numpy(g.M)
+    X, Xv = torch.from_numpy(g.X_train), torch.from_numpy(g.X_val)
+    src, dst = orc.flat_edge_index(torch.from_numpy(g.edges_train), N)
+    vs, vd = orc.flat_edge_index(torch.from_numpy(g.edges_val), N)
+    tgt = torch.from_numpy(g.target_train)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(g.class_weights))
+    AtXt = orc.compute_AtXt(Mt, At, X)
+    AtXt_val = orc.compute_AtXt(Mt, At_val, Xv)
+    ev = torch.from_numpy(g.eval_val)
+    for name, kind, F, kw in (("gcn", "gcn", [2, 6, 3], {}), ("gcn2", "gcn2", [2, 6, 6, 3], dict(nonlin="selu")),
+                              ("gcn2_twice", "gcn2", [2, 6, 6, 3], dict(nonlin="selu", apply_M_twice=True))):
+        torch.manual_seed(int(d["seed"]))
+        p = orc.draw_params(kind, T, F)
+        for n in p:
+            assert np.array_equal(p[n].numpy(), d[f"{name}_{n}0"]), (name, n)
+        if kind == "gcn":
+            fwd = lambda q, a=AtXt, s=src, t=dst: orc.gcn_forward(a, q["W"], q["U"], s, t)
+        else:
+            fwd = lambda q, a=AtXt, s=src, t=dst: orc.gcn2_forward(a, At, Mt, q["W1"], q["W2"], q["U"], s, t, **kw)
+        ps = {n: v.clone().requires_grad_(True) for n, v in p.items()}
+        out = fwd(ps)
+        loss = crit(out, tgt)
+        loss.backward()
+        loss = loss.detach()
+        assert_close(out.detach(), d[name + "_logits"], 1e-6, name + " logits")
+        assert abs(float(loss) - float(d[name + "_loss"])) <= 1e-6 * max(1.0, abs(float(d[name + "_loss"])))
+        for n in p:
+            assert_close(ps[n].grad, d[f"{name}_d{n}"], 2e-6, f"{name} d{n}")
+        if name != "gcn2_twice":
+            with torch.no_grad():
+                out_val = fwd(p, AtXt_val, vs, vd)
+            assert_close(out_val[ev], d[name + "_logits_val_eval"], 1e-6, name + " validation logits (last S_val slices)")

@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tmgcn.h")
 ACT_IDS = {None: 0, "none": 0, "relu": 1, "leaky": 2, "selu": 3}
 DW_ALGOS = {None: 0, "auto": 0, "f32mfma": 1}   # TMGCN_DW_AUTO / TMGCN_DW_F32MFMA
 GEMM_ALGOS = {None: 0, "auto": 0, "f32mfma": 1}  # TMGCN_GEMM_AUTO / TMGCN_GEMM_F32MFMA
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class TmgcnLibraryError(RuntimeError):
@@ -49,6 +49,10 @@ SIGNATURES = {
     "tmgcn_wce_workspace_bytes": (_i64, [_i64]),
     "tmgcn_wce_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _p, _p, _p, _i64, _p]),
     "tmgcn_wce_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i64, _p, _p]),
+    "tmgcn_head_loss_supported": (C.c_int, [_i32, _i32, _i32]),
+    "tmgcn_head_loss_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "tmgcn_head_loss_f32": (C.c_int, [_p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),
+    "tmgcn_scale2_f32": (C.c_int, [_p, _p, _p, _i64, _p, _p, _i64, _p]),
     "tmgcn_adj_make_keys": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "tmgcn_coo_sort_reduce_workspace_bytes": (_i64, [_i64]),
     "tmgcn_coo_sort_reduce": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),

@@ -94,7 +94,7 @@ static unsigned stream_grid(int64_t n) {
 
 using namespace tmgcn;
 
-extern "C" int tmgcn_abi_version(void) { return 3; }
+extern "C" int tmgcn_abi_version(void) { return 4; }
 
 extern "C" const char* tmgcn_last_error(void) { return g_err; }
 

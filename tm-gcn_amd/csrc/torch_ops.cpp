@@ -369,8 +369,66 @@ Tensor wce_bwd(const Tensor& logits, const Tensor& target, const Tensor& weight,
   return dz;
 }
 
+// One-pass edge head + weighted CE (+ gradients with upstream gradient 1).  Returns
+// (loss [], logits [E,C] or empty, dZ [R,F] (fold: dW [K,F]) or empty, dU [2F,C] or empty).
+std::tuple<Tensor, Tensor, Tensor, Tensor> head_loss_fwd(const Tensor& Z, const OptTensor& W_fold, const Tensor& U,
+                                                         const Tensor& eptr, const Tensor& ent, const Tensor& other,
+                                                         const Tensor& tgt, const Tensor& counts, const Tensor& weight,
+                                                         Tensor sync, bool grad, bool want_logits) {
+  want(Z, "head_loss Z");
+  want(U, "head_loss U");
+  want(weight, "head_loss weight");
+  want(eptr, "head_loss eptr", at::kInt);
+  want(ent, "head_loss ent", at::kInt);
+  want(other, "head_loss other", at::kInt);
+  want(tgt, "head_loss tgt", at::kByte);
+  want(counts, "head_loss class counts", at::kLong);
+  want(sync, "head_loss sync", at::kInt);
+  const bool fold = W_fold.has_value() && W_fold->defined();
+  if (fold) want(*W_fold, "head_loss W");
+  TORCH_CHECK(Z.dim() == 2 && U.dim() == 2, "head_loss: Z must be [R, F] and U [2F, C]");
+  const int64_t R = Z.size(0), K = fold ? Z.size(1) : 0, F = fold ? W_fold->size(1) : Z.size(1), C = U.size(1);
+  TORCH_CHECK(!fold || (W_fold->dim() == 2 && W_fold->size(0) == K), "head_loss: W ", fold ? W_fold->sizes() : Z.sizes(),
+              " does not match AtXt ", Z.sizes());
+  TORCH_CHECK(U.size(0) == 2 * F && weight.numel() == C && counts.numel() == C, "head_loss: U ", U.sizes(), " / weight / counts do not match F=",
+              F, " C=", C);
+  TORCH_CHECK(tmgcn_head_loss_supported((int32_t)F, (int32_t)C, (int32_t)K), "head_loss: unsupported widths F=", F, " C=", C, " K=", K);
+  TORCH_CHECK(eptr.numel() == R + 1 && ent.numel() % 2 == 0 && other.numel() == ent.numel() && tgt.numel() == ent.numel() &&
+                  sync.numel() >= 1,
+              "head_loss: plan arrays do not match R=", R);
+  const int64_t E = ent.numel() / 2;
+  c10::DeviceGuard g(Z.device());
+  Tensor loss = at::empty({}, Z.options());
+  Tensor logits = want_logits ? at::empty({E, C}, Z.options()) : none_like(Z);
+  Tensor dZ = grad ? (fold ? at::empty({K, F}, Z.options()) : at::empty_like(Z)) : none_like(Z);
+  Tensor dU = grad ? at::empty_like(U) : none_like(Z);
+  const int64_t need = tmgcn_head_loss_workspace_bytes((int32_t)F, (int32_t)C, (int32_t)K);
+  Tensor ws = at::empty({need}, Z.options().dtype(at::kByte));
+  ok(tmgcn_head_loss_f32((const float*)ptr(Z), fold ? (const float*)ptr(*W_fold) : nullptr, (int32_t)K, (const float*)ptr(U),
+                         (const int32_t*)ptr(eptr), (const int32_t*)ptr(ent), (const int32_t*)ptr(other),
+                         (const uint8_t*)ptr(tgt), (const int64_t*)ptr(counts), (const float*)ptr(weight), R, E, (int32_t)F,
+                         (int32_t)C, (float*)ptr(logits), (float*)loss.data_ptr(), (grad && !fold) ? (float*)ptr(dZ) : nullptr,
+                         grad ? (float*)ptr(dU) : nullptr, (grad && fold) ? (float*)ptr(dZ) : nullptr, ptr(ws), ws.numel(),
+                         (int32_t*)sync.data_ptr(), stream_of(Z)),
+     "tmgcn_head_loss_f32");
+  return {loss, logits, dZ, dU};
+}
+
+std::tuple<Tensor, Tensor> scale2(const Tensor& g, const Tensor& a, const Tensor& b) {
+  want(g, "scale2 g");
+  want(a, "scale2 a");
+  want(b, "scale2 b");
+  c10::DeviceGuard gd(a.device());
+  Tensor oa = at::empty_like(a), ob = at::empty_like(b);
+  ok(tmgcn_scale2_f32((const float*)g.data_ptr(), (const float*)ptr(a), (float*)ptr(oa), a.numel(), (const float*)ptr(b),
+                      (float*)ptr(ob), b.numel(), stream_of(a)),
+     "tmgcn_scale2_f32");
+  return {oa, ob};
+}
+
 bool spmm_gemm_supported(int64_t K, int64_t Nf) { return tmgcn_spmm_gemm_supported((int32_t)K, (int32_t)Nf) != 0; }
 bool edge_head_supported(int64_t F, int64_t C) { return tmgcn_edge_head_supported((int32_t)F, (int32_t)C) != 0; }
+bool head_loss_supported(int64_t F, int64_t C, int64_t K) { return tmgcn_head_loss_supported((int32_t)F, (int32_t)C, (int32_t)K) != 0; }
 int64_t abi_version() { return tmgcn_abi_version(); }
 
 // ---------------------------------------------------------------------------------------
@@ -514,6 +572,36 @@ struct EdgeHeadFn : public torch::autograd::Function<EdgeHeadFn> {
   }
 };
 
+// loss (and, as a non-differentiable by-product, the logits) of the fused head + criterion.  The gradients are
+// formed in the SAME launch as the loss (upstream gradient 1) and kept; backward multiplies them by the
+// upstream gradient of the loss in one launch.
+struct HeadLossFn : public torch::autograd::Function<HeadLossFn> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& Z, const OptTensor& W_fold, const Tensor& U,
+                               const Tensor& eptr, const Tensor& ent, const Tensor& other, const Tensor& tgt,
+                               const Tensor& counts, const Tensor& weight, const Tensor& sync, bool want_logits, bool need) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    const bool fold = W_fold.has_value() && W_fold->defined();
+    Tensor Z2 = Z.contiguous().reshape({-1, Z.size(-1)});
+    auto [loss, logits, dZ, dU] = head_loss_fwd(Z2, W_fold, U, eptr, ent, other, tgt, counts, weight, sync, need, want_logits);
+    if (need) ctx->save_for_backward({dZ, dU});
+    ctx->saved_data["zshape"] = Z.sizes().vec();
+    ctx->saved_data["fold"] = fold;
+    ctx->mark_non_differentiable({logits});
+    return {loss, logits};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto sv = ctx->get_saved_variables();
+    TORCH_CHECK(sv.size() == 2, "head_loss: backward through a call made without gradients");
+    auto [gz, gu] = scale2(grads[0].contiguous().to(at::kFloat), sv[0], sv[1]);
+    const bool fold = ctx->saved_data["fold"].toBool();
+    variable_list out(12);
+    if (fold) out[1] = gz; else out[0] = gz.reshape(ctx->saved_data["zshape"].toIntVector());
+    out[2] = gu;
+    return out;
+  }
+};
+
 struct ActivationFn : public torch::autograd::Function<ActivationFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x, int64_t act) {
     at::AutoDispatchBelowADInplaceOrView guard;
@@ -566,6 +654,14 @@ Tensor edge_head_ad(const Tensor& Z, const Tensor& U, const Tensor& src, const T
   return EdgeHeadFn::apply(Z, U, src, dst, eptr, eidx,
                            at::GradMode::is_enabled() && (Z.requires_grad() || U.requires_grad()));
 }
+std::tuple<Tensor, Tensor> head_loss_ad(const Tensor& Z, const OptTensor& W_fold, const Tensor& U, const Tensor& eptr,
+                                        const Tensor& ent, const Tensor& other, const Tensor& tgt, const Tensor& counts,
+                                        const Tensor& weight, const Tensor& sync, bool want_logits) {
+  const bool fold = W_fold.has_value() && W_fold->defined();
+  const bool need = at::GradMode::is_enabled() && (U.requires_grad() || (fold ? W_fold->requires_grad() : Z.requires_grad()));
+  auto out = HeadLossFn::apply(Z, W_fold, U, eptr, ent, other, tgt, counts, weight, sync, want_logits, need);
+  return {out[0], out[1]};
+}
 Tensor activation_ad(const Tensor& x, int64_t act) { return ActivationFn::apply(x, act); }
 Tensor weighted_ce_ad(const Tensor& logits, const Tensor& target, const Tensor& weight, int64_t ignore_index) {
   return WeightedCeFn::apply(logits, target, weight, ignore_index);
@@ -593,6 +689,10 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("act_bwd(Tensor x, Tensor dy, int act) -> Tensor");
   m.def("wce_fwd(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> (Tensor, Tensor)");
   m.def("wce_bwd(Tensor logits, Tensor target, Tensor weight, Tensor stats, Tensor g, int ignore_index) -> Tensor");
+  m.def("head_loss_fwd(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor ent, Tensor other, Tensor tgt, Tensor counts, "
+        "Tensor weight, Tensor(a!) sync, bool grad, bool want_logits) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("scale2(Tensor g, Tensor a, Tensor b) -> (Tensor, Tensor)");
+  m.def("head_loss_supported(int F, int C, int K) -> bool", &head_loss_supported);
   m.def("spmm_gemm_supported(int K, int Nf) -> bool", &spmm_gemm_supported);
   m.def("edge_head_supported(int F, int C) -> bool", &edge_head_supported);
   m.def("abi_version() -> int", &abi_version);
@@ -607,6 +707,8 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("edge_head(Tensor Z, Tensor U, Tensor src, Tensor dst, Tensor? eptr, Tensor? eidx) -> Tensor");
   m.def("activation(Tensor x, int act) -> Tensor");
   m.def("weighted_ce(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> Tensor");
+  m.def("head_loss(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor ent, Tensor other, Tensor tgt, Tensor counts, "
+        "Tensor weight, Tensor(a!) sync, bool want_logits) -> (Tensor, Tensor)");
 }
 
 // ROCm tensors carry the CUDA dispatch key in PyTorch-ROCm
@@ -624,6 +726,8 @@ TORCH_LIBRARY_IMPL(tmgcn, CUDA, m) {
   m.impl("act_bwd", &act_bwd);
   m.impl("wce_fwd", &wce_fwd);
   m.impl("wce_bwd", &wce_bwd);
+  m.impl("head_loss_fwd", &head_loss_fwd);
+  m.impl("scale2", &scale2);
   // below the Autograd key (inference mode, or called from inside another autograd node) the
   // differentiable operators are their plain forwards
   m.impl("m_transform", &m_transform_ad);
@@ -633,6 +737,7 @@ TORCH_LIBRARY_IMPL(tmgcn, CUDA, m) {
   m.impl("edge_head", &edge_head_ad);
   m.impl("activation", &activation_ad);
   m.impl("weighted_ce", &weighted_ce_ad);
+  m.impl("head_loss", &head_loss_ad);
 }
 
 TORCH_LIBRARY_IMPL(tmgcn, Autograd, m) {
@@ -643,6 +748,7 @@ TORCH_LIBRARY_IMPL(tmgcn, Autograd, m) {
   m.impl("edge_head", &edge_head_ad);
   m.impl("activation", &activation_ad);
   m.impl("weighted_ce", &weighted_ce_ad);
+  m.impl("head_loss", &head_loss_ad);
 }
 
 // a CPU tensor reaching a kernel-level op gets the reference-style RuntimeError, not "no kernel"
@@ -662,4 +768,5 @@ TORCH_LIBRARY_IMPL(tmgcn, CPU, m) {
   m.impl("edge_head", &edge_head_ad);
   m.impl("activation", &activation_ad);
   m.impl("weighted_ce", &weighted_ce_ad);
+  m.impl("head_loss", &head_loss_ad);
 }

@@ -1,13 +1,21 @@
 """hipGraph capture of a whole training step (forward, loss, backward, optimizer step).
 
-The reference's real configs are tiny (N ≈ 1k–7k, F = 2→6→6): a step is ~25 kernels of a few µs
-each, so eager execution is bound by Python and launch overhead (0.5 ms per step at the
-Bitcoin-shaped size vs 0.2 ms replayed).  Every launcher of the C-ABI is asynchronous,
-allocation-free and sync-free, so the whole step captures into one graph:
+The reference's real configs are tiny (N ≈ 1k–7k, F = 2→6→6): a step is a dozen kernels of a few µs
+each, so eager execution is bound by Python and launch overhead.  Every launcher of the C-ABI is
+asynchronous, allocation-free and sync-free, so the whole step captures into one graph:
 
     step = GraphedTrainStep(gcn, criterion, optimizer, target)
     for ep in range(no_epochs):
-        loss = step()            # replays; `step.output` holds the logits of that step
+        loss = step()            # replays; `step.output` holds the logits of that step (if kept)
+
+What keeps the launch count down (rocprofv3 --kernel-trace of an S1 step: profiles/):
+  * `fused_loss=True` (default when the model offers it): `gcn.loss(criterion, target)` — the edge head,
+    the class-weighted cross entropy and every gradient of both in ONE launch (csrc/head_loss.hip)
+    instead of head / loss / loss-backward / dU / dZ + three reduction tails;
+  * gradients are released before the capture (`zero_grad(set_to_none=True)`), so that the captured
+    backward WRITES each `.grad` into graph-private memory instead of zero-filling and then adding
+    into a persistent one (two launches per parameter saved) — PyTorch's whole-network capture recipe;
+  * with `tmgcn_amd.optim.FusedSGD` the optimizer step of all parameters is one launch.
 """
 from __future__ import annotations
 
@@ -16,27 +24,36 @@ import torch
 
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, criterion, optimizer: torch.optim.Optimizer,
-                 target: torch.Tensor, warmup: int = 3):
+                 target: torch.Tensor, warmup: int = 3, fused_loss: bool = True, keep_logits: bool = False):
         self.model, self.criterion, self.optimizer, self.target = model, criterion, optimizer, target
         dev = target.device
         if dev.type != "cuda":
             raise RuntimeError("GraphedTrainStep needs ROCm tensors")
+        self.fused = bool(fused_loss) and hasattr(model, "loss")
+        self.keep_logits = keep_logits or not self.fused
+
+        def forward_loss():
+            if self.fused:
+                if self.keep_logits:
+                    return model.loss(criterion, target, want_logits=True)
+                return model.loss(criterion, target), None
+            out = model()
+            return criterion(out, target), out
+
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, lazy init)
+        with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, lazy init, plans)
             for _ in range(warmup):
-                optimizer.zero_grad(set_to_none=False)
-                criterion(model(), target).backward()
+                optimizer.zero_grad(set_to_none=True)
+                forward_loss()[0].backward()
                 optimizer.step()
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=False)
+        optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            self.output = model()
-            self.loss = criterion(self.output, target)
+            self.loss, self.output = forward_loss()
             self.loss.backward()
             optimizer.step()
-            optimizer.zero_grad(set_to_none=False)
 
     def __call__(self) -> torch.Tensor:
         self.graph.replay()

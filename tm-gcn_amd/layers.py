@@ -161,6 +161,61 @@ class _Sharding:
         return self._shard.gather_rows(_edge_head(Z, local_idx, U), counts, gather_index, mine)
 
 
+def _criterion_spec(criterion, C: int, device):
+    """(class weights [C] fp32, ignore_index) when `criterion` is the scripts' criterion — a class-weighted (or
+    plain) cross entropy with mean reduction and class-index targets — else None."""
+    from .losses import WeightedCrossEntropy
+    if isinstance(criterion, torch.Tensor):
+        w, ign = criterion, -100
+    elif isinstance(criterion, WeightedCrossEntropy):
+        w, ign = criterion.weight, criterion.ignore_index
+    elif isinstance(criterion, nn.CrossEntropyLoss):
+        if criterion.reduction != "mean" or getattr(criterion, "label_smoothing", 0.0) != 0.0:
+            return None
+        w, ign = criterion.weight, criterion.ignore_index
+        if w is None:
+            w = torch.ones(C)
+    else:
+        return None
+    if w.numel() != C or (0 <= ign < C):
+        return None
+    return w.detach().to(device=device, dtype=torch.float32).contiguous(), int(ign)
+
+
+class _Head:
+    """Mixin: the two ways a model's embedding leaves it.  ``_embed(At, X, edges)`` (per class) returns
+    (Z, edge index, U, fold) — fold = the shared weight W when Z is still AtXt and Z·W (ehf:222) may be done by
+    the consumer.
+      forward(...)              logits [E, C] = [Z[src], Z[dst]]·U            (ehf:228-232 / 351-355 / 491-495)
+      loss(criterion, target)   criterion(forward(...), target) in ONE launch (ops.head_loss): the per-epoch
+                                statements  `output = gcn(); loss = criterion(output, target)`  of the scripts
+                                (experiment_reddit_our_link_prediction.py:76-77) as one call, gradients included."""
+
+    def forward(self, At=None, X=None, edges=None):
+        Z, eidx, U, fold = self._embed(At, X, edges)
+        if fold is not None:
+            Z = ops.feature_gemm(Z, fold)                                    # ehf:222
+        return self._deliver(self._head(Z, eidx, U))
+
+    def loss(self, criterion, target: torch.Tensor, At=None, X=None, edges=None, want_logits: bool = False):
+        """``criterion(self(At, X, edges), target)``; with ``want_logits`` also the logits (detached: a by-product
+        for the scripts' accuracy lines).  Fused whenever the criterion is the scripts' weighted mean cross entropy
+        (nn.CrossEntropyLoss(weight=...), losses.WeightedCrossEntropy, or the class-weight tensor itself), the
+        model is not slice-sharded and the head is narrow (even F <= 8, C <= 4); any other case runs the
+        unfused statements, same value."""
+        spec = _criterion_spec(criterion, self.F[-1], self.dev) if self._shard is None else None
+        if spec is None:
+            out = self(At, X, edges)
+            crit = criterion if callable(criterion) else nn.CrossEntropyLoss(weight=criterion.to(out.device))
+            l = crit(out, target if self.host_operands else target.to(out.device))
+            return (l, out.detach()) if want_logits else l
+        Z, eidx, U, fold = self._embed(At, X, edges)
+        res = ops.head_loss(Z, eidx, U, target, spec[0], spec[1], want_logits, fold_W=fold)
+        if want_logits:
+            return self._deliver(res[0]), self._deliver(res[1])
+        return self._deliver(res)
+
+
 def _param(t: torch.Tensor, dev, dtype) -> nn.Parameter:
     """A parameter drawn on the CPU generator (reference order/values), stored on the device in
     `dtype` (fp32, or bf16 for the "bf16 weights" config)."""
@@ -173,7 +228,7 @@ def _w(p: torch.Tensor) -> torch.Tensor:
     return p if p.dtype == torch.float32 else p.float()
 
 
-class EmbeddingGCN(_Deliver, _Sharding, nn.Module):
+class EmbeddingGCN(_Head, _Deliver, _Sharding, nn.Module):
     """1-layer TM-GCN (ehf:156-234).  ``group``: slice-shard the model over a process group (_Sharding)."""
 
     def __init__(self, At: AdjLike, X: torch.Tensor, edges: torch.Tensor, M: torch.Tensor,
@@ -202,16 +257,18 @@ class EmbeddingGCN(_Deliver, _Sharding, nn.Module):
         """ehf:203-208 — P1 then P2 (sharded: this rank's slices of both)."""
         return ops.spmm(At, self._mt_input(X, self.Mop))
 
-    def forward(self, At=None, X=None, edges=None):
+    def _embed(self, At=None, X=None, edges=None):
         if _is_recompute_call(At, X, edges):
             AtXt = self.compute_AtXt(_adj(self._own(At), self.N, self.dev), _feat(X, self.dev))
             eidx = self._edge_index(edges, self.dev)
         else:
             AtXt, eidx = self.AtXt, self._edges
+        if not self.use_Minv and self.condensed_W and self._shard is None and self.W.dtype == torch.float32:
+            return AtXt, eidx, self._p(self.U), self.W                       # Z = AtXt·W left to the consumer
         Y = ops.feature_gemm(AtXt, self._p(self.W, per_slice=not self.condensed_W, gemm=True))   # ehf:222
         if self.use_Minv:
             Y = self._mt(Y, self.Minv)                                       # ehf:224
-        return self._deliver(self._head(Y, eidx, self._p(self.U)))
+        return Y, eidx, self._p(self.U), None
 
 
 class EmbeddingGCN_reg(_Deliver, nn.Module):
@@ -244,7 +301,7 @@ class EmbeddingGCN_reg(_Deliver, nn.Module):
         return self._deliver(self.lin1(Y).squeeze(2))                        # ehf:421-423
 
 
-class EmbeddingGCN2(_Deliver, _Sharding, nn.Module):
+class EmbeddingGCN2(_Head, _Deliver, _Sharding, nn.Module):
     """2-layer TM-GCN (ehf:236-357).  ``group``: slice-shard the model over a process group (_Sharding)."""
 
     def __init__(self, At: AdjLike, X: torch.Tensor, edges: torch.Tensor, M: torch.Tensor,
@@ -284,7 +341,7 @@ class EmbeddingGCN2(_Deliver, _Sharding, nn.Module):
         """ehf:307-312 — P1 then P2 (sharded: this rank's slices of both; X is the whole constant input)."""
         return ops.spmm(At, self._mt_input(X, self.Mop))
 
-    def forward(self, At=None, X=None, edges=None):
+    def _embed(self, At=None, X=None, edges=None):
         if _is_recompute_call(At, X, edges):
             AtXt = self.compute_AtXt(_adj(self._own(At), self.N, self.dev), _feat(X, self.dev))
             eidx = self._edge_index(edges, self.dev)
@@ -307,10 +364,10 @@ class EmbeddingGCN2(_Deliver, _Sharding, nn.Module):
                 Z = self._mt(Z, self.Mop)                                          # ehf:346
         else:
             Z = ops.spmm_feature_gemm(self.At, Y, W2)                              # ehf:348-349
-        return self._deliver(self._head(Z, eidx, U))
+        return Z, eidx, U, None
 
 
-class EmbeddingKWGCN(_Deliver, _Sharding, nn.Module):
+class EmbeddingKWGCN(_Head, _Deliver, _Sharding, nn.Module):
     """Baseline GCN without the M-product, 1 or 2 layers (ehf:425-497).  ``group``: slice-shard the
     model over a process group (_Sharding) — no M, so no activation exchange in any configuration."""
 
@@ -353,7 +410,7 @@ class EmbeddingKWGCN(_Deliver, _Sharding, nn.Module):
             AX = torch.cat((AX, AX.new_zeros(T_mine - A.T, self.N, AX.shape[-1])), dim=0)
         return AX
 
-    def forward(self, A=None, X=None, edges=None):
+    def _embed(self, A=None, X=None, edges=None):
         if _is_recompute_call(A, X, edges):
             n_call = A.T if isinstance(A, BatchedCSR) else len(A)
             if n_call > self.T:
@@ -371,4 +428,4 @@ class EmbeddingKWGCN(_Deliver, _Sharding, nn.Module):
             Z = ops.spmm_feature_gemm(self.A, Y, self._p(self.W2))                 # ehf:487
         else:
             Z = ops.feature_gemm(AX, self._p(self.W1, gemm=True))                  # ehf:489
-        return self._deliver(self._head(Z, eidx, self._p(self.U)))
+        return Z, eidx, self._p(self.U), None

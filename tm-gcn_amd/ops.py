@@ -102,6 +102,57 @@ class EdgeIndex:
         return self._inv[1], self._inv[2]
 
 
+class HeadLossPlan:
+    """What the one-pass head + loss kernel (csrc/head_loss.hip) walks, built once per (edge set, target):
+    the inverted edge index of the edge set, and in the same entry order the row of each entry's OTHER
+    endpoint and its edge's target class as one byte (255 = the criterion's ignore_index), plus the
+    number of labelled edges per class (Σ_e w[t_e] = Σ_c count[c]·w[c] for whatever class weights the
+    call brings).  A label outside [0, C) other than ignore_index raises here (one host sync per target
+    tensor; nn.CrossEntropyLoss device-asserts on it).  `sync` is the launch's hand-off word: zero
+    between launches, so launches that share a plan must not overlap (one training loop does not)."""
+
+    def __init__(self, edges: "EdgeIndex", R: int, target: torch.Tensor, C: int, ignore_index: int = -100):
+        if edges.index_dtype != torch.int32 or R >= 2 ** 31 - 1:
+            raise RuntimeError("head_loss: the edge set needs 64-bit indices; use edge_head + weighted_ce")
+        dev = edges.src.device
+        t = target.detach().to(device=dev, dtype=torch.int64)
+        if t.dim() != 1 or t.numel() != edges.E:
+            raise RuntimeError(f"head_loss: target must be [E={edges.E}], got {tuple(target.shape)}")
+        if 0 <= ignore_index < C:
+            raise RuntimeError(f"head_loss: ignore_index {ignore_index} names a real class (C={C})")
+        ignored = t == ignore_index
+        bad = ((t < 0) | (t >= C)) & ~ignored
+        if bool(bad.any()):
+            j = int(torch.nonzero(bad)[0])
+            raise RuntimeError(f"head_loss: target[{j}] = {int(t[j])} is outside [0, {C}) and is not ignore_index")
+        self.eptr, self.ent = edges.inverted(R)
+        e = (self.ent >> 1).long()
+        role = (self.ent & 1).bool()
+        self.other = torch.where(role, edges.src[e], edges.dst[e]).to(torch.int32).contiguous()
+        t8 = torch.where(ignored, torch.full_like(t, 255), t).to(torch.uint8)
+        self.tgt = t8[e].contiguous()
+        self.counts = torch.bincount(t[~ignored], minlength=C)[:C].to(torch.int64).contiguous()
+        self.sync = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.R, self.C, self.ignore_index = R, C, ignore_index
+        self._target, self._version = target, target._version
+
+    def matches(self, target: torch.Tensor, R: int, C: int, ignore_index: int) -> bool:
+        return (self._target is target and self._version == target._version and self.R == R and self.C == C
+                and self.ignore_index == ignore_index)
+
+
+def head_loss_plan(edges: "EdgeIndex", R: int, target: torch.Tensor, C: int, ignore_index: int = -100) -> HeadLossPlan:
+    """The plan of (edges, target), cached on the edge set (the scripts pass the same target tensor every epoch)."""
+    plans = edges.__dict__.setdefault("_loss_plans", [])
+    for p in plans:
+        if p.matches(target, R, C, ignore_index):
+            return p
+    p = HeadLossPlan(edges, R, target, C, ignore_index)
+    del plans[2:]                      # train / val / test targets at most; older ones are rebuilt on demand
+    plans.insert(0, p)
+    return p
+
+
 class MOperator:
     """The T×T mixing matrix M of the M-product, resident on the device in fp32, with the
     band structure the kernels exploit (read_data.m:116-124 builds a lower band of 20)."""
@@ -464,6 +515,38 @@ def edge_head(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, fuse: Optional
         return _EdgeHead.apply(Z.contiguous(), U.contiguous(), edges)
     Zf = Z.reshape(-1, F)
     return torch.matmul(torch.cat((Zf[edges.src.long()], Zf[edges.dst.long()]), dim=1), U)
+
+
+def head_loss_supported(F: int, Cn: int, K: int = 0) -> bool:
+    return kernels.name == "hip" and bool(_lib.load().tmgcn_head_loss_supported(F, Cn, K))
+
+
+def head_loss(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, target: torch.Tensor, weight: torch.Tensor,
+              ignore_index: int = -100, want_logits: bool = False, fold_W: Optional[torch.Tensor] = None):
+    """``nn.CrossEntropyLoss(weight)(edge_head(Z, edges, U), target)`` — P4 and the criterion of every experiment
+    script (ehf:228-232 + experiment_reddit_our_link_prediction.py:69, 79) — with every gradient, in ONE launch
+    (csrc/head_loss.hip) where the widths allow (even F <= 8, C <= 4, 32-bit indices); otherwise the edge head
+    followed by the fused weighted CE.  Returns the loss, or (loss, logits) with ``want_logits`` (the logits are
+    a non-differentiable by-product there: differentiate the loss).
+    fold_W: Z is the 1-layer model's cached AtXt [T,N,2] and fold_W its shared weight [2,F]: Z = AtXt·W (ehf:222)
+    is recomputed inside the kernel and dW returned through autograd — nothing of size [T,N,F] is stored."""
+    F = (fold_W if fold_W is not None else Z).shape[-1]
+    K = Z.shape[-1] if fold_W is not None else 0
+    Cn = U.shape[-1]
+    R = Z.numel() // Z.shape[-1]
+    fused = (head_loss_supported(F, Cn, K) and edges.E > 0 and edges.index_dtype == torch.int32 and R < 2 ** 31 - 1
+             and Z.dtype == torch.float32)
+    if not fused:
+        from .losses import weighted_ce
+        Zf = feature_gemm(Z, fold_W) if fold_W is not None else Z
+        logits = edge_head(Zf, edges, U)
+        loss = weighted_ce(logits, target.to(logits.device), weight.to(logits.device), ignore_index)
+        return (loss, logits) if want_logits else loss
+    plan = head_loss_plan(edges, R, target, Cn, ignore_index)
+    w = weight.detach().to(device=Z.device, dtype=torch.float32).contiguous()
+    loss, logits = kernels.ops.head_loss(Z, fold_W, U.contiguous(), plan.eptr, plan.ent, plan.other, plan.tgt, plan.counts, w,
+                                         plan.sync, bool(want_logits))
+    return (loss, logits) if want_logits else loss
 
 
 def activation(x: torch.Tensor, act) -> torch.Tensor:
