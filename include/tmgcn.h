@@ -255,15 +255,20 @@ int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* w
  * gradients autograd derives for it (upstream gradient 1), in ONE launch — the per-epoch statements
  *   ehf:228-232 / 351-355 / 491-495 (gather, cat, ·U),
  *   experiment_reddit_our_link_prediction.py:69, 79 (criterion, loss.backward())
- * for the narrow heads of the reference's experiments: even F <= 8, C <= 4, 32-bit indices
+ * for the narrow heads of the reference's experiments: even F <= 8, 2 <= C <= 4, 32-bit indices
  * (tmgcn_head_loss_supported).  Row-centric over the inverted edge index; no logits / dlogits arrays,
  * no atomics, the tail reduction done by the last block: bitwise reproducible.
- *   eptr[R+1], ent[2E]   the inverted edge index of tmgcn_edge_head_bwd_i32_f32 (entry = 2*edge + role)
+ *   eptr[R+1], ent[2E]   the inverted edge index of tmgcn_edge_head_bwd_i32_f32 (entry = 2*edge + role);
+ *                        ent is read only when the logits are stored
+ *   arow[n_active][4]    the rows with at least one entry, ascending: (row, eptr[row], eptr[row+1], 0), 16-byte aligned
  *   other[2E]            row index of the OTHER endpoint of each entry's edge
- *   tgt[2E]              target class of each entry's edge (0..C-1), 255 = ignored (no weight, no gradient)
+ *   meta[2E]             role << 7 | target class of each entry's edge (0..C-1; 127 = ignored: no weight, no gradient)
  *   class_count[C]       number of labelled edges per class: Σ_e w[t_e] = Σ_c class_count[c]·w[c]
+ *   grad_scale           NULL, or one float on the device: the gradients are multiplied by it (the upstream
+ *                        gradient of the loss, when the gradient launch runs in the caller's backward)
  *   logits               [E][C] or NULL: the logits as a by-product
- *   dZ [R][F], dU [2F][C]   or both NULL (loss only)
+ *   loss                 one float, or NULL when only the gradients are wanted
+ *   dZ [R][F], dU [2F][C]   or both NULL (loss only).  Rows without a labelled edge get dZ = 0.
  *   K = 2 ("fold", the 1-layer model ehf:222): Z is AtXt [R][2] and W_fold [2][F] the shared weight;
  *       Z = AtXt·W is recomputed per row, dZ is not stored and dW [2][F] = Σ_r AtXt[r]ᵀ·dZ[r] is returned.
  *   workspace            tmgcn_head_loss_workspace_bytes(F, C, K) bytes
@@ -273,8 +278,9 @@ int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* w
 int tmgcn_head_loss_supported(int32_t F, int32_t C, int32_t K);
 int64_t tmgcn_head_loss_workspace_bytes(int32_t F, int32_t C, int32_t K);
 int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t K, const float* U,
-                        const int32_t* eptr, const int32_t* ent, const int32_t* other, const uint8_t* tgt,
-                        const int64_t* class_count, const float* weight, int64_t R, int64_t E, int32_t F,
+                        const int32_t* eptr, const int32_t* arow, int64_t n_active, const int32_t* ent,
+                        const int32_t* other, const uint8_t* meta, const int64_t* class_count,
+                        const float* weight, const float* grad_scale, int64_t R, int64_t E, int32_t F,
                         int32_t C, float* logits, float* loss, float* dZ, float* dU, float* dW,
                         void* workspace, int64_t workspace_bytes, int32_t* sync, void* stream);
 /* out_a = g·a, out_b = g·b (g: one float on the device — the upstream gradient of a scalar loss) */

@@ -9,25 +9,32 @@
 // the Reddit-LP shape: 20x the real edges), plus three reduction tails.
 //
 // ROW-centric, not edge-centric: the kernel walks the INVERTED edge index (the entries of row r are
-// the labelled edges r is an endpoint of, 2·edge + role, ascending — built once per edge set, already
-// used by the atomic-free dZ kernel).  A group of G lanes owns a row; a lane takes entries gl, gl+G, …:
-// it reads the entry stream (entry id, row of the OTHER endpoint, target class: 9 bytes, coalesced),
-// gathers the other endpoint's row (the group's own row sits in registers), recomputes that edge's
-// logits — an edge is seen from both of its endpoints, 2·F·C fmas each time, nothing next to the
-// gather — and forms  g = w[t]·(softmax(z) − onehot(t)).  Summed over the row's entries BEFORE the
-// product with U (as the standalone dZ kernel does) that is the row's dZ, written once; no dlogits
-// array exists, nothing is scattered, no atomics.  The entry that sees an edge from its src side also
-// adds the edge's loss term and its dU contribution (per-lane fp64 accumulators) and stores the
-// logits if the caller wants them.  Σ_e w[t_e] depends only on the targets: the per-class edge counts
-// come with the plan, so the gradient needs no second pass.
+// the labelled edges r is an endpoint of, ascending — built once per edge set, already used by the
+// atomic-free dZ kernel) over the list of ACTIVE rows (rows with at least one entry: classification
+// configs label 24 k edges among 570 k rows).  A group of G lanes owns a row; a lane takes entries
+// gl, gl+G, …: it reads the entry stream (row of the OTHER endpoint + one byte role/target: 5 bytes,
+// coalesced), gathers the other endpoint's row (the group's own row sits in registers), recomputes
+// that edge's logits — an edge is seen from both of its endpoints, 2·F·C fmas each time, nothing next
+// to the gather — and forms  g = w[t]·(softmax(z) − onehot(t)).  Summed over the row's entries BEFORE
+// the product with U (as the standalone dZ kernel does), separately for the entries where the row is
+// the edge's src and its dst, that is S_src, S_dst:
+//     dZ[r]   = (S_src·U_srcᵀ + S_dst·U_dstᵀ) / Σw          written once; rows without entries get 0
+//     dU_src += Z[r]ᵀ·S_src,  dU_dst += Z[r]ᵀ·S_dst          per ROW, not per edge: the 2·F·C fp64
+//                                                             accumulators are dealt over the G lanes
+// No dlogits array exists, nothing is scattered, no atomics.  The entry that sees an edge from its src
+// side also adds the edge's loss term and stores the logits if the caller wants them.  Σ_e w[t_e]
+// depends only on the targets: the per-class edge counts come with the plan, so the gradient needs no
+// second pass.
 //
-// Tail: one slab of fp64 partials per block; the LAST block to finish (device counter that it resets)
-// adds the slabs in a fixed order and writes loss, dU (and dW).  One launch, bitwise reproducible.
+// Tail: one slab of fp64 partials per block, stored write-through; the LAST block to finish (device counter
+// that it resets) adds the slabs in a fixed order and writes loss, dU (and dW).  One launch, bitwise
+// reproducible.
 //
-// K > 0 ("fold"): the 1-layer model's  Z = AtXt·W  (ehf:222, F0 = K = 2) is recomputed on the fly from
-// the 8-byte AtXt rows — same fmaf chain as the standalone small GEMM, so the same bits — and dW =
-// Σ_r AtXt[r]ᵀ·dZ[r] is accumulated in the same pass: Z and dZ are never stored, and the whole
-// training epoch of EmbeddingGCN (cached AtXt) is this one kernel plus the optimizer step.
+// K > 0 ("fold"): the 1-layer model's  Z = AtXt·W  (ehf:222, F0 = K = 2) never exists: a lane gathers the
+// 8-byte AtXt rows and the logits see the pre-multiplied head W·U (mathematically the same statements,
+// re-associated: (x·W)·U = x·(W·U)); the per-row sums S are accumulated against AtXt instead of Z and the
+// last block turns them into dU and dW.  The whole training epoch of EmbeddingGCN (cached AtXt) is this
+// one kernel plus the optimizer step.
 #include "common.h"
 
 namespace tmgcn {
@@ -37,70 +44,73 @@ struct HeadLossArgs {
   const float* Wf;             // fold: [K][F]
   const float* U;              // [2F][C]
   const int32_t* eptr;         // [R+1]
-  const int32_t* ent;          // [2E]  2*edge + role
+  const int4* arow;            // [n_active] (row, first entry, end entry, -)
+  const int32_t* ent;          // [2E]  2*edge + role (read only when the logits are stored)
   const int32_t* other;        // [2E]  row of the other endpoint
-  const uint8_t* tgt;          // [2E]  target class of the entry's edge, 255 = ignored
+  const uint8_t* meta;         // [2E]  role << 7 | target class (127 = ignored)
   const int64_t* class_count;  // [C]
   const float* weight;         // [C]
+  const float* gscale;         // upstream gradient of the loss (device scalar) or null = 1
   float* logits;               // [E][C] or null
   float* dZ;                   // [R][F] or null
-  double* part;                // [blocks][NP]
-  float* loss;
+  unsigned long long* part;    // [main blocks][NP] fp64 bit patterns (stored and read write-through)
+  float* loss;                 // or null
   float* dU;
   float* dW;
   int32_t* sync;
   int64_t R;
-  int32_t logG;
+  int32_t n_active;
+  int32_t main_blocks;         // blocks that walk active rows (the others only zero-fill dZ)
 };
 
-// acc[i] over the block: xor butterfly per wave, the four waves in order through LDS.  Thread t < NP
-// returns the block total of acc[t] (others return 0).  Fixed order: reproducible.
-template <int NP>
-__device__ __forceinline__ double block_reduce(const double (&acc)[NP], double (*red)[NP]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+template <int N, typename T>
+__device__ __forceinline__ T pick(const T (&v)[N], int i) {   // v[i] for a lane-dependent i: compare chain, no scratch
+  T r = v[0];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    double v = acc[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) red[wave][i] = v;
-  }
-  __syncthreads();
-  double total = 0.0;
-  if (threadIdx.x < NP) total = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-  __syncthreads();
-  return total;
+  for (int q = 1; q < N; ++q) r = (i == q) ? v[q] : r;
+  return r;
 }
 
-template <int FT, int K>
-__device__ __forceinline__ void load_row(const HeadLossArgs& a, int64_t r, float (&z)[FT], float (&x)[K ? K : 1]) {
-  if constexpr (K == 0) {
-    const float2* p = reinterpret_cast<const float2*>(a.Z + r * FT);
+template <int N>
+__device__ __forceinline__ void load_in(const float* __restrict__ base, int64_t r, float (&v)[N]) {
+  const float2* p = reinterpret_cast<const float2*>(base + r * N);
 #pragma unroll
-    for (int i = 0; i < FT / 2; ++i) {
-      const float2 v = p[i];
-      z[2 * i] = v.x;
-      z[2 * i + 1] = v.y;
-    }
-  } else {
-    static_assert(K == 0 || K == 2, "fold supports the reference's F0 = 2");
-    const float2 v = *reinterpret_cast<const float2*>(a.Z + r * K);
-    x[0] = v.x;
-    x[1] = v.y;
-    const float* __restrict__ W = a.Wf;
-#pragma unroll
-    for (int f = 0; f < FT; ++f) z[f] = fmaf(x[1], W[FT + f], fmaf(x[0], W[f], 0.f));   // gemm_small's chain
+  for (int i = 0; i < N / 2; ++i) {
+    const float2 t = p[i];
+    v[2 * i] = t.x;
+    v[2 * i + 1] = t.y;
   }
 }
 
-// GRAD: also dZ (or dW when folding) and dU.  Without it only role-0 entries are visited (loss, logits).
-template <int FT, int CT, bool GRAD, int K>
+constexpr int kHeadLossMaxBlocks = 1024;
+
+// What a lane gathers per endpoint is the row's INPUT of NIN floats: the embedding row itself (K = 0, NIN = F)
+// or, folded (K = 2), the AtXt row — then the head the logits see is H = W·U (per role), i.e.
+//     logits = in_src·H_s + in_dst·H_d,      H_s = U[:F] (or W·U[:F]),  H_d = U[F:] (or W·U[F:])
+// and with S_src / S_dst the per-row sums of g over the entries where the row is the edge's src / dst
+//     Q_s = Σ_r in[r]ᵀ·S_src[r],  Q_d = Σ_r in[r]ᵀ·S_dst[r]        (2·NIN·C fp64 accumulators, dealt over the G lanes)
+//     K = 0:  dU = [Q_s; Q_d]/Σw,   dZ[r] = (S_src·U_sᵀ + S_dst·U_dᵀ)/Σw
+//     K = 2:  dU = [WᵀQ_s; WᵀQ_d]/Σw,   dW = (Q_s·U_sᵀ + Q_d·U_dᵀ)/Σw      (formed by the last block; Z, dZ never exist)
+// Σ_c g[c] = 0 for every entry, so only C − 1 classes are summed; the last one is minus their sum.
+// GRAD: with gradients.  Without, only the src-side entries are visited (loss, logits).  G lanes per active row.
+template <int FT, int CT, bool GRAD, int K, int G>
 __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
-  constexpr int NO = 2 * FT * CT, NW = K * FT;
-  constexpr int NP = 1 + (GRAD ? NO + NW : 0);      // slab: Σ w·nll | dU [2F][C] | dW [K][F]
+  constexpr int NIN = K ? K : FT;
+  constexpr int CS = CT - 1;                          // classes whose S is summed
+  constexpr int NQ = GRAD ? 2 * NIN * CT : 0;
+  constexpr int NP = 1 + NQ;                          // slab: Σ w·nll | Q_s [NIN][C] | Q_d [NIN][C]
+  constexpr int NPL = (NQ + G - 1) / G;               // accumulators per lane: q = gl + j·G
+  constexpr int NPP = NP <= 32 ? 32 : (NP <= 64 ? 64 : 128);
+  constexpr int PARTS = 256 / NPP;
+  static_assert(NP <= 128, "slab wider than the finisher");
   __shared__ double red[4][NP];
+  __shared__ double fin[PARTS][NPP];
   __shared__ int is_last;
   const float* __restrict__ U = a.U;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * 256;
+
   float w[CT];
   double den = 0.0;
 #pragma unroll
@@ -108,38 +118,73 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
     w[c] = a.weight[c];
     den += (double)a.class_count[c] * (double)w[c];
   }
-  const double invden = 1.0 / den;                   // no labelled edge with weight: 0/0 = NaN, as torch
-  const int G = 1 << a.logG;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t ngroups = ((int64_t)gridDim.x * 256) >> a.logG;
-  double acc[NP];
+  const double invden = 1.0 / den;                    // no labelled edge with weight: 0/0 = NaN, as torch
+  const double invden_g = a.gscale ? invden * (double)a.gscale[0] : invden;
+  // the head as the logits see it, per role: [NIN][CT] (uniform values: scalar registers)
+  float Hs[NIN][CT], Hd[NIN][CT];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) acc[i] = 0.0;
+  for (int i = 0; i < NIN; ++i)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      if constexpr (K == 0) {
+        Hs[i][c] = U[i * CT + c];
+        Hd[i][c] = U[(FT + i) * CT + c];
+      } else {
+        float s = 0.f, d = 0.f;
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+          s = fmaf(a.Wf[i * FT + f], U[f * CT + c], s);
+          d = fmaf(a.Wf[i * FT + f], U[(FT + f) * CT + c], d);
+        }
+        Hs[i][c] = s;
+        Hd[i][c] = d;
+      }
+    }
 
-  for (int64_t r = tid >> a.logG; r < a.R; r += ngroups) {
-    float zo[FT], xo[K ? K : 1];
-    load_row<FT, K>(a, r, zo, xo);
-    double S[2][CT];
+  // (every uniform operand above is read before the first store of this kernel, so that it can live in scalar
+  // registers: behind a store the compiler must assume it clobbered and reloads per lane)
+  if constexpr (GRAD && K == 0) {                     // rows no labelled edge touches: dZ = 0
+    for (int64_t r = tid; r < a.R; r += nthreads)
+      if (a.eptr[r] == a.eptr[r + 1]) {
+        float2* o = reinterpret_cast<float2*>(a.dZ + r * FT);
 #pragma unroll
-    for (int c = 0; c < CT; ++c) S[0][c] = S[1][c] = 0.0;
-    const int p1 = a.eptr[r + 1];
-    for (int p = a.eptr[r] + gl; p < p1; p += G) {
-      const int x = a.ent[p];
-      const bool role = x & 1;
+        for (int i = 0; i < FT / 2; ++i) o[i] = make_float2(0.f, 0.f);
+      }
+  }
+  if ((int)blockIdx.x >= a.main_blocks) return;       // block-uniform: no slab, no ticket
+
+  double num = 0.0;
+  double acc[NPL ? NPL : 1];
+#pragma unroll
+  for (int j = 0; j < (NPL ? NPL : 1); ++j) acc[j] = 0.0;
+
+  const int64_t ngroups = (int64_t)a.main_blocks * 256 / G;
+  int64_t i = tid / G;
+  int4 cur = i < a.n_active ? a.arow[i] : make_int4(0, 0, 0, 0);
+  for (; i < a.n_active; i += ngroups) {
+    const int4 nxt = (i + ngroups < a.n_active) ? a.arow[i + ngroups] : make_int4(0, 0, 0, 0);   // next row's range, early
+    const int64_t r = cur.x;
+    float xo[NIN];
+    load_in<NIN>(a.Z, r, xo);
+    double S[2][CS ? CS : 1];
+#pragma unroll
+    for (int c = 0; c < (CS ? CS : 1); ++c) S[0][c] = S[1][c] = 0.0;
+    for (int p = cur.y + gl; p < cur.z; p += G) {
+      const int m = a.meta[p];
+      const bool role = m & 0x80;
       if (!GRAD && role) continue;
-      const int t = a.tgt[p];
-      float zt[FT], xt[K ? K : 1];
-      load_row<FT, K>(a, a.other[p], zt, xt);
-      // logits: f ascending, src then dst — the order of edge_head_fwd_small, from either endpoint
+      const int t = m & 0x7f;
+      float xt[NIN];
+      load_in<NIN>(a.Z, a.other[p], xt);
+      // logits: input index ascending, src then dst (K = 0: the fmaf chain of edge_head_fwd_small, from either endpoint)
       float lg[CT];
 #pragma unroll
       for (int c = 0; c < CT; ++c) lg[c] = 0.f;
 #pragma unroll
-      for (int f = 0; f < FT; ++f) {
-        const float sv = role ? zt[f] : zo[f], dv = role ? zo[f] : zt[f];
+      for (int q = 0; q < NIN; ++q) {
+        const float sv = role ? xt[q] : xo[q], dv = role ? xo[q] : xt[q];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) lg[c] = fmaf(dv, U[(FT + f) * CT + c], fmaf(sv, U[f * CT + c], lg[c]));
+        for (int c = 0; c < CT; ++c) lg[c] = fmaf(dv, Hd[q][c], fmaf(sv, Hs[q][c], lg[c]));
       }
       float mx = lg[0];
 #pragma unroll
@@ -147,7 +192,7 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
       float ex[CT], s = 0.f;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        ex[c] = expf(lg[c] - mx);
+        ex[c] = __expf(lg[c] - mx);                   // arguments <= 0: the hardware exp2 is within 2 ulp there
         s += ex[c];
       }
       const bool valid = t < CT;
@@ -158,20 +203,18 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
           wt = w[c];
           zt_t = lg[c];
         }
-      float g[CT];
-      const float inv = 1.f / s;
-#pragma unroll
-      for (int c = 0; c < CT; ++c) g[c] = valid ? wt * (ex[c] * inv - (c == t ? 1.f : 0.f)) : 0.f;
       if constexpr (GRAD) {
+        const float inv = __builtin_amdgcn_rcpf(s);            // 1 ulp
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          if (role) S[1][c] += (double)g[c]; else S[0][c] += (double)g[c];
+        for (int c = 0; c < CS; ++c) {
+          const double g = valid ? (double)(wt * (ex[c] * inv - (c == t ? 1.f : 0.f))) : 0.0;
+          if (role) S[1][c] += g; else S[0][c] += g;
         }
       }
       if (!role) {
-        if (valid) acc[0] += (double)wt * ((double)mx + (double)logf(s) - (double)zt_t);
+        if (valid) num += (double)(wt * ((mx - zt_t) + __logf(s)));
         if (a.logits) {
-          float* o = a.logits + (int64_t)(x >> 1) * CT;
+          float* o = a.logits + (int64_t)(a.ent[p] >> 1) * CT;
           if constexpr (CT == 2) {
             *reinterpret_cast<float2*>(o) = make_float2(lg[0], lg[1]);
           } else if constexpr (CT == 4) {
@@ -181,131 +224,191 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
             for (int c = 0; c < CT; ++c) o[c] = lg[c];
           }
         }
-        if constexpr (GRAD) {                       // dU += [z_src, z_dst]ᵀ · g   (this lane is the src side)
-#pragma unroll
-          for (int f = 0; f < FT; ++f)
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-              acc[1 + f * CT + c] = fma((double)zo[f], (double)g[c], acc[1 + f * CT + c]);
-              acc[1 + (FT + f) * CT + c] = fma((double)zt[f], (double)g[c], acc[1 + (FT + f) * CT + c]);
-            }
-        }
       }
     }
     if constexpr (GRAD) {
+#pragma unroll
       for (int o = G >> 1; o > 0; o >>= 1) {
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
+        for (int c = 0; c < CS; ++c) {
           S[0][c] += __shfl_xor(S[0][c], o);
           S[1][c] += __shfl_xor(S[1][c], o);
         }
       }
-      float s0[CT], s1[CT];
+      double Sf[2 * CT];                              // [role][c], all classes
+      {
+        double l0 = 0.0, l1 = 0.0;
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        s0[c] = (float)(S[0][c] * invden);
-        s1[c] = (float)(S[1][c] * invden);
-      }
-      float dz[FT];
-#pragma unroll
-      for (int f = 0; f < FT; ++f) {
-        float v = 0.f;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) v = fmaf(s1[c], U[(FT + f) * CT + c], fmaf(s0[c], U[f * CT + c], v));
-        dz[f] = v;
+        for (int c = 0; c < CS; ++c) {
+          Sf[c] = S[0][c];
+          Sf[CT + c] = S[1][c];
+          l0 -= S[0][c];
+          l1 -= S[1][c];
+        }
+        Sf[CS] = l0;
+        Sf[CT + CS] = l1;
       }
       if constexpr (K == 0) {
+        float sf[2 * CT];
+#pragma unroll
+        for (int c = 0; c < 2 * CT; ++c) sf[c] = (float)(Sf[c] * invden_g);
         float2* o = reinterpret_cast<float2*>(a.dZ + r * FT);
-        for (int i = gl; i < FT / 2; i += G) {
-          float2 v;
+        for (int q = gl; q < FT / 2; q += G) {        // lane q of the group stores features 2q, 2q+1
+          float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-          for (int q = 0; q < FT / 2; ++q)
-            if (q == i) v = make_float2(dz[2 * q], dz[2 * q + 1]);
-          o[i] = v;
+          for (int h = 0; h < FT / 2; ++h)
+            if (q == h) {
+#pragma unroll
+              for (int c = 0; c < CT; ++c) {
+                v0 = fmaf(sf[CT + c], Hd[2 * h][c], fmaf(sf[c], Hs[2 * h][c], v0));
+                v1 = fmaf(sf[CT + c], Hd[2 * h + 1][c], fmaf(sf[c], Hs[2 * h + 1][c], v1));
+              }
+            }
+          o[q] = make_float2(v0, v1);
         }
-      } else if (gl == 0) {                         // dW += AtXt[r]ᵀ · dZ[r]  (dz already carries 1/Σw)
+      }
+      // lane gl owns the accumulators q = gl + j·G of Q[role][in][c]:  += in[r][in]·S[role][c]
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-#pragma unroll
-          for (int f = 0; f < FT; ++f)
-            acc[1 + NO + k * FT + f] = fma((double)xo[k], (double)dz[f], acc[1 + NO + k * FT + f]);
+      for (int j = 0; j < NPL; ++j) {
+        const int qi = gl + j * G;
+        if (qi < NQ) {
+          const int role = qi / (NIN * CT), rem = qi - role * NIN * CT, in = rem / CT, c = rem - in * CT;
+          acc[j] = fma((double)pick<NIN>(xo, in), pick<2 * CT>(Sf, role * CT + c), acc[j]);
+        }
       }
     }
+    cur = nxt;
   }
 
-  const double mine = block_reduce<NP>(acc, red);
-  if (threadIdx.x < NP) a.part[(int64_t)blockIdx.x * NP + threadIdx.x] = mine;
-  // hand-off to the last block (cdna_hip_programming.md, in-launch split-K reduction): every storing wave
-  // drains its stores, the block meets, ONE lane publishes with an agent-scope release and takes a ticket;
-  // the block that draws the last ticket acquires once and then reads the slabs with plain loads.  The
-  // XCDs' L2s are not coherent with each other: anything weaker returns stale slabs.
+  // block totals: lanes with the same gl hold the same accumulators — butterfly over the lane bits above G,
+  // the four waves in order through LDS; the loss term over all lanes.  Fixed order: reproducible.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) num += __shfl_xor(num, o);
+  if (lane == 0) red[wave][0] = num;
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    double v = acc[j];
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) v += __shfl_xor(v, o);
+    const int qi = gl + j * G;
+    if (lane < G && qi < NQ) red[wave][1 + qi] = v;
+  }
+  __syncthreads();
+  // hand-off to the last block (cdna_hip_programming.md §6 Guideline 16, recipe R1): the slab is stored
+  // WRITE-THROUGH (8-byte relaxed agent-scope atomic stores = sc1), every storing wave drains its stores, the
+  // block meets, ONE lane takes a ticket; the block that draws the last ticket reads every slab with sc1 loads
+  // (relaxed agent-scope atomic loads).  No release / acquire fence: nothing else is handed over, and the XCDs'
+  // L2s — not coherent with each other — are bypassed both ways.
+  if (threadIdx.x < NP) {
+    const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    __hip_atomic_store(a.part + (int64_t)blockIdx.x * NP + threadIdx.x, (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int ticket = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = ticket == (int)gridDim.x - 1;
-    if (is_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
+  if (threadIdx.x == 0)
+    is_last = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.main_blocks - 1;
   __syncthreads();
   if (!is_last) return;
-  // the last block: thread t adds slabs t, t+256, … of every output, then the same block reduction
+  // the last block: 256 threads = NPP output columns x (256 / NPP) interleaved parts of the slab list; a thread
+  // adds its slabs in order (8 independent chains, folded in a fixed order), the parts are folded in order
+  {
+    const int o = threadIdx.x % NPP, part = threadIdx.x / NPP;
+    const int nb = a.main_blocks;
+    double s[8];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) acc[i] = 0.0;
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {
-    const double* P = a.part + (int64_t)b * NP;
+    for (int q = 0; q < 8; ++q) s[q] = 0.0;
+    if (o < NP) {
+      for (int b = part; b < nb; b += 8 * PARTS) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) acc[i] += P[i];
+        for (int q = 0; q < 8; ++q) {
+          const int bb = b + q * PARTS;               // all eight loads issued, then masked: no branch (and wait) per load
+          const double v = __longlong_as_double((long long)__hip_atomic_load(a.part + (int64_t)(bb < nb ? bb : nb - 1) * NP + o,
+                                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          s[q] += bb < nb ? v : 0.0;
+        }
+      }
+    }
+    fin[part][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   }
-  const double total = block_reduce<NP>(acc, red);
-  if (threadIdx.x == 0) {
-    a.loss[0] = (float)(total * invden);
-    *a.sync = 0;                                    // ready for the next launch: no memset node per step
+  __syncthreads();
+  if (threadIdx.x < NP) {
+    double total = 0.0;
+#pragma unroll
+    for (int q = 0; q < PARTS; ++q) total += fin[q][threadIdx.x];
+    fin[0][threadIdx.x] = total;                      // Q totals, for the folded outputs below
+    if (threadIdx.x == 0) {
+      if (a.loss) a.loss[0] = (float)(total * invden);
+      *a.sync = 0;                                    // ready for the next launch: no memset node per step
+    }
+    if constexpr (GRAD && K == 0) {
+      if (threadIdx.x >= 1) a.dU[threadIdx.x - 1] = (float)(total * invden_g);      // Q = [Q_s; Q_d] is dU's layout
+    }
   }
-  if constexpr (GRAD) {
-    if (threadIdx.x >= 1 && threadIdx.x < 1 + NO) a.dU[threadIdx.x - 1] = (float)(total * invden);
-    if (NW && threadIdx.x >= 1 + NO && threadIdx.x < NP) a.dW[threadIdx.x - 1 - NO] = (float)total;
+  if constexpr (GRAD && K != 0) {
+    __syncthreads();
+    const double* Q = &fin[0][1];                     // [role][k][c]
+    const int t = threadIdx.x;
+    if (t < 2 * FT * CT) {                            // dU[role·F + f][c] = Σ_k W[k][f]·Q[role][k][c]
+      const int role = t / (FT * CT), rem = t - role * FT * CT, f = rem / CT, c = rem - f * CT;
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) v = fma((double)a.Wf[k * FT + f], Q[(role * K + k) * CT + c], v);
+      a.dU[t] = (float)(v * invden_g);
+    } else if (t < 2 * FT * CT + K * FT) {            // dW[k][f] = Σ_c Q_s[k][c]·U[f][c] + Q_d[k][c]·U[F+f][c]
+      const int b = t - 2 * FT * CT, k = b / FT, f = b - k * FT;
+      double v = 0.0;
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        v = fma(Q[(K + k) * CT + c], (double)U[(FT + f) * CT + c], fma(Q[k * CT + c], (double)U[f * CT + c], v));
+      a.dW[b] = (float)(v * invden_g);
+    }
   }
 }
 
-constexpr int kHeadLossMaxBlocks = 1024;
-
-static int head_loss_logG(int64_t E, int64_t R) {
-  const int64_t avg = R > 0 ? (2 * E + R - 1) / R : 0;
-  int lg = 0;
-  while (lg < 5 && ((int64_t)2 << lg) < avg) ++lg;   // chains of about two entries per lane, G <= 32
-  return lg;
+static int head_loss_lanes(int64_t E, int64_t n_active) {   // lanes per active row: chains of about two entries
+  const int64_t avg = n_active > 0 ? (2 * E + n_active - 1) / n_active : 0;
+  return avg <= 2 ? 1 : (avg <= 8 ? 4 : 16);
 }
 
-static int head_loss_blocks(int64_t R, int logG) {
-  int64_t b = ((R << logG) + 255) / 256;
-  if (b > kHeadLossMaxBlocks) b = kHeadLossMaxBlocks;
-  if (b < 1) b = 1;
-  return (int)b;
+template <int FT, int CT, bool GRAD, int K>
+static void head_loss_launch_g(HeadLossArgs a, int G, int64_t R, hipStream_t st) {
+  int64_t main_blocks = ((int64_t)a.n_active * G + 255) / 256;
+  if (main_blocks > kHeadLossMaxBlocks) main_blocks = kHeadLossMaxBlocks;
+  if (main_blocks < 1) main_blocks = 1;
+  int64_t blocks = main_blocks;
+  if (GRAD && K == 0) {                               // the zero-fill sweep may use more blocks than there are active rows
+    const int64_t z = (R + 255) / 256;
+    blocks = z > blocks ? z : blocks;
+    if (blocks > kHeadLossMaxBlocks) blocks = kHeadLossMaxBlocks;
+  }
+  a.main_blocks = (int32_t)main_blocks;
+  const dim3 grid((unsigned)blocks), blk(256);
+  switch (G) {
+    case 1: hipLaunchKernelGGL((head_loss_small_kernel<FT, CT, GRAD, K, 1>), grid, blk, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((head_loss_small_kernel<FT, CT, GRAD, K, 4>), grid, blk, 0, st, a); break;
+    default: hipLaunchKernelGGL((head_loss_small_kernel<FT, CT, GRAD, K, 16>), grid, blk, 0, st, a);
+  }
 }
 
 template <int FT, int CT>
-static void head_loss_launch(const HeadLossArgs& a, bool grad, int K, unsigned blocks, hipStream_t st) {
+static void head_loss_launch(const HeadLossArgs& a, bool grad, int K, int G, int64_t R, hipStream_t st) {
   if (K == 0) {
-    if (grad) hipLaunchKernelGGL((head_loss_small_kernel<FT, CT, true, 0>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((head_loss_small_kernel<FT, CT, false, 0>), dim3(blocks), dim3(256), 0, st, a);
+    if (grad) head_loss_launch_g<FT, CT, true, 0>(a, G, R, st);
+    else head_loss_launch_g<FT, CT, false, 0>(a, G, R, st);
   } else {
-    if (grad) hipLaunchKernelGGL((head_loss_small_kernel<FT, CT, true, 2>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((head_loss_small_kernel<FT, CT, false, 2>), dim3(blocks), dim3(256), 0, st, a);
+    if (grad) head_loss_launch_g<FT, CT, true, 2>(a, G, R, st);
+    else head_loss_launch_g<FT, CT, false, 2>(a, G, R, st);
   }
 }
 
 template <int FT>
-static void head_loss_launch_c(const HeadLossArgs& a, int C, bool grad, int K, unsigned blocks, hipStream_t st) {
+static void head_loss_launch_c(const HeadLossArgs& a, int C, bool grad, int K, int G, int64_t R, hipStream_t st) {
   switch (C) {
-    case 1: head_loss_launch<FT, 1>(a, grad, K, blocks, st); break;
-    case 2: head_loss_launch<FT, 2>(a, grad, K, blocks, st); break;
-    case 3: head_loss_launch<FT, 3>(a, grad, K, blocks, st); break;
-    default: head_loss_launch<FT, 4>(a, grad, K, blocks, st);
+    case 2: head_loss_launch<FT, 2>(a, grad, K, G, R, st); break;
+    case 3: head_loss_launch<FT, 3>(a, grad, K, G, R, st); break;
+    default: head_loss_launch<FT, 4>(a, grad, K, G, R, st);
   }
 }
 
@@ -325,45 +428,48 @@ __global__ __launch_bounds__(256) void scale2_kernel(const float* __restrict__ g
 using namespace tmgcn;
 
 extern "C" int tmgcn_head_loss_supported(int32_t F, int32_t C, int32_t K) {
-  return (F >= 2 && F <= 8 && F % 2 == 0 && C >= 1 && C <= 4 && (K == 0 || K == 2)) ? 1 : 0;
+  return (F >= 2 && F <= 8 && F % 2 == 0 && C >= 2 && C <= 4 && (K == 0 || K == 2)) ? 1 : 0;
 }
 
 extern "C" int64_t tmgcn_head_loss_workspace_bytes(int32_t F, int32_t C, int32_t K) {
   if (!tmgcn_head_loss_supported(F, C, K)) return 0;
-  return (int64_t)kHeadLossMaxBlocks * (1 + 2 * F * C + K * F) * (int64_t)sizeof(double);
+  return (int64_t)kHeadLossMaxBlocks * (1 + 2 * (K ? K : F) * C) * (int64_t)sizeof(double);
 }
 
 extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t K, const float* U,
-                                    const int32_t* eptr, const int32_t* ent, const int32_t* other, const uint8_t* tgt,
-                                    const int64_t* class_count, const float* weight, int64_t R, int64_t E, int32_t F,
+                                    const int32_t* eptr, const int32_t* arow, int64_t n_active, const int32_t* ent,
+                                    const int32_t* other, const uint8_t* meta, const int64_t* class_count,
+                                    const float* weight, const float* grad_scale, int64_t R, int64_t E, int32_t F,
                                     int32_t C, float* logits, float* loss, float* dZ, float* dU, float* dW,
                                     void* workspace, int64_t workspace_bytes, int32_t* sync, void* stream) {
-  TMGCN_REQUIRE(tmgcn_head_loss_supported(F, C, K), "head_loss: unsupported widths F=%d C=%d K=%d (even F <= 8, C <= 4, K in {0, 2})",
+  TMGCN_REQUIRE(tmgcn_head_loss_supported(F, C, K), "head_loss: unsupported widths F=%d C=%d K=%d (even F <= 8, 2 <= C <= 4, K in {0, 2})",
                 F, C, K);
-  TMGCN_REQUIRE(R > 0 && E > 0 && R < (int64_t)0x7fffffff && 2 * E < (int64_t)0x7fffffff,
-                "head_loss: need 0 < R, 2E < 2^31 (got R=%lld E=%lld)", (long long)R, (long long)E);
-  TMGCN_REQUIRE(Z && U && eptr && ent && other && tgt && class_count && weight && loss && sync && workspace,
-                "head_loss: null pointer");
+  TMGCN_REQUIRE(R > 0 && E > 0 && R < (int64_t)0x7fffffff && 2 * E < (int64_t)0x7fffffff && n_active > 0 && n_active <= R,
+                "head_loss: need 0 < R, 2E < 2^31 and 0 < n_active <= R (got R=%lld E=%lld n_active=%lld)", (long long)R,
+                (long long)E, (long long)n_active);
+  TMGCN_REQUIRE(Z && U && eptr && arow && other && meta && class_count && weight && sync && workspace, "head_loss: null pointer");
+  TMGCN_REQUIRE(!logits || ent, "head_loss: the logits need the entry -> edge index (ent)");
   TMGCN_REQUIRE((K == 0) == (W_fold == nullptr), "head_loss: W_fold must be given exactly when K > 0");
   const bool grad = dU != nullptr;
+  TMGCN_REQUIRE(grad || loss, "head_loss: nothing to compute (neither loss nor gradients asked for)");
   TMGCN_REQUIRE(!grad || (K ? dW != nullptr : dZ != nullptr), "head_loss: gradients asked for (dU) but no %s", K ? "dW" : "dZ");
   TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(Z) % 8 == 0 && (!dZ || reinterpret_cast<uintptr_t>(dZ) % 8 == 0) &&
-                    (!logits || reinterpret_cast<uintptr_t>(logits) % 16 == 0),
-                "head_loss: Z / dZ must be 8-byte aligned, logits 16-byte aligned");
+                    (!logits || reinterpret_cast<uintptr_t>(logits) % 16 == 0) && reinterpret_cast<uintptr_t>(arow) % 16 == 0,
+                "head_loss: Z / dZ must be 8-byte aligned, logits and arow 16-byte aligned");
   if (workspace_bytes < tmgcn_head_loss_workspace_bytes(F, C, K)) {
     set_error("head_loss: workspace %lld B < required %lld B", (long long)workspace_bytes,
               (long long)tmgcn_head_loss_workspace_bytes(F, C, K));
     return TMGCN_ERR_WORKSPACE;
   }
-  HeadLossArgs a{Z, W_fold, U, eptr, ent, other, tgt, class_count, weight, logits, dZ, (double*)workspace,
-                 loss, dU, dW, sync, R, head_loss_logG(E, R)};
-  const unsigned blocks = (unsigned)head_loss_blocks(R, a.logG);
+  HeadLossArgs a{Z, W_fold, U, eptr, reinterpret_cast<const int4*>(arow), ent, other, meta, class_count, weight, grad_scale,
+                 logits, dZ, (unsigned long long*)workspace, loss, dU, dW, sync, R, (int32_t)n_active, 0};
+  const int G = head_loss_lanes(E, n_active);
   hipStream_t st = (hipStream_t)stream;
   switch (F) {
-    case 2: head_loss_launch_c<2>(a, C, grad, K, blocks, st); break;
-    case 4: head_loss_launch_c<4>(a, C, grad, K, blocks, st); break;
-    case 6: head_loss_launch_c<6>(a, C, grad, K, blocks, st); break;
-    default: head_loss_launch_c<8>(a, C, grad, K, blocks, st);
+    case 2: head_loss_launch_c<2>(a, C, grad, K, G, R, st); break;
+    case 4: head_loss_launch_c<4>(a, C, grad, K, G, R, st); break;
+    case 6: head_loss_launch_c<6>(a, C, grad, K, G, R, st); break;
+    default: head_loss_launch_c<8>(a, C, grad, K, G, R, st);
   }
   return check_launch("head_loss");
 }

@@ -369,23 +369,27 @@ Tensor wce_bwd(const Tensor& logits, const Tensor& target, const Tensor& weight,
   return dz;
 }
 
-// One-pass edge head + weighted CE (+ gradients with upstream gradient 1).  Returns
-// (loss [], logits [E,C] or empty, dZ [R,F] (fold: dW [K,F]) or empty, dU [2F,C] or empty).
+// One-pass edge head + weighted CE (+ gradients, times the device scalar `gscale` when given).  Returns
+// (loss [] or empty, logits [E,C] or empty, dZ [R,F] (fold: dW [K,F]) or empty, dU [2F,C] or empty).
 std::tuple<Tensor, Tensor, Tensor, Tensor> head_loss_fwd(const Tensor& Z, const OptTensor& W_fold, const Tensor& U,
-                                                         const Tensor& eptr, const Tensor& ent, const Tensor& other,
-                                                         const Tensor& tgt, const Tensor& counts, const Tensor& weight,
-                                                         Tensor sync, bool grad, bool want_logits) {
+                                                         const Tensor& eptr, const Tensor& arow, const Tensor& ent,
+                                                         const Tensor& other, const Tensor& meta, const Tensor& counts,
+                                                         const Tensor& weight, Tensor sync, const OptTensor& gscale,
+                                                         bool grad, bool want_logits, bool want_loss) {
   want(Z, "head_loss Z");
   want(U, "head_loss U");
   want(weight, "head_loss weight");
   want(eptr, "head_loss eptr", at::kInt);
+  want(arow, "head_loss arow", at::kInt);
   want(ent, "head_loss ent", at::kInt);
   want(other, "head_loss other", at::kInt);
-  want(tgt, "head_loss tgt", at::kByte);
+  want(meta, "head_loss meta", at::kByte);
   want(counts, "head_loss class counts", at::kLong);
   want(sync, "head_loss sync", at::kInt);
   const bool fold = W_fold.has_value() && W_fold->defined();
   if (fold) want(*W_fold, "head_loss W");
+  const bool scaled = gscale.has_value() && gscale->defined();
+  if (scaled) want(*gscale, "head_loss upstream gradient");
   TORCH_CHECK(Z.dim() == 2 && U.dim() == 2, "head_loss: Z must be [R, F] and U [2F, C]");
   const int64_t R = Z.size(0), K = fold ? Z.size(1) : 0, F = fold ? W_fold->size(1) : Z.size(1), C = U.size(1);
   TORCH_CHECK(!fold || (W_fold->dim() == 2 && W_fold->size(0) == K), "head_loss: W ", fold ? W_fold->sizes() : Z.sizes(),
@@ -393,23 +397,25 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> head_loss_fwd(const Tensor& Z, const 
   TORCH_CHECK(U.size(0) == 2 * F && weight.numel() == C && counts.numel() == C, "head_loss: U ", U.sizes(), " / weight / counts do not match F=",
               F, " C=", C);
   TORCH_CHECK(tmgcn_head_loss_supported((int32_t)F, (int32_t)C, (int32_t)K), "head_loss: unsupported widths F=", F, " C=", C, " K=", K);
-  TORCH_CHECK(eptr.numel() == R + 1 && ent.numel() % 2 == 0 && other.numel() == ent.numel() && tgt.numel() == ent.numel() &&
-                  sync.numel() >= 1,
+  TORCH_CHECK(eptr.numel() == R + 1 && ent.numel() % 2 == 0 && other.numel() == ent.numel() && meta.numel() == ent.numel() &&
+                  arow.dim() == 2 && arow.size(1) == 4 && sync.numel() >= 1,
               "head_loss: plan arrays do not match R=", R);
+  TORCH_CHECK(grad || want_loss, "head_loss: nothing asked for");
   const int64_t E = ent.numel() / 2;
   c10::DeviceGuard g(Z.device());
-  Tensor loss = at::empty({}, Z.options());
+  Tensor loss = want_loss ? at::empty({}, Z.options()) : none_like(Z);
   Tensor logits = want_logits ? at::empty({E, C}, Z.options()) : none_like(Z);
   Tensor dZ = grad ? (fold ? at::empty({K, F}, Z.options()) : at::empty_like(Z)) : none_like(Z);
   Tensor dU = grad ? at::empty_like(U) : none_like(Z);
   const int64_t need = tmgcn_head_loss_workspace_bytes((int32_t)F, (int32_t)C, (int32_t)K);
   Tensor ws = at::empty({need}, Z.options().dtype(at::kByte));
   ok(tmgcn_head_loss_f32((const float*)ptr(Z), fold ? (const float*)ptr(*W_fold) : nullptr, (int32_t)K, (const float*)ptr(U),
-                         (const int32_t*)ptr(eptr), (const int32_t*)ptr(ent), (const int32_t*)ptr(other),
-                         (const uint8_t*)ptr(tgt), (const int64_t*)ptr(counts), (const float*)ptr(weight), R, E, (int32_t)F,
-                         (int32_t)C, (float*)ptr(logits), (float*)loss.data_ptr(), (grad && !fold) ? (float*)ptr(dZ) : nullptr,
-                         grad ? (float*)ptr(dU) : nullptr, (grad && fold) ? (float*)ptr(dZ) : nullptr, ptr(ws), ws.numel(),
-                         (int32_t*)sync.data_ptr(), stream_of(Z)),
+                         (const int32_t*)ptr(eptr), (const int32_t*)ptr(arow), arow.size(0), (const int32_t*)ptr(ent),
+                         (const int32_t*)ptr(other), (const uint8_t*)ptr(meta), (const int64_t*)ptr(counts),
+                         (const float*)ptr(weight), scaled ? (const float*)gscale->data_ptr() : nullptr, R, E, (int32_t)F,
+                         (int32_t)C, (float*)ptr(logits), want_loss ? (float*)loss.data_ptr() : nullptr,
+                         (grad && !fold) ? (float*)ptr(dZ) : nullptr, grad ? (float*)ptr(dU) : nullptr,
+                         (grad && fold) ? (float*)ptr(dZ) : nullptr, ptr(ws), ws.numel(), (int32_t*)sync.data_ptr(), stream_of(Z)),
      "tmgcn_head_loss_f32");
   return {loss, logits, dZ, dU};
 }
@@ -572,30 +578,53 @@ struct EdgeHeadFn : public torch::autograd::Function<EdgeHeadFn> {
   }
 };
 
-// loss (and, as a non-differentiable by-product, the logits) of the fused head + criterion.  The gradients are
-// formed in the SAME launch as the loss (upstream gradient 1) and kept; backward multiplies them by the
-// upstream gradient of the loss in one launch.
+// loss (and, as a non-differentiable by-product, the logits) of the fused head + criterion.  Two schedules:
+//   speculative  the gradients are formed in the SAME launch as the loss (upstream gradient 1) and kept; backward
+//                multiplies them by the upstream gradient of the loss in one small launch.  Taken when the entry
+//                stream outweighs dZ: link prediction (E >> R), and always when the layer-1 GEMM is folded in
+//                (only dW and dU leave the kernel).
+//   deferred     forward = the loss-only form (src-side entries only); backward = the gradient form with the upstream
+//                gradient as a device scalar inside the kernel.  Taken when dZ is the bigger object (classification:
+//                24 k labelled edges among 570 k rows): no pass over dZ just to scale it.
 struct HeadLossFn : public torch::autograd::Function<HeadLossFn> {
   static variable_list forward(AutogradContext* ctx, const Tensor& Z, const OptTensor& W_fold, const Tensor& U,
-                               const Tensor& eptr, const Tensor& ent, const Tensor& other, const Tensor& tgt,
-                               const Tensor& counts, const Tensor& weight, const Tensor& sync, bool want_logits, bool need) {
+                               const Tensor& eptr, const Tensor& arow, const Tensor& ent, const Tensor& other,
+                               const Tensor& meta, const Tensor& counts, const Tensor& weight, const Tensor& sync,
+                               bool want_logits, bool need) {
     at::AutoDispatchBelowADInplaceOrView guard;
     const bool fold = W_fold.has_value() && W_fold->defined();
     Tensor Z2 = Z.contiguous().reshape({-1, Z.size(-1)});
-    auto [loss, logits, dZ, dU] = head_loss_fwd(Z2, W_fold, U, eptr, ent, other, tgt, counts, weight, sync, need, want_logits);
-    if (need) ctx->save_for_backward({dZ, dU});
+    const int64_t R = Z2.size(0), F = fold ? W_fold->size(1) : Z2.size(1), E = ent.numel() / 2;
+    const bool deferred = need && !fold && R * F * 8 > E * 10;
+    auto [loss, logits, dZ, dU] = head_loss_fwd(Z2, W_fold, U, eptr, arow, ent, other, meta, counts, weight, sync, OptTensor(),
+                                                need && !deferred, want_logits, true);
+    if (need && deferred)
+      ctx->save_for_backward({Z2, U, eptr, arow, ent, other, meta, counts, weight, sync});
+    else if (need)
+      ctx->save_for_backward({dZ, dU});
     ctx->saved_data["zshape"] = Z.sizes().vec();
     ctx->saved_data["fold"] = fold;
+    ctx->saved_data["deferred"] = deferred;
     ctx->mark_non_differentiable({logits});
     return {loss, logits};
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     at::AutoDispatchBelowADInplaceOrView guard;
     auto sv = ctx->get_saved_variables();
-    TORCH_CHECK(sv.size() == 2, "head_loss: backward through a call made without gradients");
-    auto [gz, gu] = scale2(grads[0].contiguous().to(at::kFloat), sv[0], sv[1]);
-    const bool fold = ctx->saved_data["fold"].toBool();
-    variable_list out(12);
+    const bool fold = ctx->saved_data["fold"].toBool(), deferred = ctx->saved_data["deferred"].toBool();
+    Tensor g = grads[0].contiguous().to(at::kFloat);
+    Tensor gz, gu;
+    if (deferred) {
+      TORCH_CHECK(sv.size() == 10, "head_loss: backward through a call made without gradients");
+      auto out = head_loss_fwd(sv[0], OptTensor(), sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7], sv[8], sv[9], g, true, false,
+                               false);
+      gz = std::get<2>(out);
+      gu = std::get<3>(out);
+    } else {
+      TORCH_CHECK(sv.size() == 2, "head_loss: backward through a call made without gradients");
+      std::tie(gz, gu) = scale2(g, sv[0], sv[1]);
+    }
+    variable_list out(13);
     if (fold) out[1] = gz; else out[0] = gz.reshape(ctx->saved_data["zshape"].toIntVector());
     out[2] = gu;
     return out;
@@ -655,11 +684,11 @@ Tensor edge_head_ad(const Tensor& Z, const Tensor& U, const Tensor& src, const T
                            at::GradMode::is_enabled() && (Z.requires_grad() || U.requires_grad()));
 }
 std::tuple<Tensor, Tensor> head_loss_ad(const Tensor& Z, const OptTensor& W_fold, const Tensor& U, const Tensor& eptr,
-                                        const Tensor& ent, const Tensor& other, const Tensor& tgt, const Tensor& counts,
-                                        const Tensor& weight, const Tensor& sync, bool want_logits) {
+                                        const Tensor& arow, const Tensor& ent, const Tensor& other, const Tensor& meta,
+                                        const Tensor& counts, const Tensor& weight, const Tensor& sync, bool want_logits) {
   const bool fold = W_fold.has_value() && W_fold->defined();
   const bool need = at::GradMode::is_enabled() && (U.requires_grad() || (fold ? W_fold->requires_grad() : Z.requires_grad()));
-  auto out = HeadLossFn::apply(Z, W_fold, U, eptr, ent, other, tgt, counts, weight, sync, want_logits, need);
+  auto out = HeadLossFn::apply(Z, W_fold, U, eptr, arow, ent, other, meta, counts, weight, sync, want_logits, need);
   return {out[0], out[1]};
 }
 Tensor activation_ad(const Tensor& x, int64_t act) { return ActivationFn::apply(x, act); }
@@ -689,8 +718,9 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("act_bwd(Tensor x, Tensor dy, int act) -> Tensor");
   m.def("wce_fwd(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> (Tensor, Tensor)");
   m.def("wce_bwd(Tensor logits, Tensor target, Tensor weight, Tensor stats, Tensor g, int ignore_index) -> Tensor");
-  m.def("head_loss_fwd(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor ent, Tensor other, Tensor tgt, Tensor counts, "
-        "Tensor weight, Tensor(a!) sync, bool grad, bool want_logits) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("head_loss_fwd(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor arow, Tensor ent, Tensor other, Tensor meta, "
+        "Tensor counts, Tensor weight, Tensor(a!) sync, Tensor? gscale, bool grad, bool want_logits, bool want_loss) -> "
+        "(Tensor, Tensor, Tensor, Tensor)");
   m.def("scale2(Tensor g, Tensor a, Tensor b) -> (Tensor, Tensor)");
   m.def("head_loss_supported(int F, int C, int K) -> bool", &head_loss_supported);
   m.def("spmm_gemm_supported(int K, int Nf) -> bool", &spmm_gemm_supported);
@@ -707,8 +737,8 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("edge_head(Tensor Z, Tensor U, Tensor src, Tensor dst, Tensor? eptr, Tensor? eidx) -> Tensor");
   m.def("activation(Tensor x, int act) -> Tensor");
   m.def("weighted_ce(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> Tensor");
-  m.def("head_loss(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor ent, Tensor other, Tensor tgt, Tensor counts, "
-        "Tensor weight, Tensor(a!) sync, bool want_logits) -> (Tensor, Tensor)");
+  m.def("head_loss(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor arow, Tensor ent, Tensor other, Tensor meta, "
+        "Tensor counts, Tensor weight, Tensor(a!) sync, bool want_logits) -> (Tensor, Tensor)");
 }
 
 // ROCm tensors carry the CUDA dispatch key in PyTorch-ROCm

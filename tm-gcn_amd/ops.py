@@ -105,7 +105,8 @@ class EdgeIndex:
 class HeadLossPlan:
     """What the one-pass head + loss kernel (csrc/head_loss.hip) walks, built once per (edge set, target):
     the inverted edge index of the edge set, and in the same entry order the row of each entry's OTHER
-    endpoint and its edge's target class as one byte (255 = the criterion's ignore_index), plus the
+    endpoint and one byte role << 7 | target class (127 = the criterion's ignore_index), the list of rows that have
+    entries at all, plus the
     number of labelled edges per class (Σ_e w[t_e] = Σ_c count[c]·w[c] for whatever class weights the
     call brings).  A label outside [0, C) other than ignore_index raises here (one host sync per target
     tensor; nn.CrossEntropyLoss device-asserts on it).  `sync` is the launch's hand-off word: zero
@@ -129,8 +130,11 @@ class HeadLossPlan:
         e = (self.ent >> 1).long()
         role = (self.ent & 1).bool()
         self.other = torch.where(role, edges.src[e], edges.dst[e]).to(torch.int32).contiguous()
-        t8 = torch.where(ignored, torch.full_like(t, 255), t).to(torch.uint8)
-        self.tgt = t8[e].contiguous()
+        t8 = torch.where(ignored, torch.full_like(t, 127), t)                     # 7 bits of class, bit 7 = role
+        self.meta = (t8[e] | (role.long() << 7)).to(torch.uint8).contiguous()
+        active = torch.nonzero(self.eptr[1:] > self.eptr[:-1]).flatten()            # rows with at least one entry
+        self.arow = torch.stack((active.to(torch.int32), self.eptr[:-1][active], self.eptr[1:][active],
+                                 torch.zeros_like(active, dtype=torch.int32)), dim=1).contiguous()
         self.counts = torch.bincount(t[~ignored], minlength=C)[:C].to(torch.int64).contiguous()
         self.sync = torch.zeros(1, dtype=torch.int32, device=dev)
         self.R, self.C, self.ignore_index = R, C, ignore_index
@@ -544,8 +548,8 @@ def head_loss(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, target: torch.
         return (loss, logits) if want_logits else loss
     plan = head_loss_plan(edges, R, target, Cn, ignore_index)
     w = weight.detach().to(device=Z.device, dtype=torch.float32).contiguous()
-    loss, logits = kernels.ops.head_loss(Z, fold_W, U.contiguous(), plan.eptr, plan.ent, plan.other, plan.tgt, plan.counts, w,
-                                         plan.sync, bool(want_logits))
+    loss, logits = kernels.ops.head_loss(Z, fold_W, U.contiguous(), plan.eptr, plan.arow, plan.ent, plan.other, plan.meta,
+                                         plan.counts, w, plan.sync, bool(want_logits))
     return (loss, logits) if want_logits else loss
 
 
