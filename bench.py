@@ -263,7 +263,11 @@ def gpu_epochs(g, spec, epochs, mode):
         with torch.no_grad():
             for q in m.parameters():
                 q.mul_(spec["scale"])
-    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+    if mode in ("fused", "graph_fused"):      # the opt-in fused pieces: one-launch head + loss + gradients, one-launch SGD
+        from tmgcn_amd.optim import FusedSGD
+        opt = FusedSGD(m.parameters(), lr=0.01, momentum=0.9)
+    else:
+        opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
     if mode in ("fused", "graph_fused"):
         from tmgcn_amd.losses import WeightedCrossEntropy
         crit = WeightedCrossEntropy(torch.tensor([0.9, 0.1])).cuda()

@@ -273,7 +273,7 @@ int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* w
  *       Z = AtXt·W is recomputed per row, dZ is not stored and dW [2][F] = Σ_r AtXt[r]ᵀ·dZ[r] is returned.
  *   workspace            tmgcn_head_loss_workspace_bytes(F, C, K) bytes
  *   sync                 one int32, ZERO before the first launch; the kernel leaves it zero.  Launches
- *                        that share a sync word must not overlap.
+ *                        that share a sync word must not overlap.  NULL = a word of the library's own pool.
  */
 int tmgcn_head_loss_supported(int32_t F, int32_t C, int32_t K);
 int64_t tmgcn_head_loss_workspace_bytes(int32_t F, int32_t C, int32_t K);
@@ -283,6 +283,15 @@ int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t K, const fl
                         const float* weight, const float* grad_scale, int64_t R, int64_t E, int32_t F,
                         int32_t C, float* logits, float* loss, float* dZ, float* dU, float* dW,
                         void* workspace, int64_t workspace_bytes, int32_t* sync, void* stream);
+/* ---- optimizer step of all parameters in one launch (ABI 4) ------------------------------------
+ * torch.optim.SGD(params, lr, momentum, dampening, weight_decay, nesterov, maximize).step() for up to 16 tensors
+ * (experiment_reddit_our_link_prediction.py:68, 80):  g (+ wd·p);  buf = first_step ? g : m·buf + (1-d)·g;
+ * p -= lr·(nesterov ? g + m·buf : buf).  HOST arrays of DEVICE pointers; all tensors fp32 (bf16 = 0) or all
+ * stored in bf16 (bf16 = 1: widened on load, fp32 arithmetic, rounded to nearest even once).
+ */
+int tmgcn_sgd_step(void* const* params, const void* const* grads, void* const* momentum_bufs, const int64_t* numel,
+                   int32_t n, int32_t bf16, float lr, float momentum, float dampening, float weight_decay,
+                   int32_t nesterov, int32_t maximize, int32_t first_step, void* stream);
 /* out_a = g·a, out_b = g·b (g: one float on the device — the upstream gradient of a scalar loss) */
 int tmgcn_scale2_f32(const float* g, const float* a, float* out_a, int64_t na, const float* b, float* out_b,
                      int64_t nb, void* stream);

@@ -28,6 +28,23 @@ inline int check_launch(const char* what) {
 unsigned int* acquire_tile_counters(hipStream_t stream, int n);  // n consecutive zeroed counters
 inline unsigned int* acquire_tile_counter(hipStream_t stream) { return acquire_tile_counters(stream, 1); }
 
+// A hand-off word for a kernel whose last block finishes a reduction (pointwise.hip owns the pool): zero when
+// the launch starts, left zero by the launch — no memset node per call.
+int32_t* acquire_sync_word(hipStream_t stream);
+
+// Called by EVERY thread of a block after its slab stores (write-through: 4- / 8-byte relaxed agent-scope atomic
+// stores): drains the stores, meets, takes ONE ticket; true in every thread of the block that drew the last one.
+// That block then reads the slabs with relaxed agent-scope atomic loads (cdna_hip_programming.md §6 Guideline 16,
+// recipe R1: no release / acquire fence when every handed-off byte is stored and loaded write-through).
+__device__ __forceinline__ bool last_block_ticket(int32_t* sync, int n_blocks, int* lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    *lds_flag = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_blocks - 1;
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
 #define TMGCN_REQUIRE(cond, ...)            \
   do {                                      \
     if (!(cond)) {                          \

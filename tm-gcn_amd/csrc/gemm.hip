@@ -652,6 +652,9 @@ struct DwArgs {
   int64_t batch_rows;
   int32_t chunks;  // row chunks per batch
   int64_t rows_per_chunk;
+  float* dW = nullptr;       // narrow kernel: the last block to finish reduces the slabs into dW itself
+  int32_t* sync = nullptr;   //   (hand-off word: zero on entry, left zero)
+  int32_t n_batch = 1;
 };
 
 // grid: x = batch*chunks + chunk, y = 128x128 output tile (ky * n_tiles_n + ny)
@@ -1241,9 +1244,49 @@ __global__ __launch_bounds__(256) void gemm_dw_narrow_kernel(DwArgs a) {
       if (lane == 0) red[wave][k * NT + n] = v;
     }
   __syncthreads();
+  // slab stored write-through (4-byte relaxed agent-scope atomic store); the last block to finish adds the slabs
+  // of every batch in a fixed order and writes dW — no second launch (common.h: last_block_ticket)
   if (threadIdx.x < NO)
-    a.part[(int64_t)blockIdx.x * NO + threadIdx.x] =
-        (float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(a.part) + (int64_t)blockIdx.x * NO + threadIdx.x,
+                       __float_as_uint((float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x])),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __shared__ int is_last;
+  if (!last_block_ticket(a.sync, (int)gridDim.x, &is_last)) return;
+  if (threadIdx.x == 0) *a.sync = 0;
+  const unsigned* P = reinterpret_cast<const unsigned*>(a.part);
+  if (a.n_batch == 1) {
+    // one output matrix: 64 columns (outputs, NO <= 64) x 4 interleaved parts of the chunk list, 8 loads in flight
+    __shared__ double fin[4][64];
+    const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
+    double s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = 0.0;
+    if (o < NO) {
+      for (int c = part; c < a.chunks; c += 32) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int cc = c + 4 * q;
+          const float v = __uint_as_float(__hip_atomic_load(P + (int64_t)(cc < a.chunks ? cc : a.chunks - 1) * NO + o,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          s[q] += cc < a.chunks ? (double)v : 0.0;
+        }
+      }
+    }
+    fin[part][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (threadIdx.x < NO)
+      a.dW[threadIdx.x] = (float)((fin[0][threadIdx.x] + fin[1][threadIdx.x]) + (fin[2][threadIdx.x] + fin[3][threadIdx.x]));
+  } else {
+    // one weight per slice: few chunks per batch, many outputs — a thread per output walks its chunks in order
+    const int64_t total = (int64_t)a.n_batch * NO;
+    for (int64_t idx = threadIdx.x; idx < total; idx += 256) {
+      const int64_t b = idx / NO, o = idx - b * NO;
+      double sum = 0.0;
+      for (int c = 0; c < a.chunks; ++c)
+        sum += (double)__uint_as_float(__hip_atomic_load(P + (b * a.chunks + c) * NO + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      a.dW[idx] = (float)sum;
+    }
+  }
 }
 
 // dW[b][o] = sum over chunks of part[b][chunk][o].  A block owns 64 consecutive outputs; its sixteen
@@ -1459,6 +1502,10 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
   DwArgs a{A, dY, (float*)workspace, R, K, Nf, rows_per_batch ? rows_per_batch : R, chunks, rpc};
   const unsigned gx = (unsigned)(nb * chunks);
   if (narrow) {
+    a.dW = dW;
+    a.n_batch = (int32_t)nb;
+    a.sync = acquire_sync_word(st);
+    TMGCN_REQUIRE(a.sync, "gemm_dw: no hand-off word");
 #define TMGCN_DWN_N(KT_)                                                                             \
   switch (Nf) {                                                                                      \
     case 2: hipLaunchKernelGGL((gemm_dw_narrow_kernel<KT_, 2>), dim3(gx), dim3(256), 0, st, a); break; \
@@ -1473,6 +1520,7 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
       default: TMGCN_DWN_N(8)
     }
 #undef TMGCN_DWN_N
+    return check_launch("gemm_dw_narrow");          // reduced by its own last block
   } else if (use_small(K, Nf)) {
     const size_t smem = (size_t)DW_ROWS * (K + Nf) * sizeof(float);
     hipLaunchKernelGGL(gemm_dw_small_kernel, dim3(gx), dim3(256), smem, st, a);

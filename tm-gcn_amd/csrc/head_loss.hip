@@ -82,7 +82,7 @@ __device__ __forceinline__ void load_in(const float* __restrict__ base, int64_t 
   }
 }
 
-constexpr int kHeadLossMaxBlocks = 1024;
+constexpr int kHeadLossMaxBlocks = 2048;
 
 // What a lane gathers per endpoint is the row's INPUT of NIN floats: the embedding row itself (K = 0, NIN = F)
 // or, folded (K = 2), the AtXt row — then the head the logits see is H = W·U (per role), i.e.
@@ -305,12 +305,7 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
     __hip_atomic_store(a.part + (int64_t)blockIdx.x * NP + threadIdx.x, (unsigned long long)__double_as_longlong(v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0)
-    is_last = __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.main_blocks - 1;
-  __syncthreads();
-  if (!is_last) return;
+  if (!last_block_ticket(a.sync, a.main_blocks, &is_last)) return;
   // the last block: 256 threads = NPP output columns x (256 / NPP) interleaved parts of the slab list; a thread
   // adds its slabs in order (8 independent chains, folded in a fixed order), the parts are folded in order
   {
@@ -447,7 +442,9 @@ extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t 
   TMGCN_REQUIRE(R > 0 && E > 0 && R < (int64_t)0x7fffffff && 2 * E < (int64_t)0x7fffffff && n_active > 0 && n_active <= R,
                 "head_loss: need 0 < R, 2E < 2^31 and 0 < n_active <= R (got R=%lld E=%lld n_active=%lld)", (long long)R,
                 (long long)E, (long long)n_active);
-  TMGCN_REQUIRE(Z && U && eptr && arow && other && meta && class_count && weight && sync && workspace, "head_loss: null pointer");
+  TMGCN_REQUIRE(Z && U && eptr && arow && other && meta && class_count && weight && workspace, "head_loss: null pointer");
+  if (!sync) sync = acquire_sync_word((hipStream_t)stream);
+  TMGCN_REQUIRE(sync, "head_loss: no hand-off word");
   TMGCN_REQUIRE(!logits || ent, "head_loss: the logits need the entry -> edge index (ent)");
   TMGCN_REQUIRE((K == 0) == (W_fold == nullptr), "head_loss: W_fold must be given exactly when K > 0");
   const bool grad = dU != nullptr;

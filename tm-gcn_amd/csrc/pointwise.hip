@@ -32,6 +32,37 @@ unsigned int* acquire_tile_counters(hipStream_t stream, int n) {
   return c;
 }
 
+// Hand-off words of the kernels whose LAST block finishes a reduction (head_loss, the narrow dW): a word is zero
+// when a launch starts and the launch leaves it zero, so no memset node precedes the kernel.  Launches in
+// flight at the same time must not share a word: eager launches walk the lower half of the pool round-robin (two
+// of them would have to be 1024 launches apart and still overlap), launches recorded into a hipGraph take a word of
+// the upper half for good (a replayed graph meets only its own words).
+constexpr int kSyncPool = 2048;
+__device__ int g_sync_words[kSyncPool];
+
+int32_t* acquire_sync_word(hipStream_t stream) {
+  static int32_t* base[kMaxDevices] = {nullptr};
+  static std::atomic<unsigned> next_eager{0}, next_captured{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= kMaxDevices) dev = 0;
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sync_words)) != hipSuccess) return nullptr;
+    base[dev] = static_cast<int32_t*>(p);
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    cs = hipStreamCaptureStatusNone;
+  }
+  if (cs == hipStreamCaptureStatusActive) {
+    const unsigned k = next_captured.fetch_add(1);
+    return base[dev] + kSyncPool / 2 + (k % (kSyncPool / 2));   // > 1024 recorded launches: wraps (documented limit)
+  }
+  return base[dev] + (next_eager.fetch_add(1) % (kSyncPool / 2));
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -83,6 +114,56 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// One launch for the optimizer step of every parameter (the scripts' t.optim.SGD(gcn.parameters(), lr, momentum):
+// experiment_reddit_our_link_prediction.py:68, 80) — torch's foreach implementation is three to four launches plus
+// a zero-fill per parameter list.  fp32 arithmetic; bf16-stored tensors are widened on load and rounded once.
+constexpr int kSgdMaxTensors = 16;
+struct SgdArgs {
+  void* param[kSgdMaxTensors];
+  const void* grad[kSgdMaxTensors];
+  void* buf[kSgdMaxTensors];
+  int32_t first_block[kSgdMaxTensors + 1];
+  int32_t numel[kSgdMaxTensors];
+  int32_t n, bf16;
+  float lr, momentum, dampening, weight_decay;
+  int32_t nesterov, maximize, first_step;
+};
+
+__device__ __forceinline__ float ld_elem(const void* p, int i, int bf16) {
+  if (bf16) return __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(p)[i] << 16);
+  return reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st_elem(void* p, int i, int bf16, float v) {
+  if (bf16) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);                  // round to nearest even (NaN payloads aside: weights are finite)
+    reinterpret_cast<uint16_t*>(p)[i] = (uint16_t)(u >> 16);
+  } else {
+    reinterpret_cast<float*>(p)[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_step_kernel(SgdArgs a) {
+  int t = 0;
+#pragma unroll
+  for (int k = 1; k < kSgdMaxTensors; ++k)
+    if (k < a.n && (int)blockIdx.x >= a.first_block[k]) t = k;
+  const int i = ((int)blockIdx.x - a.first_block[t]) * 256 + threadIdx.x;
+  if (i >= a.numel[t]) return;
+  float p = ld_elem(a.param[t], i, a.bf16);
+  float g = ld_elem(a.grad[t], i, a.bf16);
+  if (a.maximize) g = -g;
+  if (a.weight_decay != 0.f) g = fmaf(a.weight_decay, p, g);
+  if (a.momentum != 0.f) {
+    float b;
+    if (a.first_step) b = g;
+    else b = __fmul_rn(a.momentum, ld_elem(a.buf[t], i, a.bf16)) + (1.f - a.dampening) * g;   // buf.mul_(m).add_(g, alpha=1-d)
+    st_elem(a.buf[t], i, a.bf16, b);
+    g = a.nesterov ? fmaf(a.momentum, b, g) : b;
+  }
+  st_elem(a.param[t], i, a.bf16, fmaf(-a.lr, g, p));
+}
+
 static unsigned stream_grid(int64_t n) {
   int64_t b = (n / 4 + 255) / 256;
   if (b < 1) b = 1;
@@ -120,4 +201,38 @@ extern "C" int tmgcn_act_bwd_f32(const float* x, const float* dy, float* dx, int
   hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx,
                      n, act, vec);
   return check_launch("act_bwd");
+}
+
+extern "C" int tmgcn_sgd_step(void* const* params, const void* const* grads, void* const* momentum_bufs, const int64_t* numel,
+                              int32_t n, int32_t bf16, float lr, float momentum, float dampening, float weight_decay,
+                              int32_t nesterov, int32_t maximize, int32_t first_step, void* stream) {
+  TMGCN_REQUIRE(n >= 0 && n <= kSgdMaxTensors, "sgd_step: 0 <= n <= %d tensors per call (got %d)", kSgdMaxTensors, n);
+  if (n == 0) return TMGCN_OK;
+  TMGCN_REQUIRE(params && grads && numel && (momentum == 0.f || momentum_bufs), "sgd_step: null pointer");
+  SgdArgs a{};
+  int64_t blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    TMGCN_REQUIRE(params[k] && grads[k] && numel[k] >= 0 && numel[k] < (int64_t)0x7fffffff && (momentum == 0.f || momentum_bufs[k]),
+                  "sgd_step: tensor %d: null pointer or bad size", k);
+    a.param[k] = params[k];
+    a.grad[k] = grads[k];
+    a.buf[k] = momentum != 0.f ? momentum_bufs[k] : nullptr;
+    a.numel[k] = (int32_t)numel[k];
+    a.first_block[k] = (int32_t)blocks;
+    blocks += (numel[k] + 255) / 256;
+    TMGCN_REQUIRE(blocks < (int64_t)0x7fffffff, "sgd_step: too many elements for one launch");
+  }
+  a.first_block[n] = (int32_t)blocks;
+  a.n = n;
+  a.bf16 = bf16;
+  a.lr = lr;
+  a.momentum = momentum;
+  a.dampening = dampening;
+  a.weight_decay = weight_decay;
+  a.nesterov = nesterov;
+  a.maximize = maximize;
+  a.first_step = first_step;
+  if (blocks == 0) return TMGCN_OK;
+  hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("sgd_step");
 }

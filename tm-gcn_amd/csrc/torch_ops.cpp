@@ -432,6 +432,39 @@ std::tuple<Tensor, Tensor> scale2(const Tensor& g, const Tensor& a, const Tensor
   return {oa, ob};
 }
 
+// Optimizer step of up to 16 parameters in one launch (torch.optim.SGD semantics; tmgcn_amd.optim.FusedSGD).
+void sgd_step(at::TensorList params, at::TensorList grads, at::TensorList bufs, double lr, double momentum,
+              double dampening, double weight_decay, bool nesterov, bool maximize, bool first_step) {
+  const int64_t n = (int64_t)params.size();
+  TORCH_CHECK(n >= 1 && n <= 16 && (int64_t)grads.size() == n && (momentum == 0.0 || (int64_t)bufs.size() == n),
+              "sgd_step: 1..16 parameters with as many gradients (and momentum buffers)");
+  const auto dt = params[0].scalar_type();
+  TORCH_CHECK(dt == at::kFloat || dt == at::kBFloat16, "sgd_step: fp32 or bf16 parameters");
+  void* pp[16];
+  const void* gp[16];
+  void* bp[16];
+  int64_t ne[16];
+  for (int64_t k = 0; k < n; ++k) {
+    want(params[k], "sgd_step parameter", dt);
+    want(grads[k], "sgd_step gradient", dt);
+    TORCH_CHECK(grads[k].numel() == params[k].numel() && params[k].device() == params[0].device(), "sgd_step: tensor ", k,
+                " does not match");
+    pp[k] = params[k].data_ptr();
+    gp[k] = grads[k].const_data_ptr();
+    bp[k] = nullptr;
+    if (momentum != 0.0) {
+      want(bufs[k], "sgd_step momentum buffer", dt);
+      TORCH_CHECK(bufs[k].numel() == params[k].numel(), "sgd_step: momentum buffer ", k, " does not match");
+      bp[k] = bufs[k].data_ptr();
+    }
+    ne[k] = params[k].numel();
+  }
+  c10::DeviceGuard g(params[0].device());
+  ok(tmgcn_sgd_step(pp, gp, bp, ne, (int32_t)n, dt == at::kBFloat16 ? 1 : 0, (float)lr, (float)momentum, (float)dampening,
+                    (float)weight_decay, nesterov ? 1 : 0, maximize ? 1 : 0, first_step ? 1 : 0, stream_of(params[0])),
+     "tmgcn_sgd_step");
+}
+
 bool spmm_gemm_supported(int64_t K, int64_t Nf) { return tmgcn_spmm_gemm_supported((int32_t)K, (int32_t)Nf) != 0; }
 bool edge_head_supported(int64_t F, int64_t C) { return tmgcn_edge_head_supported((int32_t)F, (int32_t)C) != 0; }
 bool head_loss_supported(int64_t F, int64_t C, int64_t K) { return tmgcn_head_loss_supported((int32_t)F, (int32_t)C, (int32_t)K) != 0; }
@@ -722,6 +755,8 @@ TORCH_LIBRARY(tmgcn, m) {
         "Tensor counts, Tensor weight, Tensor(a!) sync, Tensor? gscale, bool grad, bool want_logits, bool want_loss) -> "
         "(Tensor, Tensor, Tensor, Tensor)");
   m.def("scale2(Tensor g, Tensor a, Tensor b) -> (Tensor, Tensor)");
+  m.def("sgd_step(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] bufs, float lr, float momentum, float dampening, "
+        "float weight_decay, bool nesterov, bool maximize, bool first_step) -> ()");
   m.def("head_loss_supported(int F, int C, int K) -> bool", &head_loss_supported);
   m.def("spmm_gemm_supported(int K, int Nf) -> bool", &spmm_gemm_supported);
   m.def("edge_head_supported(int F, int C) -> bool", &edge_head_supported);
@@ -758,6 +793,7 @@ TORCH_LIBRARY_IMPL(tmgcn, CUDA, m) {
   m.impl("wce_bwd", &wce_bwd);
   m.impl("head_loss_fwd", &head_loss_fwd);
   m.impl("scale2", &scale2);
+  m.impl("sgd_step", &sgd_step);
   // below the Autograd key (inference mode, or called from inside another autograd node) the
   // differentiable operators are their plain forwards
   m.impl("m_transform", &m_transform_ad);
