@@ -17,10 +17,6 @@
 #include "common.h"
 #include "spmm_row.h"
 
-#ifndef TMGCN_FUSED_XCD_SWEEPS
-#define TMGCN_FUSED_XCD_SWEEPS 0
-#endif
-
 namespace tmgcn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -31,24 +27,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 #ifndef TMGCN_FUSED_U
 #define TMGCN_FUSED_U 4     // gathers in flight per lane (F = 64 / 128 variants)
-#endif
-
-#ifndef TMGCN_FUSED_LDS_PAD
-#define TMGCN_FUSED_LDS_PAD 0
-#endif
-// EXPERIMENT ("16-byte epilogue"): transpose each 4x4 accumulator block across its
-// lane quad (common.h quad_transpose4) so that a lane stores four consecutive COLUMNS of one row with
-// one 16-byte store instead of four 4-byte stores of one column of four rows.  A/B in
-// profiles/r3*_ab_fused_variants.txt; off by default unless it pays.
-#ifndef TMGCN_FUSED_QT
-#define TMGCN_FUSED_QT 0
-#endif
-// EXPERIMENT (round 3): software prefetch of the index stream in phase 1 — the row pointers of the row
-// after next and the first 64 (col, val) pairs of the next row are requested before the current row's
-// gathers, so that the rowptr -> (col, val) -> gather dependency chain of a row overlaps the gathers
-// of the row before it.  A/B in profiles/r3*_ab_fused_prefetch.txt.
-#ifndef TMGCN_FUSED_PREFETCH
-#define TMGCN_FUSED_PREFETCH 0
 #endif
 
 constexpr int FBM = 64;         // rows per tile
@@ -79,7 +57,7 @@ struct FusedArgs {
 
 template <int LPR, int U, int NJ>  // NJ = K / 8 (K is a multiple of 8 here)
 __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedArgs a) {
-  __shared__ float As[FBM * FLDA + TMGCN_FUSED_LDS_PAD];  // (pad: occupancy experiments only)
+  __shared__ float As[FBM * FLDA];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 31;
@@ -95,24 +73,10 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
 
   for (;;) {
     // next tile from the device counter (ascending, so resident blocks stay inside one slice)
-#if TMGCN_FUSED_XCD_SWEEPS
-    // EXPERIMENT (not the default; DESIGN.md §4 "XCD-aware order"): workgroups are dealt to the 8 XCDs
-    // round-robin, so blockIdx.x % 8 names the XCD; each XCD sweeps its own eighth of the tiles (its
-    // own slices) from its own counter.  Slower: eight 1-GB gather windows compete for the shared
-    // 256 MB Infinity Cache instead of one, and a 4 MB L2 holds none of them either way.
-    const unsigned sweep = blockIdx.x % TMGCN_FUSED_XCD_SWEEPS;
-    const int64_t per_sweep = (a.n_tiles + TMGCN_FUSED_XCD_SWEEPS - 1) / TMGCN_FUSED_XCD_SWEEPS;
-    if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter + sweep, 1u);
-    __syncthreads();
-    if ((int64_t)s_tile >= per_sweep) break;
-    const int64_t tile = sweep * per_sweep + s_tile;
-    if (tile >= a.n_tiles) break;
-#else
     if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter, 1u);
     __syncthreads();
     const int64_t tile = s_tile;
     if (tile >= a.n_tiles) break;
-#endif
     const int64_t batch = tile / a.tiles_per_batch;
     const int64_t row0 = batch * batch_rows + (tile % a.tiles_per_batch) * FBM;
     int64_t row_end = (batch + 1) * batch_rows;
@@ -135,53 +99,6 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
     }
 
     // ---- phase 1: gather 16 rows per wave into the LDS tile
-#if TMGCN_FUSED_PREFETCH
-    {
-      // two-deep software pipeline over this wave's rows rr = wave, wave+4, …: (b1, e1, c1, v1) belong to
-      // the row being gathered, (b2, e2) to the next one; rows past the tile / the matrix are empty
-      auto bounds = [&](int rr, int64_t& b, int64_t& e) {
-        const int64_t r = row0 + rr;
-        b = e = 0;
-        if (rr < FBM && r < row_end) {
-          b = a.rowptr[r];
-          e = a.rowptr[r + 1];
-        }
-      };
-      auto first = [&](int64_t b, int64_t e, int& c, float& v) {
-        c = 0;
-        v = 0.f;
-        if (b + lane < e) {
-          c = a.col[b + lane];
-          v = a.val[b + lane];
-        }
-      };
-      int64_t b1, e1, b2, e2;
-      int c1;
-      float v1;
-      bounds(wave, b1, e1);
-      bounds(wave + 4, b2, e2);
-      first(b1, e1, c1, v1);
-      for (int rr = wave; rr < FBM; rr += 4) {
-        const int64_t r = row0 + rr;
-        int64_t b3, e3;
-        bounds(rr + 8, b3, e3);                       // row pointers two rows ahead
-        int c2;
-        float v2;
-        first(b2, e2, c2, v2);                        // index pairs one row ahead
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < row_end) {
-          const int64_t slice = r / a.N;
-          acc = gather_row<LPR, U, true>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, b1, e1, F4, lane, c1, v1);
-        }
-        if (lane < LPR && lane < F4) {
-          *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
-          if (a.AX && r < row_end) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
-        }
-        b1 = b2; e1 = e2; c1 = c2; v1 = v2;
-        b2 = b3; e2 = e3;
-      }
-    }
-#else
     for (int rr = wave; rr < FBM; rr += 4) {
       const int64_t r = row0 + rr;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -195,67 +112,39 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
         if (a.AX && r < row_end) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
       }
     }
-#endif
     __syncthreads();
 
     // ---- phase 2: tile · Wop on the matrix cores
     if (n0 < a.Nf) {
-      f32x16 acc[FBM / 32];
-#pragma unroll
-      for (int mb = 0; mb < FBM / 32; ++mb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
-      // A fragments are fetched one k-group ahead of the MFMAs that use them; the
-      // sched_barrier keeps hipcc from hoisting all 32 ds_read_b128 (128 VGPRs) to the top.
+      // One 32-row half of the tile at a time: its 16 accumulators are stored before the other half's products
+      // start, so only ONE accumulator set is live next to the 64 W-fragment registers (both halves live — the
+      // round 1-3 form — cost 15 spilled VGPRs at 4 waves per SIMD; profiles/r4*_ab_fused_spill.txt).
+      // A fragments are fetched one k-group ahead of the MFMAs that use them; the sched_barrier keeps hipcc
+      // from hoisting all the ds_read_b128 to the top.
       const float* Arow = &As[li * FLDA + 4 * lh];
-      float4 av_next = *reinterpret_cast<const float4*>(Arow);
+      const int n = n0 + li;
 #pragma unroll
       for (int mb = 0; mb < FBM / 32; ++mb) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float4 av_next = *reinterpret_cast<const float4*>(Arow + mb * 32 * FLDA);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          {
-            const float4 av = av_next;
-            const bool last = (j + 1 >= nj);
-            if (!(last && mb + 1 == FBM / 32)) {
-              const int mbn = last ? mb + 1 : mb, jn = last ? 0 : j + 1;
-              av_next = *reinterpret_cast<const float4*>(Arow + mbn * 32 * FLDA + 8 * jn);
-            }
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wreg[j][0], acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wreg[j][1], acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wreg[j][2], acc[mb], 0, 0, 0);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wreg[j][3], acc[mb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          const float4 av = av_next;
+          if (j + 1 < nj) av_next = *reinterpret_cast<const float4*>(Arow + mb * 32 * FLDA + 8 * (j + 1));
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wreg[j][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wreg[j][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wreg[j][2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wreg[j][3], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-      }
-      const int n = n0 + li;
-#if TMGCN_FUSED_QT
-      if (a.Nf % 4 == 0) {  // wave-uniform: whole column quads are in or out of range
-        const int j = li & 3, nq = n0 + 4 * (li >> 2);
-#pragma unroll
-        for (int mb = 0; mb < FBM / 32; ++mb) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            float v[4] = {acc[mb][4 * g], acc[mb][4 * g + 1], acc[mb][4 * g + 2], acc[mb][4 * g + 3]};
-            quad_transpose4(v, j);  // lane j of the quad now owns row 8g + 4lh + j, columns nq .. nq+3
-            const int64_t r = row0 + mb * 32 + 8 * g + 4 * lh + j;
-            if (r < row_end && nq < a.Nf) {
-              if (a.pre) store_f4(reinterpret_cast<float4*>(&a.pre[r * a.Nf + nq]), make_float4(v[0], v[1], v[2], v[3]));
-              store_f4(reinterpret_cast<float4*>(&a.Y[r * a.Nf + nq]),
-                       make_float4(act_apply(v[0], a.act), act_apply(v[1], a.act), act_apply(v[2], a.act), act_apply(v[3], a.act)));
-            }
-          }
-        }
-      } else
-#endif
-      if (n < a.Nf) {
-#pragma unroll
-        for (int mb = 0; mb < FBM / 32; ++mb) {
+        if (n < a.Nf) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int64_t r = row0 + mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
             if (r < row_end) {
-              const float s = acc[mb][i];
+              const float s = acc[i];
               if (a.pre) store_f1(&a.pre[r * a.Nf + n], s);
               store_f1(&a.Y[r * a.Nf + n], act_apply(s, a.act));
             }
