@@ -16,9 +16,22 @@ def load(build_if_stale: bool = True):
     if _LIB is not None:
         return _LIB
     path, src = os.path.join(HERE, "libtmgcn_ref.so"), os.path.join(HERE, "tmgcn_ref.c")
-    stale = not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path))
-    if stale and build_if_stale:
-        subprocess.check_call(["make", "-C", HERE])
+    override = os.environ.get("TMGCN_REF_LIB")      # tests/sanitize: the -fsanitize=address,undefined build of the same source
+    if override:
+        path, build_if_stale = override, False
+    def stale():
+        return not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path))
+
+    if stale() and build_if_stale:
+        # several processes may get here at once (the ranks of a multi-GPU bench after a fresh checkout): one builds,
+        # the others wait on the lock and find the library fresh; the build runs without the profiler / preload
+        # variables a GPU rank may carry
+        import fcntl
+        with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if stale():
+                env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS"))}
+                subprocess.check_call(["make", "-C", HERE], env=env)
     lib = C.CDLL(path)
     p, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.ref_mtransform.argtypes = [p, C.c_int, C.c_int, p, p, i64]

@@ -32,8 +32,11 @@ MERGE_MAX_BAND = 64   # slices the band of M may reach from one output slice in 
 class DeviceCOO:
     """A batched COO on the device: int64-viewed uint64 keys (slice*N+row)*N+col, fp32 values."""
 
-    def __init__(self, key: torch.Tensor, val: torch.Tensor, T: int, N: int):
+    def __init__(self, key: torch.Tensor, val: torch.Tensor, T: int, N: int, sorted_reduced: bool = False):
         self.key, self.val, self.T, self.N = key, val, T, N
+        # keys ascending and distinct (the state sort_reduce leaves): what to_csr and the merge kernels assume.
+        # Steps that need it sort first when the flag is not set, instead of silently building a wrong CSR.
+        self.sorted_reduced = sorted_reduced
 
     @property
     def n(self) -> int:
@@ -72,7 +75,7 @@ class DeviceCOO:
         m = int(cnt.item())  # plan-time sync: the number of distinct entries is data dependent
         if m and int(ko[m - 1].item()) == SENTINEL:
             m -= 1
-        return DeviceCOO(ko[:m].contiguous(), vo[:m].contiguous(), self.T, self.N)
+        return DeviceCOO(ko[:m].contiguous(), vo[:m].contiguous(), self.T, self.N, sorted_reduced=True)
 
     def _expand(self, fn_name: str, fan: int, *args) -> "DeviceCOO":
         lib = _lib.load()
@@ -91,16 +94,18 @@ class DeviceCOO:
     @staticmethod
     def from_csr(A: BatchedCSR) -> "DeviceCOO":
         """Batched CSR -> sorted, reduced COO keys (slice*N + row)*N + col."""
-        return DeviceCOO((A.row_ids() * A.N + A.col.long()).contiguous(), A.val, A.T, A.N)
+        return DeviceCOO((A.row_ids() * A.N + A.col.long()).contiguous(), A.val, A.T, A.N, sorted_reduced=True)
 
     def edge_life(self, window: int, algo: str = "auto") -> "DeviceCOO":
         """B'[t] = B[t] + B[t-1] + … + B[t-window+1] — read_data.py:116-125.  That is the mode-1 product
         with a lower band of ones, so it runs as the same segmented merge as the M-product (no
         `window`-fold expansion, no sort) whenever the window fits the merge kernel; `algo="expand"`
-        keeps the expand + sort + reduce form.  The input must be sorted and reduced (it is, after
-        `sort_reduce` / `symmetrise`)."""
+        keeps the expand + sort + reduce form.  An input that is not sorted and reduced yet (a raw
+        `from_edges` list) is sorted first."""
         if window <= 1:
             return self
+        if not self.sorted_reduced:
+            return self.sort_reduce().edge_life(window, algo)
         if algo == "auto":
             algo = "merge" if window <= MERGE_MAX_BAND else "expand"
         if algo == "merge":
@@ -112,6 +117,8 @@ class DeviceCOO:
     def add_identity_and_normalise(self) -> "DeviceCOO":
         """C = D^-1/2 (B + I) D^-1/2, D = row sums of B + I — read_data.py:130-169."""
         lib = _lib.load()
+        if not self.sorted_reduced:
+            return self.sort_reduce().add_identity_and_normalise()
         dev = self.val.device
         TN = self.T * self.N
         ik = torch.empty(TN, dtype=torch.int64, device=dev)
@@ -133,7 +140,10 @@ class DeviceCOO:
         return self._expand("tmgcn_adj_mproduct_expand", lo + hi + 1, self.T, _ptr(op.M), op.T, lo, hi).sort_reduce()
 
     def to_csr(self) -> BatchedCSR:
-        """Sorted, reduced COO -> batched CSR (rowptr by binary search of the keys, col = key mod N)."""
+        """Sorted, reduced COO -> batched CSR (rowptr by binary search of the keys, col = key mod N); an unsorted
+        list is sorted and reduced first."""
+        if not self.sorted_reduced:
+            return self.sort_reduce().to_csr()
         lib = _lib.load()
         dev = self.val.device
         TN = self.T * self.N

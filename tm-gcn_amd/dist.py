@@ -133,16 +133,26 @@ def cu_mask_words(n_cu: int, cus_free: int) -> List[int]:
     return mask
 
 
-def cu_masked_stream(device, cus_free: int):
+_MASKED_STREAMS = {}     # (device index, cus_free, lane) -> torch.cuda.ExternalStream; created once per process
+
+
+def cu_masked_stream(device, cus_free: int, lane: int = 0):
     """A HIP stream whose kernels may run on all CUs of `device` but the last `cus_free`
     (hipExtStreamCreateWithCUMask), as a torch stream.  The pipelined sharded layer launches its
     persistent kernels on such streams so that RCCL's kernels — 256-thread workgroups of 132 VGPRs
     and 20 KB of LDS each (rocprofv3, RCCL 2.26): one does NOT fit beside three 128-VGPR blocks of
     the fused kernel on a CU, so leaving a block slot per CU free gives them nothing — always find
     whole CUs to become resident on.  The gather is bound by requests in flight, not by CUs: giving
-    up 16 of 256 CUs costs it about 1 %."""
+    up 16 of 256 CUs costs it about 1 %.
+    The raw HIP streams are never destroyed, so they are created once per (device, cus_free, lane) and
+    shared by every layer of the process.  Launch only COUNTER-scheduled persistent kernels on them (the fused
+    SpMM+GEMM draws its tiles from a device counter): a kernel with a static blockIdx-strided schedule sizes its
+    grid for all CUs and would run the blocks of the masked CUs as a serial tail."""
     import ctypes as C
     device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(cus_free), int(lane))
+    if key in _MASKED_STREAMS:
+        return _MASKED_STREAMS[key]
     mask = cu_mask_words(torch.cuda.get_device_properties(device).multi_processor_count, cus_free)
     words = len(mask)
     hip = C.CDLL(_loaded_hip_runtime())
@@ -153,7 +163,8 @@ def cu_masked_stream(device, cus_free: int):
         rc = hip.hipExtStreamCreateWithCUMask(C.byref(handle), words, (C.c_uint32 * words)(*mask))
     if rc != 0 or not handle.value:
         raise RuntimeError(f"hipExtStreamCreateWithCUMask failed (status {rc})")
-    return torch.cuda.ExternalStream(handle.value, device=device)
+    _MASKED_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=device)
+    return _MASKED_STREAMS[key]
 
 
 def _world(group):
@@ -545,7 +556,7 @@ class ShardedTMGCNLayer:
         if self.cu_reserve > 0:              # CU-masked streams (never the caller's own stream)
             if self._lanes is None:
                 try:
-                    self._lanes = [cu_masked_stream(self.A.device, self.cu_reserve) for _ in range(max(1, self.pipeline_lanes))]
+                    self._lanes = [cu_masked_stream(self.A.device, self.cu_reserve, lane) for lane in range(max(1, self.pipeline_lanes))]
                 except (RuntimeError, OSError, AttributeError) as e:
                     # a performance device, not a correctness one: without it the exchange merely overlaps
                     # less.  The choice is local to this rank (no collective depends on it).

@@ -57,9 +57,12 @@ def band_matrix(T: int, no_diag: int = 20, weights: str = "ones", rownorm: bool 
 def _block(c: DeviceCOO, start: int, count: int) -> DeviceCOO:
     """Slices start..start+count-1 of a sorted COO, re-based to slice 0 (func_create_sparse,
     read_data.py:174-183).  Sorted keys make a block one contiguous key range."""
+    if not c.sorted_reduced:
+        c = c.sort_reduce()
     NN = c.N * c.N
     lo, hi = torch.searchsorted(c.key, torch.tensor([start * NN, (start + count) * NN], device=c.key.device)).tolist()
-    return DeviceCOO((c.key[lo:hi] - start * NN).contiguous(), c.val[lo:hi].contiguous(), count, c.N)
+    return DeviceCOO((c.key[lo:hi] - start * NN).contiguous(), c.val[lo:hi].contiguous(), count, c.N,
+                     sorted_reduced=c.sorted_reduced)
 
 
 def _mat_arrays(c: DeviceCOO) -> Tuple[np.ndarray, np.ndarray]:

@@ -97,7 +97,13 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
     share = max(1, (os.cpu_count() or 1) // max(1, world))
     os.environ.setdefault("OMP_NUM_THREADS", str(min(share, 32)))
     from oracle import c_ref
-    lib, cptr = c_ref.load(), c_ref.cptr
+    # a stale / missing oracle library is rebuilt by rank 0 alone (c_ref.load holds a file lock around the build);
+    # the other ranks wait for it and then only load
+    if world > 1:
+        if rank == 0:
+            c_ref.load()
+        dist.barrier()
+    lib, cptr = c_ref.load(build_if_stale=(world == 1 or rank == 0)), c_ref.cptr
     t_start = time.perf_counter()
     lap = {}
 
@@ -129,6 +135,13 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
     if want64 and dev.type == "cuda":
         free_b, _ = torch.cuda.mem_get_info(dev)
         want64 = free_b > Tl * N * F * 8 + (16 << 30)
+    if world > 1:
+        # a COLLECTIVE decision (as bench.fits() makes its own): the fp64 leg all-reduces P, so either every rank
+        # builds it or none does — a rank deciding alone from its own free memory would leave the others waiting in
+        # a collective it never enters
+        flag = torch.tensor([1 if want64 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        want64 = bool(int(flag.item()))
     Xt64 = torch.zeros(Tl, N, F, dtype=torch.float64, device=dev) if want64 else None
     for jj, j in enumerate(needed_j):
         Xj = x_slice(j)
@@ -225,13 +238,13 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
     mark("dW_fp64_and_identities")
 
     # ------------------------------------------------------------------ collective verdict
-    keys = sorted(k for k, v in errs.items() if v is not None)
-    vec = torch.tensor([errs[k] for k in keys], dtype=torch.float64, device=dev)
+    # the SAME keys in the same order on every rank (a skipped entry travels as -1): the all-reduced vector has one
+    # length everywhere whatever each rank measured
+    keys = sorted(errs)
+    vec = torch.tensor([-1.0 if errs[k] is None else errs[k] for k in keys], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.MAX)
-    out = {k: float(v) for k, v in zip(keys, vec.tolist())}
-    for k, v in errs.items():
-        out.setdefault(k, v)
+    out = {k: (None if v < 0 else float(v)) for k, v in zip(keys, vec.tolist())}
     ok = all(v <= tol for k, v in out.items() if v is not None)
     out.update({"rows_Y_per_slice": S, "slices_checked": Tl * world, "nodes_dX": Sx, "tol": tol, "ok": bool(ok),
                 "dW_reference": "fp64 product of the regenerated inputs on the device (torch ops), all-reduced in fp64"

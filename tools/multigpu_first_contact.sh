@@ -35,7 +35,11 @@ echo "lanes=1 g=$G rc=$? $(grep -h 'ms/step' "$OUT/lanes1_g$G.err" | grep ' r0 '
 
 # 4. where the time goes: kernel trace of rank 0's process tree is not separable under torchrun; trace the
 #    2-rank case instead and decompose a step (RCCL kernel time, overlap with the fused kernel, idle gaps)
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_g2" -- python3 bench.py --gpus 2 --steps 4 --warmup 2 --no-compare-exchange --no-verify > "$OUT/traced_g2.json" 2> "$OUT/traced_g2.err"
+# the launcher starts FIRST and every rank is profiled directly (the profiled program sits right behind `--`, with no
+# process hop behind it: WORLD_SIZE is set by torchrun, so bench.py runs its worker without spawning anything)
+python3 -m torch.distributed.run --no-python --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29541 \
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_g2" -- python3 bench.py --gpus 2 --steps 4 --warmup 2 \
+  --no-compare-exchange --no-verify --no-measure-traffic > "$OUT/traced_g2.json" 2> "$OUT/traced_g2.err"
 for f in $(find "$OUT/trace_g2" -name "*kernel_trace.csv" | head -4); do python3 tools/timeline_gaps.py "$f" --steps 2 > "$f.gaps.json" 2>&1; done
 find "$OUT" -name "*.csv" -size +6M -delete
 cat "$OUT/status.log"
