@@ -69,6 +69,9 @@ def parse(argv=None):
     p.add_argument("--no-measure-traffic", action="store_true",
                    help="do not measure roofline.traffic in this run (two short child runs of this script under "
                         "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, N = 1 only); the committed PMC record is quoted instead")
+    p.add_argument("--no-hbm-only", action="store_true",
+                   help="skip the roofline.frac_hbm_only leg (N = 1 only): the same edge-slices per launch as 2 slices of "
+                        "N x slices/2 nodes, i.e. one multi-GB gather window per slice that the 256 MB Infinity Cache cannot help")
     p.add_argument("--no-verify", action="store_true",
                    help="skip the verify leg (sampled rows of Y / dX and the all-reduced dW against the CPU oracle)")
     p.add_argument("--verify-rows", type=int, default=128, help="sampled rows per slice (Y) and sampled nodes (dX) per rank")
@@ -179,19 +182,17 @@ def cpu_baseline(args):
     reference's way) on the host cores, 2 slices of the S4 graph (same degree / F):
       * the identical-N point SURVEY §8d defines (N = --nodes): 2 repetitions, each reported;
       * a smaller sample (N = --cpu-nodes) with a warm-up and 3 repetitions, for the spread.
-    `value` is the identical-N rate when it was run, else the small sample's.  Threads: torch's
-    sparse kernels do not scale to hundreds of threads (256 threads were slower than 32 on the
-    EPYC 9575F in round 1), so min(32, cores) is used and stated."""
+    `value` is the identical-N rate when it was run, else the small sample's.  Threads: chosen by a recorded
+    sweep over {8, 32, 128, all} on the small sample (`small_sample.thread_sweep_s`); the best count is used
+    and stated."""
     import torch
     from oracle import tmgcn_oracle as orc
     from tmgcn_amd import synth
 
     ncpu = os.cpu_count() or 1
-    threads = min(32, ncpu)
-    torch.set_num_threads(threads)
     Tc, F = 2, args.feat
 
-    def sample(Nc, reps, warm):
+    def inputs(Nc):
         A = synth.device_er_csr(Tc, Nc, args.deg, "cpu")
         At = A.to_coo_list(torch.float64)
         X = synth.device_features(Tc, Nc, F, "cpu").double()
@@ -199,29 +200,54 @@ def cpu_baseline(args):
         g = torch.Generator().manual_seed(1)
         W = torch.randn(F, F, generator=g) * 0.1
         dY = torch.randn(Tc, Nc, F, generator=g)
-        if warm:
-            orc.layer_fwd_bwd(M, At, X, W, dY)
+        return A.nnz, (M, At, X, W, dY)
+
+    def timed(ops_in, reps):
         times = []
         for _ in range(reps):
             t0 = time.perf_counter()
-            orc.layer_fwd_bwd(M, At, X, W, dY)
+            orc.layer_fwd_bwd(*ops_in)
             times.append(time.perf_counter() - t0)
-        return {"nodes": Nc, "slices": Tc, "edge_slices": A.nnz, "reps_s": [round(t, 3) for t in times],
-                "rate_best": A.nnz / min(times), "rate_mean": A.nnz * len(times) / sum(times)}
+        return times
 
-    stage(f"cpu_baseline: N={args.cpu_nodes} sample, {threads} threads")
-    small = sample(min(args.nodes, args.cpu_nodes), 3, True)
+    # BASELINE.md §3 promises "all cores"; torch's sparse kernels do not scale there (256 threads were slower than 32 on
+    # the EPYC 9575F in round 1).  So the thread count is CHOSEN BY A RECORDED SWEEP on the small sample — one repetition
+    # at each of {8, 32, 128, all hardware threads} after a warm-up — and the best one is used for everything else.
+    Ns = min(args.nodes, args.cpu_nodes)
+    nnz_s, ops_s = inputs(Ns)
+    sweep = {}
+    counts = sorted({min(c, ncpu) for c in (8, 32, 128, ncpu)})
+    torch.set_num_threads(counts[0])
+    stage(f"cpu_baseline: N={Ns} sample, thread sweep {counts}")
+    orc.layer_fwd_bwd(*ops_s)                                   # warm-up (allocator, sparse kernels' first-call costs)
+    for c in counts:
+        torch.set_num_threads(c)
+        sweep[c] = timed(ops_s, 1)[0]
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    ts = [sweep[threads]] + timed(ops_s, 2)
+    small = {"nodes": Ns, "slices": Tc, "edge_slices": nnz_s, "threads": threads, "reps_s": [round(t, 3) for t in ts],
+             "rate_best": nnz_s / min(ts), "rate_mean": nnz_s * len(ts) / sum(ts),
+             "thread_sweep_s": {str(c): round(t, 3) for c, t in sweep.items()},
+             "thread_sweep_rate": {str(c): nnz_s / t for c, t in sweep.items()}}
+    del ops_s
     full_n = args.nodes if args.cpu_full_nodes < 0 else args.cpu_full_nodes
     full = None
     if full_n and full_n > small["nodes"]:
-        stage(f"cpu_baseline: identical-N point N={full_n}")
-        full = sample(full_n, 2, False)
+        stage(f"cpu_baseline: identical-N point N={full_n}, {threads} threads")
+        nnz_f, ops_f = inputs(full_n)
+        tf = timed(ops_f, 1)                                    # one repetition (rounds 1-3: two, within 3 % of each other)
+        full = {"nodes": full_n, "slices": Tc, "edge_slices": nnz_f, "threads": threads, "reps_s": [round(t, 3) for t in tf],
+                "rate_best": nnz_f / min(tf), "rate_mean": nnz_f * len(tf) / sum(tf)}
+        del ops_f
     head = full or small
     return {"value": head["rate_best"], "unit": "edge-slices/s", "cores": threads, "kind": "port",
             "sample": f"oracle = the reference's way on torch CPU (COO fp64, sparse.mm per slice, autograd), {_cpu_model()}, "
-                      f"{threads} of {ncpu} hardware threads; fwd+bwd of {Tc} slices, deg={args.deg}+1, F={F}->{F}; "
-                      f"value = best of {len(head['reps_s'])} repetitions at N={head['nodes']} "
-                      f"({', '.join(str(t) for t in head['reps_s'])} s); extrapolates to T slices by T/2 (slices are independent)",
+                      f"{threads} of {ncpu} hardware threads — the best of the recorded sweep over {counts} threads on the N={Ns} "
+                      f"sample (BASELINE.md §3 says all cores: {ncpu} threads ran at {sweep[max(counts)] / sweep[threads]:.2f}x the time of "
+                      f"{threads}); fwd+bwd of {Tc} slices, deg={args.deg}+1, F={F}->{F}; value = best of {len(head['reps_s'])} "
+                      f"repetition(s) at N={head['nodes']} ({', '.join(str(t) for t in head['reps_s'])} s); extrapolates to T slices "
+                      "by T/2 (slices are independent)",
             "identical_n": full, "small_sample": small}
 
 
@@ -351,7 +377,7 @@ def cpu_epochs(g, spec, epochs, threads):
 def epochs_block(args, configs=("S1", "S2", "S3"), modes=("eager", "graph", "fused", "graph_fused", "script")):
     """north_star's epoch-throughput target (>= 10x the reference's CPU epoch on Reddit link
     prediction at 1 GPU), as a record: per config the GPU epoch in every mode, the CPU oracle's
-    epoch (median of --cpu-epoch-reps at 8 and at 32 threads, the better one reported) and the
+    epoch (median of --cpu-epoch-reps at 8 and at 32 threads, both recorded, the better one reported) and the
     ratio for an untouched script ("script" mode) and for the best mode."""
     from tmgcn_amd import synth
     ncpu = os.cpu_count() or 1
@@ -373,7 +399,10 @@ def epochs_block(args, configs=("S1", "S2", "S3"), modes=("eager", "graph", "fus
         if args.cpu_epoch_reps > 0:
             cpu = {}
             loss_cpu = None
-            for th in sorted({min(8, ncpu), min(32, ncpu)}):   # all 256 threads is pathological on these small ops
+            # 8 and 32 threads only: on these small per-slice ops (N = 1 000-6 000) more threads are pathological — with 128 / 256
+            # threads one S1 epoch did not finish in ten minutes on the 256-thread EPYC 9575F (round 4; the layer leg's
+            # cpu_baseline, whose operands are 100x larger, does sweep up to all hardware threads)
+            for th in sorted({min(8, ncpu), min(32, ncpu)}):
                 loss_cpu, cpu[th] = cpu_epochs(g, spec, args.cpu_epoch_reps, th)
             th_best = min(cpu, key=cpu.get)
             rec.update({"cpu_ms": round(cpu[th_best] * 1e3, 2), "cpu_threads": th_best,
@@ -525,6 +554,27 @@ def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_tim
             "gather_chunks": len(layer.gather_chunks(F)) if (layer.collective and exchange == "allgather"
                                                                and layer.gather_chunk_nodes != 0) else None,
             "peak_gb": peak_gb, "verify": ver, "phases": phases_rec}
+
+
+def hbm_only_fields(h, dom, F):
+    """roofline.frac_hbm_only (+ its provenance) from the large-gather-window run, same formula as `frac`."""
+    if not h:
+        return {}
+    if "error" in h:
+        return {"frac_hbm_only": None, "hbm_only_note": "large-window run failed: " + h["error"]}
+    kt = h["kt"]
+    sp, spT = kt[dom], kt.get(dom + "_T")
+    both = [sp] + ([spT] if spT and spT["launches"] == sp["launches"] else [])
+    avg_ms = sum(x["total_ms"] for x in both) / sum(x["launches"] for x in both)
+    d = h["nnz"] / h["rows"]
+    bpu = 8 + F * 4 + (4 + F * 4) / d
+    units = h["nnz"] * 3 / sp["launches"]
+    ach = bpu * units / (avg_ms * 1e-3) / 1e9
+    return {"frac_hbm_only": ach / HBM_PEAK_GBS, "achieved_hbm_only": ach,
+            "hbm_only": {"what": f"the same kernel and edge-slices per launch as {h['slices']} slices of N = {h['nodes']} nodes: "
+                                 f"one {h['gather_window_gb']} GB gather window per slice, of which the 256 MB Infinity Cache holds "
+                                 "3 % (the headline's 1 GB windows: 25 %) — what HBM alone sustains",
+                         "avg_launch_ms": avg_ms, "edge_slices_per_launch": units, "ms_per_step": h["ms_per_step"], "steps": 3}}
 
 
 def free_device_memory():
@@ -696,6 +746,21 @@ def worker(args):
                          f"are free (rank {rank}); nothing was allocated")
     res = run_layer(args, dist, dev, rank, world, args.exchange, N, args.steps, args.warmup, verify=not args.no_verify)
     free_device_memory()
+    hbm_only = None
+    if world == 1 and not collective and not args.no_hbm_only and Tl >= 4:
+        # The headline figure leans on the Infinity Cache (a quarter of each slice's 1 GB gather window fits its
+        # 256 MB).  The same kernel on the same number of edge-slices per launch, arranged as 2 slices of N·Tl/2
+        # nodes (S4 default: 16 M nodes, an 8 GB window per slice), is what HBM alone sustains.
+        import copy
+        a2 = copy.copy(args)
+        a2.slices_per_gpu, a2.nodes = 2, N * (Tl // 2)
+        try:
+            r2 = run_layer(a2, dist, dev, rank, world, args.exchange, a2.nodes, 3, 1)
+            hbm_only = {"nodes": a2.nodes, "slices": 2, "gather_window_gb": round(a2.nodes * F * 4 / 1e9, 2), "kt": r2["kt"],
+                        "nnz": r2["nnz_rank"], "rows": r2["rows_rank"], "ms_per_step": round(r2["elapsed"] / 3 * 1e3, 3)}
+        except RuntimeError as e:               # does not fit on this device: the headline stands alone
+            hbm_only = {"error": str(e)[:200]}
+        free_device_memory()
     if rank == 0:
         # the headline measurement, on stderr, BEFORE the side legs (exchange comparison, epochs, CPU baseline):
         # should one of those die, the record of the run's purpose survives in the log (the JSON line on
@@ -798,6 +863,7 @@ def worker(args):
                          "avg_launch_ms": avg_ms, "launches_averaged": sum(x["launches"] for x in both),
                          "forward_launch_ms": sp["avg_ms"], "backward_launch_ms": spT["avg_ms"] if spT else None,
                          "frac_forward_only": achieved_fwd / HBM_PEAK_GBS,
+                         **hbm_only_fields(hbm_only, dom, F),
                          "traffic_is_for": "the forward launch (the larger of the two: it also stores AX and Y)",
                          "note": None if sp["launches"] == args.steps else
                          "pipelined multi-GPU path: one-slice launches alternate between two streams and are enqueued ahead, so a "
