@@ -192,6 +192,13 @@ int64_t tmgcn_gemm_dw_workspace_bytes(int64_t R, int32_t K, int32_t Nf, int64_t 
 int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW,
                       int64_t R, int32_t K, int32_t Nf, int64_t rows_per_batch, int32_t algo,
                       void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with the activation gradient folded in (ABI 4):  dW_b = A_bᵀ · (dY ⊙ act'(pre_act))  — autograd of
+ * act(A·W) (ehf:330-334, 486) with respect to W without the [T,N,F] pass of tmgcn_act_bwd_f32 in between.  Narrow
+ * layers only (tmgcn_gemm_dw_act_supported: even K, Nf <= 8 — the reference's 2x6 / 6x6); same workspace. */
+int tmgcn_gemm_dw_act_supported(int32_t K, int32_t Nf);
+int tmgcn_gemm_dw_act_f32(const float* A, const float* dY, const float* pre_act, int32_t act, float* dW,
+                          int64_t R, int32_t K, int32_t Nf, int64_t rows_per_batch,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- P5: pointwise non-linearity between layers (ehf:284-289, 332-334, 486) -------
  *   fwd: y = act(x);   bwd: dx = dy * act'(x)   (x = the pre-activation input)

@@ -58,6 +58,9 @@ int main(void) {
   BAD(tmgcn_gemm_bf16w_f32(0, 0, 0, 0, 10, 4, 4, 0, 0, 0, 0, 5, 0));                      /* unknown algo */
   BAD(tmgcn_gemm_dw_f32(0, 0, 0, 10, 4, 4, 0, 0, 0, 0, 0));                               /* null dW */
   BAD(tmgcn_gemm_dw_f32(0, 0, (float*)hn, 10, 0, 4, 0, 0, 0, 0, 0));                      /* K = 0 */
+  NOP(tmgcn_gemm_dw_act_supported(16, 16));
+  BAD(tmgcn_gemm_dw_act_f32(0, 0, 0, 3, (float*)hn, 10, 16, 16, 0, 0, 0, 0));             /* wide: not supported */
+  BAD(tmgcn_gemm_dw_act_f32(0, 0, 0, 3, (float*)hn, 10, 2, 6, 0, 0, 0, 0));               /* no pre-activation */
   if (tmgcn_gemm_dw_workspace_bytes(1000, 6, 6, 0) <= 0) { ++failures; printf("FAIL gemm_dw workspace size\n"); }
   /* P5 */
   BAD(tmgcn_act_fwd_f32(0, 0, -1, 1, 0));

@@ -315,6 +315,46 @@ def test_gemm_dw(K, Nf, per_slice):
     assert torch.equal(got, ops.kernels.gemm_dw(A.to(DEV), dY.to(DEV), per_slice)), "dW not reproducible"
 
 
+@pytest.mark.parametrize("K,Nf", [(2, 6), (6, 6), (6, 2), (2, 2), (8, 8), (4, 6)])
+@pytest.mark.parametrize("T,N", [(3, 333), (1, 7), (5, 4099), (95, 6000)])
+def test_gemm_dw_narrow_shapes_and_sizes(K, Nf, T, N):
+    """The narrow dW kernel (four lanes per row, four rows in flight, reduced by its own last block) over row counts
+    from less than one block trip to hundreds of slabs, shared and per-slice weights, against the C oracle."""
+    lib = load_c_oracle()
+    g = torch.Generator().manual_seed(K * 100 + Nf + N)
+    A = torch.randn(T, N, K, generator=g)
+    dY = torch.randn(T, N, Nf, generator=g)
+    for per_slice in (False, True):
+        ref = torch.empty((T, K, Nf) if per_slice else (K, Nf))
+        lib.ref_gemm_dw(cptr(A), cptr(dY), cptr(ref), T * N, K, Nf, N if per_slice else 0)
+        got = ops.kernels.gemm_dw(A.to(DEV), dY.to(DEV), per_slice)
+        assert_close(got, ref, REL_TOL, f"dW {K}x{Nf} T={T} N={N} per_slice={per_slice}")
+        assert torch.equal(got, ops.kernels.gemm_dw(A.to(DEV), dY.to(DEV), per_slice)), "dW not reproducible"
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky", "selu"])
+@pytest.mark.parametrize("K,Nf,per_slice", [(2, 6, False), (6, 6, False), (2, 6, True)])
+def test_gemm_dw_with_folded_activation_gradient(act, K, Nf, per_slice):
+    """dW = Aᵀ·(dY ⊙ act'(pre)) in one launch == act_bwd followed by the plain dW kernel (bit for bit: the same
+    products in the same order), and the layer-1 backward of feature_gemm(act=...) uses it when the input is a constant."""
+    from tmgcn_amd import _lib
+    T, N = 4, 2500
+    g = torch.Generator().manual_seed(K + Nf)
+    A, dY = torch.randn(T, N, K, generator=g).to(DEV), torch.randn(T, N, Nf, generator=g).to(DEV)
+    pre = torch.randn(T, N, Nf, generator=g).to(DEV)
+    fused = ops.kernels.ops.bgemm_dW_act(A, dY, pre, _lib.ACT_IDS[act], per_slice)
+    two = ops.kernels.gemm_dw(A, ops.kernels.act_bwd(pre, dY, act), per_slice)
+    assert torch.equal(fused, two)
+    # through autograd: constant input, differentiable weight
+    W = (torch.randn(*((T,) if per_slice else ()), K, Nf, generator=g) * 0.5).to(DEV).requires_grad_(True)
+    Y = ops.feature_gemm(A, W, act=act)
+    Y.backward(dY)
+    W2 = W.detach().clone().requires_grad_(True)
+    A2 = A.clone().requires_grad_(True)                       # input needs a gradient too: the unfused route
+    ops.feature_gemm(A2, W2, act=act).backward(dY)
+    assert torch.equal(W.grad, W2.grad)
+
+
 @pytest.mark.parametrize("K,Nf,R", [(128, 128, 70001), (132, 260, 5000), (16, 16, 33), (64, 36, 4099), (20, 100, 777)])
 def test_gemm_dw_bf16_split_is_fp32_accurate(K, Nf, R):
     """dW runs on the bf16 matrix cores through an exact 3-way split of the fp32 operands (hi + mid +

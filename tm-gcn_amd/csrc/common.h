@@ -167,10 +167,29 @@ __device__ __forceinline__ float act_grad(float x, int act) {
     case TMGCN_ACT_SELU: {
       const float scale = 1.0507009873554804934193349852946f;
       const float alpha = 1.6732632423543772848170429916717f;
-      return x > 0.f ? scale : scale * alpha * expf(x);
+      return x > 0.f ? scale : scale * alpha * expf(fminf(x, 0.f));   // exp evaluated unconditionally: a select, not a branch
     }
     default: return 1.f;
   }
 }
+
+// act_grad() with the activation decoded ONCE (uniform registers) instead of a switch per element: the same values,
+// bit for bit — x > 0 ? pos : neg · (use_exp ? exp(x) : 1) — as selects, so a loop over elements stays branch-free
+// (a branch per element also splits the loads around it: every use waits for all of them).
+struct ActGrad {
+  float pos, neg;
+  bool use_exp;
+  __device__ __forceinline__ explicit ActGrad(int act) {
+    const float scale = 1.0507009873554804934193349852946f;
+    const float alpha = 1.6732632423543772848170429916717f;
+    pos = act == TMGCN_ACT_SELU ? scale : 1.f;
+    neg = act == TMGCN_ACT_SELU ? scale * alpha : (act == TMGCN_ACT_LEAKY ? 0.01f : (act == TMGCN_ACT_RELU ? 0.f : 1.f));
+    use_exp = act == TMGCN_ACT_SELU;
+  }
+  __device__ __forceinline__ float operator()(float x) const {
+    const float e = expf(fminf(x, 0.f));
+    return x > 0.f ? pos : neg * (use_exp ? e : 1.f);
+  }
+};
 
 }  // namespace tmgcn

@@ -655,6 +655,8 @@ struct DwArgs {
   float* dW = nullptr;       // narrow kernel: the last block to finish reduces the slabs into dW itself
   int32_t* sync = nullptr;   //   (hand-off word: zero on entry, left zero)
   int32_t n_batch = 1;
+  const float* pre = nullptr;  // narrow kernel, optional: dY is multiplied by act'(pre) on the fly
+  int32_t act = 0;
 };
 
 // grid: x = batch*chunks + chunk, y = 128x128 output tile (ky * n_tiles_n + ny)
@@ -1190,13 +1192,18 @@ __global__ __launch_bounds__(256) void gemm_dw_small_kernel(DwArgs a) {
   }
 }
 
-// Narrow layers (K, Nf even and <= 8: the scripts' 2x6, 6x6, 6x2): both widths known at compile
-// time, every lane keeps all K·Nf sums of its own rows (r0 + t, r0 + t + 256, ...) in fp64
-// registers — 8-byte row loads, no LDS staging, no barrier in the row loop — and the block folds
-// them once: xor butterfly inside each wave, then the four waves in order.
-template <int KT, int NT>
+// Narrow layers (K, Nf even and <= 8: the scripts' 2x6, 6x6, 6x2), both widths known at compile time.
+// FOUR lanes share a row: lane j of a group takes the (K/2) x (Nf/2) block (k-half j >> 1, n-half j & 1) of the row's
+// outer product — it loads only its halves of the A and dY rows (the four lanes together read each row once, whole
+// cache lines) and keeps K·Nf/4 fp64 sums instead of K·Nf (9 instead of 36 for the 6x6 weight: 18 VGPRs, not 72), which
+// leaves room for FOUR rows in flight per lane (the one-row form was bound by its load -> fma dependency, and four rows
+// next to 72 accumulator registers were slower: round 2).  The block folds once: xor butterfly over the lane bits above
+// the group (4 stages of K·Nf/4 values, not 6 of K·Nf), then the four waves in order.
+// ACT: dY is multiplied by act'(pre) on the fly (dW = Aᵀ·(dY ⊙ act'(pre)), autograd of act(A·W) with respect to W) — the
+// layer-1 backward of the 2-layer models without the [T,N,F] act_bwd pass in between.
+template <int KT, int NT, bool ACT>
 __global__ __launch_bounds__(256) void gemm_dw_narrow_kernel(DwArgs a) {
-  constexpr int NO = KT * NT;
+  constexpr int NO = KT * NT, KH = KT / 2, NH = NT / 2;
   __shared__ double red[4][NO];
   const int64_t batch = blockIdx.x / a.chunks;
   const int chunk = blockIdx.x % a.chunks;
@@ -1206,42 +1213,59 @@ __global__ __launch_bounds__(256) void gemm_dw_narrow_kernel(DwArgs a) {
   const int64_t r0 = b0 + (int64_t)chunk * a.rows_per_chunk;
   int64_t r1 = r0 + a.rows_per_chunk;
   if (r1 > b1) r1 = b1;
-  double acc[KT][NT];
+  const int j = threadIdx.x & 3, kh = j >> 1, nh = j & 1;
+  double acc[KH][NH];
 #pragma unroll
-  for (int k = 0; k < KT; ++k)
+  for (int k = 0; k < KH; ++k)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[k][n] = 0.0;
-  // (four rows in flight per lane were tried: slower — 48 more VGPRs next to the 72 of acc)
-  for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
-    const float2* xa = reinterpret_cast<const float2*>(a.A + r * KT);
-    const float2* ga = reinterpret_cast<const float2*>(a.dY + r * NT);
-    float x[KT], g[NT];
+    for (int n = 0; n < NH; ++n) acc[k][n] = 0.0;
+  // RUN rows in flight per lane (rows r, r + 64, …: a block covers 64·RUN rows per trip).  No bounds test inside: a load
+  // under a per-lane condition compiles to a branch with a full vmcnt(0) wait per element, so full trips run
+  // unconditionally and the last rows of the chunk take single-row trips.
+  const ActGrad dact(a.act);
+  auto trip = [&](int64_t r, auto run_tag) {
+    constexpr int RUN = decltype(run_tag)::value;
+    float x[RUN][KH], g[RUN][NH], pa[RUN][ACT ? NH : 1];
 #pragma unroll
-    for (int i = 0; i < KT / 2; ++i) {
-      const float2 v = xa[i];
-      x[2 * i] = v.x;
-      x[2 * i + 1] = v.y;
+    for (int u = 0; u < RUN; ++u) {
+      const float* xa = a.A + (r + 64 * u) * KT + kh * KH;
+      const float* ga = a.dY + (r + 64 * u) * NT + nh * NH;
+#pragma unroll
+      for (int i = 0; i < KH; ++i) x[u][i] = xa[i];
+#pragma unroll
+      for (int i = 0; i < NH; ++i) g[u][i] = ga[i];
+      if constexpr (ACT) {
+        const float* pp = a.pre + (r + 64 * u) * NT + nh * NH;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) pa[u][i] = pp[i];
+      }
+    }
+    if constexpr (ACT) {
+#pragma unroll
+      for (int u = 0; u < RUN; ++u)
+#pragma unroll
+        for (int i = 0; i < NH; ++i) g[u][i] *= dact(pa[u][i]);
     }
 #pragma unroll
-    for (int i = 0; i < NT / 2; ++i) {
-      const float2 v = ga[i];
-      g[2 * i] = v.x;
-      g[2 * i + 1] = v.y;
-    }
+    for (int u = 0; u < RUN; ++u)
 #pragma unroll
-    for (int k = 0; k < KT; ++k)
+      for (int k = 0; k < KH; ++k)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[k][n] = fma((double)x[k], (double)g[n], acc[k][n]);
-  }
+        for (int n = 0; n < NH; ++n) acc[k][n] = fma((double)x[u][k], (double)g[u][n], acc[k][n]);
+  };
+  constexpr int RU = 4;
+  int64_t r = r0 + (threadIdx.x >> 2);
+  for (; r + 64 * (RU - 1) < r1; r += 64 * RU) trip(r, std::integral_constant<int, RU>{});
+  for (; r < r1; r += 64) trip(r, std::integral_constant<int, 1>{});
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < KT; ++k)
+  for (int k = 0; k < KH; ++k)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
+    for (int n = 0; n < NH; ++n) {
       double v = acc[k][n];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if (lane == 0) red[wave][k * NT + n] = v;
+      for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o);
+      if (lane < 4) red[wave][(kh * KH + k) * NT + nh * NH + n] = v;
     }
   __syncthreads();
   // slab stored write-through (4-byte relaxed agent-scope atomic store); the last block to finish adds the slabs
@@ -1255,27 +1279,33 @@ __global__ __launch_bounds__(256) void gemm_dw_narrow_kernel(DwArgs a) {
   if (threadIdx.x == 0) *a.sync = 0;
   const unsigned* P = reinterpret_cast<const unsigned*>(a.part);
   if (a.n_batch == 1) {
-    // one output matrix: 64 columns (outputs, NO <= 64) x 4 interleaved parts of the chunk list, 8 loads in flight
-    __shared__ double fin[4][64];
-    const int o = threadIdx.x & 63, part = threadIdx.x >> 6;
-    double s[8];
+    // one output matrix: SUBS = 256 / NO threads per output, each adding the slabs c = sub, sub + SUBS, … (8 loads in
+    // flight, masked rather than branched), then the SUBS partial sums of an output in order
+    constexpr int SUBS = 256 / NO;
+    __shared__ double fin[SUBS][NO];
+    const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
+    if (sub < SUBS) {
+      double s[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s[q] = 0.0;
-    if (o < NO) {
-      for (int c = part; c < a.chunks; c += 32) {
+      for (int q = 0; q < 8; ++q) s[q] = 0.0;
+      for (int c = sub; c < a.chunks; c += 8 * SUBS) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const int cc = c + 4 * q;
+          const int cc = c + q * SUBS;
           const float v = __uint_as_float(__hip_atomic_load(P + (int64_t)(cc < a.chunks ? cc : a.chunks - 1) * NO + o,
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           s[q] += cc < a.chunks ? (double)v : 0.0;
         }
       }
+      fin[sub][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
-    fin[part][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
-    if (threadIdx.x < NO)
-      a.dW[threadIdx.x] = (float)((fin[0][threadIdx.x] + fin[1][threadIdx.x]) + (fin[2][threadIdx.x] + fin[3][threadIdx.x]));
+    if (threadIdx.x < NO) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < SUBS; ++q) t += fin[q][threadIdx.x];
+      a.dW[threadIdx.x] = (float)t;
+    }
   } else {
     // one weight per slice: few chunks per batch, many outputs — a thread per output walks its chunks in order
     const int64_t total = (int64_t)a.n_batch * NO;
@@ -1468,9 +1498,9 @@ extern "C" int64_t tmgcn_gemm_dw_workspace_bytes(int64_t R, int32_t K, int32_t N
   return nb * chunks * (int64_t)K * Nf * (int64_t)sizeof(float);
 }
 
-extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int64_t R, int32_t K,
-                                  int32_t Nf, int64_t rows_per_batch, int32_t algo, void* workspace,
-                                  int64_t workspace_bytes, void* stream) {
+static int gemm_dw_launch(const float* A, const float* dY, const float* pre, int32_t act, float* dW, int64_t R, int32_t K,
+                          int32_t Nf, int64_t rows_per_batch, int32_t algo, void* workspace, int64_t workspace_bytes,
+                          void* stream) {
   TMGCN_REQUIRE(R >= 0 && K > 0 && Nf > 0, "gemm_dw: bad shape");
   TMGCN_REQUIRE(algo == TMGCN_DW_AUTO || algo == TMGCN_DW_F32MFMA, "gemm_dw: unknown algo %d", algo);
   TMGCN_REQUIRE(rows_per_batch >= 0, "gemm_dw: negative rows_per_batch");
@@ -1492,6 +1522,8 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
   }
   const bool narrow = K % 2 == 0 && Nf % 2 == 0 && K <= 8 && Nf <= 8 && reinterpret_cast<uintptr_t>(A) % 8 == 0 &&
                       reinterpret_cast<uintptr_t>(dY) % 8 == 0;
+  TMGCN_REQUIRE(!pre || narrow, "gemm_dw_act: the fused activation gradient needs the narrow kernel (even K, Nf <= 8, 8-byte "
+                                 "aligned operands); use tmgcn_act_bwd_f32 + tmgcn_gemm_dw_f32");
   if (narrow && rpc < 2048) {
     // the narrow kernel's fixed cost is the K·Nf-value block reduction: fatter chunks (never more
     // slabs than planned, so the workspace still fits)
@@ -1503,15 +1535,20 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
   const unsigned gx = (unsigned)(nb * chunks);
   if (narrow) {
     a.dW = dW;
+    a.pre = pre;
+    a.act = act;
     a.n_batch = (int32_t)nb;
     a.sync = acquire_sync_word(st);
     TMGCN_REQUIRE(a.sync, "gemm_dw: no hand-off word");
-#define TMGCN_DWN_N(KT_)                                                                             \
-  switch (Nf) {                                                                                      \
-    case 2: hipLaunchKernelGGL((gemm_dw_narrow_kernel<KT_, 2>), dim3(gx), dim3(256), 0, st, a); break; \
-    case 4: hipLaunchKernelGGL((gemm_dw_narrow_kernel<KT_, 4>), dim3(gx), dim3(256), 0, st, a); break; \
-    case 6: hipLaunchKernelGGL((gemm_dw_narrow_kernel<KT_, 6>), dim3(gx), dim3(256), 0, st, a); break; \
-    default: hipLaunchKernelGGL((gemm_dw_narrow_kernel<KT_, 8>), dim3(gx), dim3(256), 0, st, a);     \
+#define TMGCN_DWN_L(KT_, NT_)                                                                          \
+  if (pre) hipLaunchKernelGGL((gemm_dw_narrow_kernel<KT_, NT_, true>), dim3(gx), dim3(256), 0, st, a); \
+  else hipLaunchKernelGGL((gemm_dw_narrow_kernel<KT_, NT_, false>), dim3(gx), dim3(256), 0, st, a);
+#define TMGCN_DWN_N(KT_)                \
+  switch (Nf) {                         \
+    case 2: TMGCN_DWN_L(KT_, 2) break;  \
+    case 4: TMGCN_DWN_L(KT_, 4) break;  \
+    case 6: TMGCN_DWN_L(KT_, 6) break;  \
+    default: TMGCN_DWN_L(KT_, 8)        \
   }
     switch (K) {
       case 2: TMGCN_DWN_N(2) break;
@@ -1520,6 +1557,7 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
       default: TMGCN_DWN_N(8)
     }
 #undef TMGCN_DWN_N
+#undef TMGCN_DWN_L
     return check_launch("gemm_dw_narrow");          // reduced by its own last block
   } else if (use_small(K, Nf)) {
     const size_t smem = (size_t)DW_ROWS * (K + Nf) * sizeof(float);
@@ -1544,4 +1582,23 @@ extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int
     hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(DWR_WAVES * 64), 0, st,
                        (const float*)workspace, dW, n_out, chunks, total);
   return check_launch("gemm_dw_reduce");
+}
+
+extern "C" int tmgcn_gemm_dw_f32(const float* A, const float* dY, float* dW, int64_t R, int32_t K, int32_t Nf,
+                                  int64_t rows_per_batch, int32_t algo, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+  return gemm_dw_launch(A, dY, nullptr, TMGCN_ACT_NONE, dW, R, K, Nf, rows_per_batch, algo, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tmgcn_gemm_dw_act_supported(int32_t K, int32_t Nf) {
+  return (K >= 2 && Nf >= 2 && K % 2 == 0 && Nf % 2 == 0 && K <= 8 && Nf <= 8) ? 1 : 0;
+}
+
+extern "C" int tmgcn_gemm_dw_act_f32(const float* A, const float* dY, const float* pre_act, int32_t act, float* dW,
+                                      int64_t R, int32_t K, int32_t Nf, int64_t rows_per_batch, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
+  TMGCN_REQUIRE(tmgcn_gemm_dw_act_supported(K, Nf), "gemm_dw_act: even K, Nf <= 8 only (got %d x %d)", K, Nf);
+  TMGCN_REQUIRE(act >= TMGCN_ACT_NONE && act <= TMGCN_ACT_SELU, "gemm_dw_act: unknown activation %d", act);
+  TMGCN_REQUIRE(pre_act && reinterpret_cast<uintptr_t>(pre_act) % 8 == 0, "gemm_dw_act: pre_act must be given, 8-byte aligned");
+  return gemm_dw_launch(A, dY, pre_act, act, dW, R, K, Nf, rows_per_batch, TMGCN_DW_AUTO, workspace, workspace_bytes, stream);
 }

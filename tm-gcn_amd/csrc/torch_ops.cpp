@@ -253,6 +253,25 @@ Tensor bgemm_dW(const Tensor& A, const Tensor& dY, bool per_slice, int64_t algo)
   return dW;
 }
 
+// dW = Aᵀ·(dY ⊙ act'(pre)) in one launch (narrow layers; shared weight or one per slice)
+Tensor bgemm_dW_act(const Tensor& A, const Tensor& dY, const Tensor& pre, int64_t act, bool per_slice) {
+  want(A, "gemm_dw A");
+  want(dY, "gemm_dw dY");
+  want(pre, "gemm_dw pre-activation");
+  TORCH_CHECK(A.dim() == 3 && dY.dim() == 3 && A.size(0) == dY.size(0) && A.size(1) == dY.size(1) && pre.sizes() == dY.sizes(),
+              "gemm_dw_act: A ", A.sizes(), ", dY ", dY.sizes(), " and pre ", pre.sizes(), " do not match");
+  c10::DeviceGuard g(A.device());
+  const int64_t T = A.size(0), N = A.size(1), K = A.size(2), Nf = dY.size(2), R = T * N;
+  const int64_t rpb = per_slice ? N : 0;
+  const int64_t need = tmgcn_gemm_dw_workspace_bytes(R, (int32_t)K, (int32_t)Nf, rpb);
+  Tensor ws = at::empty({need > 0 ? need : 1}, A.options().dtype(at::kByte));
+  Tensor dW = per_slice ? at::empty({T, K, Nf}, A.options()) : at::empty({K, Nf}, A.options());
+  ok(tmgcn_gemm_dw_act_f32((const float*)ptr(A), (const float*)ptr(dY), (const float*)ptr(pre), (int32_t)act, (float*)ptr(dW), R,
+                           (int32_t)K, (int32_t)Nf, rpb, ptr(ws), ws.numel(), stream_of(A)),
+     "tmgcn_gemm_dw_act_f32");
+  return dW;
+}
+
 Tensor edge_head_fwd(const Tensor& Z2, const Tensor& src, const Tensor& dst, const Tensor& U) {
   want(Z2, "edge_head Z");
   want(U, "edge_head U");
@@ -537,8 +556,20 @@ struct FeatureGemmFn : public torch::autograd::Function<FeatureGemmFn> {
     const Tensor &A = sv[0], &W = sv[1], &pre = sv[2];
     const int64_t act = ctx->saved_data["act"].toInt();
     Tensor dY = grads[0].contiguous();
-    if (act != TMGCN_ACT_NONE) dY = act_bwd(pre, dY, act);
     Tensor dA, dW;
+    // layer 1 of the 2-layer models: the input (AtXt / AX) is a constant, so only dW is asked for — the activation
+    // gradient is folded into the dW kernel and dY ⊙ act'(pre) never exists as a tensor
+    const bool fold_act = act != TMGCN_ACT_NONE && !ctx->needs_input_grad(0) && ctx->needs_input_grad(1) && A.dim() == 3 &&
+                          tmgcn_gemm_dw_act_supported((int32_t)A.size(-1), (int32_t)dY.size(-1)) &&
+                          reinterpret_cast<uintptr_t>(A.const_data_ptr()) % 8 == 0 &&
+                          reinterpret_cast<uintptr_t>(dY.const_data_ptr()) % 8 == 0 &&
+                          reinterpret_cast<uintptr_t>(pre.const_data_ptr()) % 8 == 0;
+    if (fold_act) {
+      dW = bgemm_dW_act(A, dY, pre, act, W.dim() == 3);
+      if (dW.scalar_type() != W.scalar_type()) dW = dW.to(W.scalar_type());
+      return {dA, dW, Tensor()};
+    }
+    if (act != TMGCN_ACT_NONE) dY = act_bwd(pre, dY, act);
     if (ctx->needs_input_grad(0)) dA = std::get<0>(bgemm(dY, W, true, TMGCN_ACT_NONE, false, TMGCN_GEMM_AUTO));
     if (ctx->needs_input_grad(1)) {
       dW = bgemm_dW(A, dY, W.dim() == 3, TMGCN_DW_AUTO);  // summed in fp32, rounded once for a bf16 parameter
@@ -744,6 +775,7 @@ TORCH_LIBRARY(tmgcn, m) {
         "Tensor(a!) Y, Tensor(b!)? AX, Tensor(c!)? pre, int grid_reserve, float avg_nnz_per_row=-1.0) -> ()");
   m.def("bgemm(Tensor A, Tensor W, bool trans_w, int act, bool want_pre, int algo) -> (Tensor, Tensor)");
   m.def("bgemm_dW(Tensor A, Tensor dY, bool per_slice, int algo) -> Tensor");
+  m.def("bgemm_dW_act(Tensor A, Tensor dY, Tensor pre, int act, bool per_slice) -> Tensor");
   m.def("edge_head_fwd(Tensor Z2, Tensor src, Tensor dst, Tensor U) -> Tensor");
   m.def("edge_head_bwd(Tensor Z2, Tensor src, Tensor dst, Tensor U, Tensor dout, Tensor eptr, Tensor eidx, "
         "bool need_dz, bool need_du) -> (Tensor, Tensor)");
@@ -785,6 +817,7 @@ TORCH_LIBRARY_IMPL(tmgcn, CUDA, m) {
   m.impl("spmm_gemm_out", &spmm_gemm_out);
   m.impl("bgemm", &bgemm);
   m.impl("bgemm_dW", &bgemm_dW);
+  m.impl("bgemm_dW_act", &bgemm_dW_act);
   m.impl("edge_head_fwd", &edge_head_fwd);
   m.impl("edge_head_bwd", &edge_head_bwd);
   m.impl("act_fwd", &act_fwd);
