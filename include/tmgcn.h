@@ -200,6 +200,26 @@ int tmgcn_gemm_dw_act_f32(const float* A, const float* dY, const float* pre_act,
                           int64_t R, int32_t K, int32_t Nf, int64_t rows_per_batch,
                           void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- layers 1 + 2 of the narrow 2-layer models, fused (ABI 4) --------------------------------------
+ *   forward   Z = act2( (Â ⋆ act1(H·W1)) · W2 )     ehf:330-335 + 348-349 (EmbeddingGCN2, default branch), ehf:486-487 (KWGCN)
+ *   backward  dW1 = Σ_r H[r]ᵀ · ( ((Âᵀ ⋆ dZ')·W2ᵀ)[r] ⊙ act1'(H[r]·W1) ),   dZ' = dZ ⊙ act2'(pre2)
+ * H [R][2] is the model's cached constant (AtXt / AX, ehf:293 / 464): the [R][F] intermediates (layer-1 output, its
+ * pre-activation, dY, dP) are never stored.  Shared weights W1 [2][F], W2 [F][Nf]; 2 -> even F <= 8 -> even Nf <= 8
+ * (tmgcn_layer12_supported).  Same per-lane fmaf chains as tmgcn_gemm_f32 + tmgcn_spmm_gemm_f32 on these widths.
+ * AX (optional) receives Â ⋆ act1(H·W1) for dW2 = AXᵀ·dZ' (tmgcn_gemm_dw_f32); pre2 the pre-activation of layer 2
+ * when act2 is not none.  The backward takes the TRANSPOSED batched CSR. */
+int tmgcn_layer12_supported(int32_t K0, int32_t F, int32_t Nf);
+int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* H,
+                          const float* W1, int32_t act1, const float* W2, int32_t act2, int64_t n_rows,
+                          int32_t N, int32_t K0, int32_t F, int32_t Nf, float* Z, float* AX, float* pre2,
+                          float avg_nnz_per_row, void* stream);
+int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F);
+int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const float* dZ,
+                          const float* pre2, const float* H, const float* W1, int32_t act1, const float* W2,
+                          int32_t act2, int64_t n_rows, int32_t N, int32_t K0, int32_t F, int32_t Nf,
+                          float* dW1, float avg_nnz_per_row, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+
 /* ---- P5: pointwise non-linearity between layers (ehf:284-289, 332-334, 486) -------
  *   fwd: y = act(x);   bwd: dx = dy * act'(x)   (x = the pre-activation input)
  */

@@ -604,3 +604,36 @@ def test_weighted_cross_entropy_matches_torch_fp64(E, C):
     assert_close(zg.grad, zr.grad, 2e-6, "wce dlogits")
     with pytest.raises(RuntimeError):
         WeightedCrossEntropy(torch.ones(9))(torch.randn(4, 9, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV))
+
+
+@pytest.mark.parametrize("act1,act2", [("selu", None), ("relu", None), ("leaky", "relu"), (None, "selu")])
+@pytest.mark.parametrize("T,N,deg,F,Nf", [(5, 300, 3.0, 6, 6), (3, 77, 12.0, 6, 2), (4, 500, 0.4, 2, 6), (2, 64, 40.0, 8, 4)])
+def test_layer12_fused_matches_the_two_operators(act1, act2, T, N, deg, F, Nf):
+    """ops.layer12 (csrc/layer12.hip: layers 1 + 2 of the narrow 2-layer models in one launch each way) against
+    feature_gemm followed by spmm_feature_gemm: the same Z to the last bit or two (same per-lane fmaf chains; a row's
+    partial sums are folded over however many lanes each kernel gives a row), dW1 / dW2 to fp32 rounding (the fused
+    backward accumulates dW1 per row in fp64), reproducible."""
+    from tmgcn_amd import adjacency
+    rng = np.random.default_rng(T * 1000 + N)
+    nnz = int(T * N * deg)
+    A = adjacency.DeviceCOO.from_edges(rng.integers(0, T, nnz), rng.integers(0, N, nnz), rng.integers(0, N, nnz),
+                                       rng.uniform(0.1, 1.0, nnz).astype(np.float32), T, N).sort_reduce().to_csr()
+    g = torch.Generator().manual_seed(7)
+    H = torch.randn(T, N, 2, generator=g).to(DEV)
+    W1 = (torch.randn(2, F, generator=g) * 0.7).to(DEV)
+    W2 = (torch.randn(F, Nf, generator=g) * 0.7).to(DEV)
+    dZ = torch.randn(T, N, Nf, generator=g).to(DEV)
+    a1, a2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+    Z = ops.layer12(H, a1, act1, A, a2, act2, fuse=True)
+    Z.backward(dZ)
+    b1, b2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+    Zr = ops.layer12(H, b1, act1, A, b2, act2, fuse=False)
+    Zr.backward(dZ)
+    assert_close(Z.detach(), Zr.detach(), 1e-6, "Z")
+    assert_close(a1.grad, b1.grad, 2e-6, "dW1")
+    assert_close(a2.grad, b2.grad, 2e-6, "dW2")
+    c1, c2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+    ops.layer12(H, c1, act1, A, c2, act2, fuse=True).backward(dZ)
+    assert torch.equal(c1.grad, a1.grad) and torch.equal(c2.grad, a2.grad)
+    with torch.no_grad():                                      # no gradients: nothing but Z is stored
+        assert torch.equal(ops.layer12(H, W1, act1, A, W2, act2), Z.detach())

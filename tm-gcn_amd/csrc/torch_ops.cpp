@@ -485,6 +485,7 @@ void sgd_step(at::TensorList params, at::TensorList grads, at::TensorList bufs, 
 }
 
 bool spmm_gemm_supported(int64_t K, int64_t Nf) { return tmgcn_spmm_gemm_supported((int32_t)K, (int32_t)Nf) != 0; }
+bool layer12_supported(int64_t K0, int64_t F, int64_t Nf) { return tmgcn_layer12_supported((int32_t)K0, (int32_t)F, (int32_t)Nf) != 0; }
 bool edge_head_supported(int64_t F, int64_t C) { return tmgcn_edge_head_supported((int32_t)F, (int32_t)C) != 0; }
 bool head_loss_supported(int64_t F, int64_t C, int64_t K) { return tmgcn_head_loss_supported((int32_t)F, (int32_t)C, (int32_t)K) != 0; }
 int64_t abi_version() { return tmgcn_abi_version(); }
@@ -695,6 +696,86 @@ struct HeadLossFn : public torch::autograd::Function<HeadLossFn> {
   }
 };
 
+// Layers 1 + 2 of the narrow 2-layer models (csrc/layer12.hip): Z = act2((Â ⋆ act1(H·W1))·W2) with H a constant.
+struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
+  static Tensor forward(AutogradContext* ctx, const Tensor& H, const Tensor& W1, const Tensor& W2, const Tensor& rowptr,
+                        const Tensor& col, const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col,
+                        const OptTensor& t_val, int64_t N, double avg, int64_t act1, int64_t act2, bool need1, bool need2) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    want(H, "layer12 H");
+    want(W1, "layer12 W1");
+    want(W2, "layer12 W2");
+    check_csr(rowptr, col, val, H, N, "layer12");
+    TORCH_CHECK(W1.dim() == 2 && W2.dim() == 2 && W1.size(0) == H.size(2) && W2.size(0) == W1.size(1), "layer12: W1 ",
+                W1.sizes(), " / W2 ", W2.sizes(), " do not chain from H ", H.sizes());
+    const int64_t K0 = H.size(2), F = W1.size(1), Nf = W2.size(1), R = H.size(0) * H.size(1);
+    TORCH_CHECK(tmgcn_layer12_supported((int32_t)K0, (int32_t)F, (int32_t)Nf), "layer12: unsupported widths ", K0, " -> ", F, " -> ", Nf);
+    c10::DeviceGuard g(H.device());
+    Tensor Z = at::empty({H.size(0), H.size(1), Nf}, H.options());
+    Tensor AX = need2 ? at::empty({H.size(0), H.size(1), F}, H.options()) : Tensor();
+    Tensor pre2 = ((need1 || need2) && act2 != TMGCN_ACT_NONE) ? at::empty_like(Z) : Tensor();
+    // The fused forward re-applies W1 and the non-linearity to every GATHERED row: per non-zero, not per row.  That
+    // pays while rows are short (3 non-zeros per row at the Bitcoin-OTC shape: 35 vs 41 us); with ~27 per row (AMLSim
+    // shape) forming the layer-1 output once is cheaper (36 vs 40 us; tools/ab_layer12.py) — same bits either way,
+    // and the fused BACKWARD (which recomputes per row) is used in both cases, so no pre-activation is kept.
+    if (avg >= 0.0 && avg <= 6.0) {
+      ok(tmgcn_layer12_fwd_f32((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val), (const float*)ptr(H),
+                               (const float*)ptr(W1), (int32_t)act1, (const float*)ptr(W2), (int32_t)act2, R, (int32_t)N,
+                               (int32_t)K0, (int32_t)F, (int32_t)Nf, (float*)ptr(Z), (float*)ptr(AX), (float*)ptr(pre2), (float)avg,
+                               stream_of(H)),
+         "tmgcn_layer12_fwd_f32");
+    } else {
+      Tensor Y = std::get<0>(bgemm(H, W1, false, act1, false, TMGCN_GEMM_AUTO));
+      ok(tmgcn_spmm_gemm_f32_hint((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val), (const float*)ptr(Y),
+                                  R, (int32_t)N, (int32_t)F, (const float*)ptr(W2), (int32_t)Nf, 0, 0, 0, (int32_t)act2, (float*)ptr(Z),
+                                  (float*)ptr(AX), (float*)ptr(pre2), 0, (float)avg, stream_of(H)),
+         "tmgcn_spmm_gemm_f32");
+    }
+    if (need1 || need2) {
+      TORCH_CHECK(!need1 || (t_rowptr.has_value() && t_col.has_value() && t_val.has_value()),
+                  "layer12: the gradient of W1 needs the transposed adjacency");
+      ctx->save_for_backward({H, W1, W2, AX.defined() ? AX : none_like(H), pre2.defined() ? pre2 : none_like(H),
+                              need1 ? *t_rowptr : none_like(H), need1 ? *t_col : none_like(H), need1 ? *t_val : none_like(H)});
+    }
+    ctx->saved_data["N"] = N;
+    ctx->saved_data["avg"] = avg;
+    ctx->saved_data["act1"] = act1;
+    ctx->saved_data["act2"] = act2;
+    return Z;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    auto sv = ctx->get_saved_variables();
+    TORCH_CHECK(sv.size() == 8, "layer12: backward through a call made without gradients");
+    const Tensor &H = sv[0], &W1 = sv[1], &W2 = sv[2], &AX = sv[3], &pre2 = sv[4];
+    const int64_t N = ctx->saved_data["N"].toInt(), act1 = ctx->saved_data["act1"].toInt(), act2 = ctx->saved_data["act2"].toInt();
+    const double avg = ctx->saved_data["avg"].toDouble();
+    Tensor dZ = grads[0].contiguous();
+    if (reinterpret_cast<uintptr_t>(dZ.const_data_ptr()) % 8 != 0) dZ = dZ.clone();
+    c10::DeviceGuard g(H.device());
+    Tensor dW1, dW2;
+    const int64_t K0 = H.size(2), F = W1.size(1), Nf = W2.size(1), R = H.size(0) * H.size(1);
+    if (ctx->needs_input_grad(1)) {
+      dW1 = at::empty_like(W1);
+      const int64_t need = tmgcn_layer12_bwd_workspace_bytes((int32_t)K0, (int32_t)F);
+      Tensor ws = at::empty({need}, H.options().dtype(at::kByte));
+      ok(tmgcn_layer12_bwd_f32((const int64_t*)ptr(sv[5]), (const int32_t*)ptr(sv[6]), (const float*)ptr(sv[7]), (const float*)ptr(dZ),
+                               act2 != TMGCN_ACT_NONE ? (const float*)ptr(pre2) : nullptr, (const float*)ptr(H), (const float*)ptr(W1),
+                               (int32_t)act1, (const float*)ptr(W2), (int32_t)act2, R, (int32_t)N, (int32_t)K0, (int32_t)F,
+                               (int32_t)Nf, (float*)ptr(dW1), (float)avg, ptr(ws), ws.numel(), stream_of(H)),
+         "tmgcn_layer12_bwd_f32");
+    }
+    if (ctx->needs_input_grad(2)) {
+      if (act2 != TMGCN_ACT_NONE) dW2 = bgemm_dW_act(AX, dZ, pre2, act2, false);
+      else dW2 = bgemm_dW(AX, dZ, false, TMGCN_DW_AUTO);
+    }
+    variable_list out(15);
+    out[1] = dW1;
+    out[2] = dW2;
+    return out;
+  }
+};
+
 struct ActivationFn : public torch::autograd::Function<ActivationFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& x, int64_t act) {
     at::AutoDispatchBelowADInplaceOrView guard;
@@ -755,6 +836,14 @@ std::tuple<Tensor, Tensor> head_loss_ad(const Tensor& Z, const OptTensor& W_fold
   auto out = HeadLossFn::apply(Z, W_fold, U, eptr, arow, ent, other, meta, counts, weight, sync, want_logits, need);
   return {out[0], out[1]};
 }
+Tensor layer12_ad(const Tensor& H, const Tensor& W1, const Tensor& W2, const Tensor& rowptr, const Tensor& col, const Tensor& val,
+                  const OptTensor& t_rowptr, const OptTensor& t_col, const OptTensor& t_val, int64_t N, double avg,
+                  int64_t act1, int64_t act2) {
+  TORCH_CHECK(!(at::GradMode::is_enabled() && H.requires_grad()), "layer12: H is the model's constant input (no gradient is formed for it)");
+  const bool grad = at::GradMode::is_enabled();
+  return Layer12Fn::apply(H, W1, W2, rowptr, col, val, t_rowptr, t_col, t_val, N, avg, act1, act2, grad && W1.requires_grad(),
+                          grad && W2.requires_grad());
+}
 Tensor activation_ad(const Tensor& x, int64_t act) { return ActivationFn::apply(x, act); }
 Tensor weighted_ce_ad(const Tensor& logits, const Tensor& target, const Tensor& weight, int64_t ignore_index) {
   return WeightedCeFn::apply(logits, target, weight, ignore_index);
@@ -803,6 +892,9 @@ TORCH_LIBRARY(tmgcn, m) {
         "Tensor? t_col, Tensor? t_val, int N, float avg_nnz_per_row, int act, int grid_reserve) -> Tensor");
   m.def("edge_head(Tensor Z, Tensor U, Tensor src, Tensor dst, Tensor? eptr, Tensor? eidx) -> Tensor");
   m.def("activation(Tensor x, int act) -> Tensor");
+  m.def("layer12(Tensor H, Tensor W1, Tensor W2, Tensor rowptr, Tensor col, Tensor val, Tensor? t_rowptr, Tensor? t_col, "
+        "Tensor? t_val, int N, float avg_nnz_per_row, int act1, int act2) -> Tensor");
+  m.def("layer12_supported(int K0, int F, int Nf) -> bool", &layer12_supported);
   m.def("weighted_ce(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> Tensor");
   m.def("head_loss(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor arow, Tensor ent, Tensor other, Tensor meta, "
         "Tensor counts, Tensor weight, Tensor(a!) sync, bool want_logits) -> (Tensor, Tensor)");
@@ -835,6 +927,7 @@ TORCH_LIBRARY_IMPL(tmgcn, CUDA, m) {
   m.impl("spmm_feature_gemm", &spmm_feature_gemm_ad);
   m.impl("edge_head", &edge_head_ad);
   m.impl("activation", &activation_ad);
+  m.impl("layer12", &layer12_ad);
   m.impl("weighted_ce", &weighted_ce_ad);
   m.impl("head_loss", &head_loss_ad);
 }
@@ -846,6 +939,7 @@ TORCH_LIBRARY_IMPL(tmgcn, Autograd, m) {
   m.impl("spmm_feature_gemm", &spmm_feature_gemm_ad);
   m.impl("edge_head", &edge_head_ad);
   m.impl("activation", &activation_ad);
+  m.impl("layer12", &layer12_ad);
   m.impl("weighted_ce", &weighted_ce_ad);
   m.impl("head_loss", &head_loss_ad);
 }
@@ -866,6 +960,7 @@ TORCH_LIBRARY_IMPL(tmgcn, CPU, m) {
   m.impl("spmm_feature_gemm", &spmm_feature_gemm_ad);
   m.impl("edge_head", &edge_head_ad);
   m.impl("activation", &activation_ad);
+  m.impl("layer12", &layer12_ad);
   m.impl("weighted_ce", &weighted_ce_ad);
   m.impl("head_loss", &head_loss_ad);
 }

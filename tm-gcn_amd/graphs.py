@@ -50,9 +50,12 @@ class GraphedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
+        # the upstream gradient of the loss, made once: a bare `loss.backward()` has autograd fill a fresh
+        # ones_like(loss) on every replay (one more launch per step)
+        self._one = torch.ones((), device=dev)
         with torch.cuda.graph(self.graph):
             self.loss, self.output = forward_loss()
-            self.loss.backward()
+            self.loss.backward(gradient=self._one.to(self.loss.dtype))
             optimizer.step()
 
     def __call__(self) -> torch.Tensor:

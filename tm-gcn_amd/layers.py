@@ -349,6 +349,10 @@ class EmbeddingGCN2(_Head, _Deliver, _Sharding, nn.Module):
             AtXt, eidx = self.AtXt, self._edges
         ps = not self.condensed_W
         W1, W2, U = self._p(self.W1, ps, gemm=True), self._p(self.W2, ps), self._p(self.U)
+        if not self.use_Minv and not self.apply_M_twice and not ps and self._shard is None:
+            # the as-run default branch (ehf:330-335 + 348-349): both layers in one launch each way, the layer-1
+            # activations never stored (ops.layer12; the unfused pair where the widths do not allow it)
+            return ops.layer12(AtXt, self._p(self.W1), self.nonlin2, self.At, W2), eidx, U, None
         # first layer (ehf:330-335)
         if self.use_Minv:
             Y = ops.activation(self._mt(ops.feature_gemm(AtXt, W1), self.Minv), self.nonlin2)
@@ -423,7 +427,9 @@ class EmbeddingKWGCN(_Head, _Deliver, _Sharding, nn.Module):
             eidx = self._edge_index(edges, self.dev)
         else:
             AX, eidx = self.AX, self._edges
-        if self.no_layers == 2:
+        if self.no_layers == 2 and self._shard is None:
+            Z = ops.layer12(AX, self._p(self.W1), self.nonlin2, self.A, self._p(self.W2))   # ehf:486-487 in one launch each way
+        elif self.no_layers == 2:
             Y = ops.feature_gemm(AX, self._p(self.W1, gemm=True), act=self.nonlin2)  # ehf:486
             Z = ops.spmm_feature_gemm(self.A, Y, self._p(self.W2))                 # ehf:487
         else:

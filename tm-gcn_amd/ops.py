@@ -502,6 +502,29 @@ def spmm_feature_gemm(A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, act=None,
     return feature_gemm(spmm(A, X), W, act=act)
 
 
+def layer12_supported(K0: int, F: int, Nf: int) -> bool:
+    return kernels.name == "hip" and bool(_lib.load().tmgcn_layer12_supported(K0, F, Nf))
+
+
+def layer12(H: torch.Tensor, W1: torch.Tensor, act1, A: BatchedCSR, W2: torch.Tensor, act2=None, fuse: Optional[bool] = None):
+    """act2((Â ⋆ act1(H·W1))·W2): layers 1 and 2 of the narrow 2-layer models (ehf:330-335 + 348-349; 486-487) with H the
+    model's cached constant (AtXt / AX).  One forward and one backward launch (csrc/layer12.hip) when H carries no
+    gradient, the weights are shared ([K,F] / [F,Nf]) and the widths are 2 -> even F <= 8 -> even Nf <= 8 — the layer-1
+    output, its pre-activation and their gradients are never stored; otherwise the two operators back to back."""
+    can = (W1.dim() == 2 and W2.dim() == 2 and H.dim() == 3 and not (H.requires_grad and torch.is_grad_enabled())
+           and W1.dtype == torch.float32 and W2.dtype == torch.float32 and _registered()
+           and layer12_supported(H.shape[-1], W1.shape[-1], W2.shape[-1]) and H.data_ptr() % 8 == 0)
+    if fuse is None:
+        fuse = can
+    if fuse and not can:
+        raise RuntimeError("layer12: operands do not allow the fused kernels")
+    if not fuse:
+        return spmm_feature_gemm(A, feature_gemm(H, W1, act=act1), W2, act=act2)
+    need = torch.is_grad_enabled() and W1.requires_grad
+    return kernels.ops.layer12(H, W1.contiguous(), W2.contiguous(), A.rowptr, A.col, A.val, *_csr_t(A, need), A.N, A.avg_nnz_per_row,
+                               _lib.ACT_IDS[act1], _lib.ACT_IDS[act2])
+
+
 def edge_head(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, fuse: Optional[bool] = None) -> torch.Tensor:
     """P4: logits[e] = [Z[src[e]], Z[dst[e]]] · U  (ehf:228-232).  One fused gather-and-dot kernel
     (atomic-free backward) when F <= 256 and C <= 8, else stock gather + matmul."""
