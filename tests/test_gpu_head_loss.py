@@ -218,3 +218,24 @@ def test_graphed_step_with_fused_loss_follows_the_eager_trajectory():
     assert step.fused
     got = [float(step()) for _ in range(7)]
     assert_close(np.array(got), d["losses"][3:], REL_TOL, "graph + fused loss, steps 4-10")
+
+
+@pytest.mark.parametrize("T,N,E", [(4, 30, 800), (6, 2000, 300)])       # dense entries / most rows without an entry
+def test_unit_gradient_fast_path(T, N, E):
+    """unit_grad=True + loss.backward(gradient=ops.unit_gradient(dev)): loss and gradients from ONE launch, bit-equal to
+    the default schedules; the promise is only a hint — another upstream gradient is still multiplied in."""
+    Z, _, U, edges, target, weight = _problem(T, N, 6, 2, E, seed=11)
+    idx = ops.EdgeIndex(edges, N, "cuda", T=T)
+    Za, Ua = Z.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    la = ops.head_loss(Za, idx, Ua, target, weight)
+    la.backward()
+    Zb, Ub = Z.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    lb = ops.head_loss(Zb, idx, Ub, target, weight, unit_grad=True)
+    lb.backward(gradient=ops.unit_gradient(Z.device))
+    assert torch.equal(la.detach(), lb.detach())
+    assert_close(Zb.grad, Za.grad, 1e-7, "dZ")          # deferred vs speculative schedule: same sums, one rounding apart at most
+    assert_close(Ub.grad, Ua.grad, 1e-7, "dU")
+    Zc, Uc = Z.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    (ops.head_loss(Zc, idx, Uc, target, weight, unit_grad=True) * 3.0).backward()
+    assert_close(Zc.grad, 3.0 * Za.grad, 1e-6, "dZ x 3")
+    assert_close(Uc.grad, 3.0 * Ua.grad, 1e-6, "dU x 3")

@@ -26,6 +26,7 @@
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -643,6 +644,28 @@ struct EdgeHeadFn : public torch::autograd::Function<EdgeHeadFn> {
   }
 };
 
+// The constant 1.0 a training step may hand to `loss.backward(gradient=…)` instead of letting autograd fill a fresh
+// ones_like(loss) every step: one tensor per device, made once.  HeadLossFn::backward recognises it BY ADDRESS and then
+// returns the gradients it formed with upstream gradient 1 unscaled — no scaling launch; any other gradient tensor is
+// multiplied in as usual.
+static std::mutex g_unit_mutex;
+static std::vector<Tensor> g_unit_grad(64);
+Tensor unit_gradient(const Tensor& like) {
+  TORCH_CHECK(like.is_cuda(), "unit_gradient: a ROCm tensor names the device");
+  const int dev = like.device().index();
+  std::lock_guard<std::mutex> lock(g_unit_mutex);
+  TORCH_CHECK(dev >= 0 && dev < (int)g_unit_grad.size(), "unit_gradient: device index out of range");
+  if (!g_unit_grad[dev].defined()) g_unit_grad[dev] = at::ones({}, like.options().dtype(at::kFloat));
+  return g_unit_grad[dev];
+}
+static bool is_unit_gradient(const Tensor& g) {
+  if (!g.defined() || !g.is_cuda()) return false;
+  const int dev = g.device().index();
+  std::lock_guard<std::mutex> lock(g_unit_mutex);
+  return dev >= 0 && dev < (int)g_unit_grad.size() && g_unit_grad[dev].defined() && g.numel() == 1 &&
+         g.const_data_ptr() == g_unit_grad[dev].const_data_ptr();
+}
+
 // loss (and, as a non-differentiable by-product, the logits) of the fused head + criterion.  Two schedules:
 //   speculative  the gradients are formed in the SAME launch as the loss (upstream gradient 1) and kept; backward
 //                multiplies them by the upstream gradient of the loss in one small launch.  Taken when the entry
@@ -655,12 +678,14 @@ struct HeadLossFn : public torch::autograd::Function<HeadLossFn> {
   static variable_list forward(AutogradContext* ctx, const Tensor& Z, const OptTensor& W_fold, const Tensor& U,
                                const Tensor& eptr, const Tensor& arow, const Tensor& ent, const Tensor& other,
                                const Tensor& meta, const Tensor& counts, const Tensor& weight, const Tensor& sync,
-                               bool want_logits, bool need) {
+                               bool want_logits, bool need, bool unit_grad) {
     at::AutoDispatchBelowADInplaceOrView guard;
     const bool fold = W_fold.has_value() && W_fold->defined();
     Tensor Z2 = Z.contiguous().reshape({-1, Z.size(-1)});
     const int64_t R = Z2.size(0), F = fold ? W_fold->size(1) : Z2.size(1), E = ent.numel() / 2;
-    const bool deferred = need && !fold && R * F * 8 > E * 10;
+    // unit_grad: the caller will run backward with tmgcn::unit_gradient() — the speculative gradients need no scaling
+    // pass then, so one launch does everything whatever the shape
+    const bool deferred = need && !fold && !unit_grad && R * F * 8 > E * 10;
     auto [loss, logits, dZ, dU] = head_loss_fwd(Z2, W_fold, U, eptr, arow, ent, other, meta, counts, weight, sync, OptTensor(),
                                                 need && !deferred, want_logits, true);
     if (need && deferred)
@@ -687,9 +712,14 @@ struct HeadLossFn : public torch::autograd::Function<HeadLossFn> {
       gu = std::get<3>(out);
     } else {
       TORCH_CHECK(sv.size() == 2, "head_loss: backward through a call made without gradients");
-      std::tie(gz, gu) = scale2(g, sv[0], sv[1]);
+      if (is_unit_gradient(grads[0])) {
+        gz = sv[0];
+        gu = sv[1];
+      } else {
+        std::tie(gz, gu) = scale2(g, sv[0], sv[1]);
+      }
     }
-    variable_list out(13);
+    variable_list out(14);
     if (fold) out[1] = gz; else out[0] = gz.reshape(ctx->saved_data["zshape"].toIntVector());
     out[2] = gu;
     return out;
@@ -830,10 +860,11 @@ Tensor edge_head_ad(const Tensor& Z, const Tensor& U, const Tensor& src, const T
 }
 std::tuple<Tensor, Tensor> head_loss_ad(const Tensor& Z, const OptTensor& W_fold, const Tensor& U, const Tensor& eptr,
                                         const Tensor& arow, const Tensor& ent, const Tensor& other, const Tensor& meta,
-                                        const Tensor& counts, const Tensor& weight, const Tensor& sync, bool want_logits) {
+                                        const Tensor& counts, const Tensor& weight, const Tensor& sync, bool want_logits,
+                                        bool unit_grad) {
   const bool fold = W_fold.has_value() && W_fold->defined();
   const bool need = at::GradMode::is_enabled() && (U.requires_grad() || (fold ? W_fold->requires_grad() : Z.requires_grad()));
-  auto out = HeadLossFn::apply(Z, W_fold, U, eptr, arow, ent, other, meta, counts, weight, sync, want_logits, need);
+  auto out = HeadLossFn::apply(Z, W_fold, U, eptr, arow, ent, other, meta, counts, weight, sync, want_logits, need, unit_grad);
   return {out[0], out[1]};
 }
 Tensor layer12_ad(const Tensor& H, const Tensor& W1, const Tensor& W2, const Tensor& rowptr, const Tensor& col, const Tensor& val,
@@ -897,7 +928,8 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("layer12_supported(int K0, int F, int Nf) -> bool", &layer12_supported);
   m.def("weighted_ce(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> Tensor");
   m.def("head_loss(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor arow, Tensor ent, Tensor other, Tensor meta, "
-        "Tensor counts, Tensor weight, Tensor(a!) sync, bool want_logits) -> (Tensor, Tensor)");
+        "Tensor counts, Tensor weight, Tensor(a!) sync, bool want_logits, bool unit_grad) -> (Tensor, Tensor)");
+  m.def("unit_gradient(Tensor like) -> Tensor");
 }
 
 // ROCm tensors carry the CUDA dispatch key in PyTorch-ROCm
@@ -919,6 +951,7 @@ TORCH_LIBRARY_IMPL(tmgcn, CUDA, m) {
   m.impl("head_loss_fwd", &head_loss_fwd);
   m.impl("scale2", &scale2);
   m.impl("sgd_step", &sgd_step);
+  m.impl("unit_gradient", &unit_gradient);
   // below the Autograd key (inference mode, or called from inside another autograd node) the
   // differentiable operators are their plain forwards
   m.impl("m_transform", &m_transform_ad);

@@ -29,14 +29,15 @@ class GraphedTrainStep:
         dev = target.device
         if dev.type != "cuda":
             raise RuntimeError("GraphedTrainStep needs ROCm tensors")
+        from . import ops
         self.fused = bool(fused_loss) and hasattr(model, "loss")
         self.keep_logits = keep_logits or not self.fused
 
         def forward_loss():
             if self.fused:
                 if self.keep_logits:
-                    return model.loss(criterion, target, want_logits=True)
-                return model.loss(criterion, target), None
+                    return model.loss(criterion, target, want_logits=True, unit_grad=True)
+                return model.loss(criterion, target, unit_grad=True), None
             out = model()
             return criterion(out, target), out
 
@@ -45,17 +46,19 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, lazy init, plans)
             for _ in range(warmup):
                 optimizer.zero_grad(set_to_none=True)
-                forward_loss()[0].backward()
+                forward_loss()[0].backward(gradient=ops.unit_gradient(dev))
                 optimizer.step()
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        # the upstream gradient of the loss, made once: a bare `loss.backward()` has autograd fill a fresh
-        # ones_like(loss) on every replay (one more launch per step)
-        self._one = torch.ones((), device=dev)
+        # the upstream gradient of the loss, made once (ops.unit_gradient): a bare `loss.backward()` has autograd fill a
+        # fresh ones_like(loss) on every replay (one more launch per step), and the fused head + loss skips its scaling
+        # launch when it meets this very tensor
+        from . import ops
+        self._one = ops.unit_gradient(dev)
         with torch.cuda.graph(self.graph):
             self.loss, self.output = forward_loss()
-            self.loss.backward(gradient=self._one.to(self.loss.dtype))
+            self.loss.backward(gradient=self._one)
             optimizer.step()
 
     def __call__(self) -> torch.Tensor:

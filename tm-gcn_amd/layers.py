@@ -197,12 +197,13 @@ class _Head:
             Z = ops.feature_gemm(Z, fold)                                    # ehf:222
         return self._deliver(self._head(Z, eidx, U))
 
-    def loss(self, criterion, target: torch.Tensor, At=None, X=None, edges=None, want_logits: bool = False):
+    def loss(self, criterion, target: torch.Tensor, At=None, X=None, edges=None, want_logits: bool = False,
+             unit_grad: bool = False):
         """``criterion(self(At, X, edges), target)``; with ``want_logits`` also the logits (detached: a by-product
         for the scripts' accuracy lines).  Fused whenever the criterion is the scripts' weighted mean cross entropy
         (nn.CrossEntropyLoss(weight=...), losses.WeightedCrossEntropy, or the class-weight tensor itself), the
         model is not slice-sharded and the head is narrow (even F <= 8, C <= 4); any other case runs the
-        unfused statements, same value."""
+        unfused statements, same value.  ``unit_grad``: see ops.head_loss (graphs.GraphedTrainStep sets it)."""
         spec = _criterion_spec(criterion, self.F[-1], self.dev) if self._shard is None else None
         if spec is None:
             out = self(At, X, edges)
@@ -210,7 +211,7 @@ class _Head:
             l = crit(out, target if self.host_operands else target.to(out.device))
             return (l, out.detach()) if want_logits else l
         Z, eidx, U, fold = self._embed(At, X, edges)
-        res = ops.head_loss(Z, eidx, U, target, spec[0], spec[1], want_logits, fold_W=fold)
+        res = ops.head_loss(Z, eidx, U, target, spec[0], spec[1], want_logits, fold_W=fold, unit_grad=unit_grad)
         if want_logits:
             return self._deliver(res[0]), self._deliver(res[1])
         return self._deliver(res)

@@ -548,15 +548,26 @@ def head_loss_supported(F: int, Cn: int, K: int = 0) -> bool:
     return kernels.name == "hip" and bool(_lib.load().tmgcn_head_loss_supported(F, Cn, K))
 
 
+def unit_gradient(device) -> torch.Tensor:
+    """The constant 1.0 (one 0-dim fp32 tensor per device) to pass as ``loss.backward(gradient=...)``: autograd then
+    does not fill a fresh ones_like(loss) every step, and the fused head + loss recognises it by address and skips
+    the launch that multiplies its gradients by the upstream gradient."""
+    return kernels.ops.unit_gradient(torch.empty(0, device=device))
+
+
 def head_loss(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, target: torch.Tensor, weight: torch.Tensor,
-              ignore_index: int = -100, want_logits: bool = False, fold_W: Optional[torch.Tensor] = None):
+              ignore_index: int = -100, want_logits: bool = False, fold_W: Optional[torch.Tensor] = None,
+              unit_grad: bool = False):
     """``nn.CrossEntropyLoss(weight)(edge_head(Z, edges, U), target)`` — P4 and the criterion of every experiment
     script (ehf:228-232 + experiment_reddit_our_link_prediction.py:69, 79) — with every gradient, in ONE launch
     (csrc/head_loss.hip) where the widths allow (even F <= 8, C <= 4, 32-bit indices); otherwise the edge head
     followed by the fused weighted CE.  Returns the loss, or (loss, logits) with ``want_logits`` (the logits are
     a non-differentiable by-product there: differentiate the loss).
     fold_W: Z is the 1-layer model's cached AtXt [T,N,2] and fold_W its shared weight [2,F]: Z = AtXt·W (ehf:222)
-    is recomputed inside the kernel and dW returned through autograd — nothing of size [T,N,F] is stored."""
+    is recomputed inside the kernel and dW returned through autograd — nothing of size [T,N,F] is stored.
+    unit_grad: a promise that backward will be run as ``loss.backward(gradient=ops.unit_gradient(device))``: loss and
+    gradients then take one launch for every shape (a different upstream gradient is still honoured, at the price of
+    one scaling launch)."""
     F = (fold_W if fold_W is not None else Z).shape[-1]
     K = Z.shape[-1] if fold_W is not None else 0
     Cn = U.shape[-1]
@@ -572,7 +583,7 @@ def head_loss(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, target: torch.
     plan = head_loss_plan(edges, R, target, Cn, ignore_index)
     w = weight.detach().to(device=Z.device, dtype=torch.float32).contiguous()
     loss, logits = kernels.ops.head_loss(Z, fold_W, U.contiguous(), plan.eptr, plan.arow, plan.ent, plan.other, plan.meta,
-                                         plan.counts, w, plan.sync, bool(want_logits))
+                                         plan.counts, w, plan.sync, bool(want_logits), bool(unit_grad))
     return (loss, logits) if want_logits else loss
 
 
