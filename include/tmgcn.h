@@ -319,6 +319,10 @@ int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t K, const fl
 int tmgcn_sgd_step(void* const* params, const void* const* grads, void* const* momentum_bufs, const int64_t* numel,
                    int32_t n, int32_t bf16, float lr, float momentum, float dampening, float weight_decay,
                    int32_t nesterov, int32_t maximize, int32_t first_step, void* stream);
+/* bf16 <-> fp32 of up to 16 tensors in one launch (to_bf16 = 0: src bf16 -> dst fp32; 1: src fp32 -> dst bf16, round to
+ * nearest even).  HOST arrays of DEVICE pointers. */
+int tmgcn_cast_multi(const void* const* src, void* const* dst, const int64_t* numel, int32_t n, int32_t to_bf16,
+                     void* stream);
 /* out_a = g·a, out_b = g·b (g: one float on the device — the upstream gradient of a scalar loss) */
 int tmgcn_scale2_f32(const float* g, const float* a, float* out_a, int64_t na, const float* b, float* out_b,
                      int64_t nb, void* stream);

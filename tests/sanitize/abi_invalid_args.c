@@ -91,6 +91,9 @@ int main(void) {
     printf("FAIL head_loss workspace size\n");
   }
   BAD(tmgcn_scale2_f32(0, 0, 0, 4, 0, 0, 4, 0));
+  BAD(tmgcn_cast_multi(0, 0, 0, 2, 0, 0));                                                 /* null host arrays */
+  BAD(tmgcn_cast_multi(hg, hp, hn, 2, 1, 0));                                              /* null device pointers */
+  NOP(tmgcn_cast_multi(hg, hp, hn, 0, 1, 0));
   /* optimizer step (HOST arrays of device pointers) */
   BAD(tmgcn_sgd_step(hp, hg, hp, hn, 17, 0, .1f, .9f, 0.f, 0.f, 0, 0, 0, 0));             /* too many tensors */
   BAD(tmgcn_sgd_step(hp, hg, hp, hn, 2, 0, .1f, .9f, 0.f, 0.f, 0, 0, 0, 0));              /* null device pointers */

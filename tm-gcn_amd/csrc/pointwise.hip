@@ -164,6 +164,27 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(SgdArgs a) {
   st_elem(a.param[t], i, a.bf16, fmaf(-a.lr, g, p));
 }
 
+// bf16 <-> fp32 of up to 16 small tensors in one launch (the "bf16 weights" configuration widens its two or three
+// parameters every step and rounds their gradients back: six single-tensor cast launches otherwise)
+struct CastArgs {
+  const void* src[kSgdMaxTensors];
+  void* dst[kSgdMaxTensors];
+  int32_t first_block[kSgdMaxTensors + 1];
+  int32_t numel[kSgdMaxTensors];
+  int32_t n, to_bf16;
+};
+
+__global__ __launch_bounds__(256) void cast_multi_kernel(CastArgs a) {
+  int t = 0;
+#pragma unroll
+  for (int k = 1; k < kSgdMaxTensors; ++k)
+    if (k < a.n && (int)blockIdx.x >= a.first_block[k]) t = k;
+  const int i = ((int)blockIdx.x - a.first_block[t]) * 256 + threadIdx.x;
+  if (i >= a.numel[t]) return;
+  if (a.to_bf16) st_elem(a.dst[t], i, 1, reinterpret_cast<const float*>(a.src[t])[i]);
+  else reinterpret_cast<float*>(a.dst[t])[i] = ld_elem(a.src[t], i, 1);
+}
+
 static unsigned stream_grid(int64_t n) {
   int64_t b = (n / 4 + 255) / 256;
   if (b < 1) b = 1;
@@ -235,4 +256,29 @@ extern "C" int tmgcn_sgd_step(void* const* params, const void* const* grads, voi
   if (blocks == 0) return TMGCN_OK;
   hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("sgd_step");
+}
+
+extern "C" int tmgcn_cast_multi(const void* const* src, void* const* dst, const int64_t* numel, int32_t n, int32_t to_bf16,
+                                void* stream) {
+  TMGCN_REQUIRE(n >= 0 && n <= kSgdMaxTensors, "cast_multi: 0 <= n <= %d tensors per call (got %d)", kSgdMaxTensors, n);
+  if (n == 0) return TMGCN_OK;
+  TMGCN_REQUIRE(src && dst && numel, "cast_multi: null pointer");
+  CastArgs a{};
+  int64_t blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    TMGCN_REQUIRE(numel[k] >= 0 && numel[k] < (int64_t)0x7fffffff && (numel[k] == 0 || (src[k] && dst[k])),
+                  "cast_multi: tensor %d: null pointer or bad size", k);
+    a.src[k] = src[k];
+    a.dst[k] = dst[k];
+    a.numel[k] = (int32_t)numel[k];
+    a.first_block[k] = (int32_t)blocks;
+    blocks += (numel[k] + 255) / 256;
+    TMGCN_REQUIRE(blocks < (int64_t)0x7fffffff, "cast_multi: too many elements for one launch");
+  }
+  a.first_block[n] = (int32_t)blocks;
+  a.n = n;
+  a.to_bf16 = to_bf16;
+  if (blocks == 0) return TMGCN_OK;
+  hipLaunchKernelGGL(cast_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("cast_multi");
 }

@@ -485,6 +485,51 @@ void sgd_step(at::TensorList params, at::TensorList grads, at::TensorList bufs, 
      "tmgcn_sgd_step");
 }
 
+// bf16 parameters -> fp32 copies (one launch for all of them); backward: the fp32 gradients rounded to bf16 (one launch)
+std::vector<Tensor> cast_multi(at::TensorList src, bool to_bf16) {
+  const int64_t n = (int64_t)src.size();
+  TORCH_CHECK(n >= 1 && n <= 16, "cast_multi: 1..16 tensors");
+  const void* sp[16];
+  void* dp[16];
+  int64_t ne[16];
+  std::vector<Tensor> out;
+  c10::DeviceGuard g(src[0].device());
+  for (int64_t k = 0; k < n; ++k) {
+    want(src[k], "cast_multi source", to_bf16 ? at::kFloat : at::kBFloat16);
+    out.push_back(at::empty_like(src[k], src[k].options().dtype(to_bf16 ? at::kBFloat16 : at::kFloat)));
+    sp[k] = src[k].const_data_ptr();
+    dp[k] = out[k].data_ptr();
+    ne[k] = src[k].numel();
+  }
+  ok(tmgcn_cast_multi(sp, dp, ne, (int32_t)n, to_bf16 ? 1 : 0, stream_of(src[0])), "tmgcn_cast_multi");
+  return out;
+}
+
+struct WidenFn : public torch::autograd::Function<WidenFn> {
+  static variable_list forward(AutogradContext* ctx, at::TensorList params) {   // TensorList: each element is an input of the node
+    at::AutoDispatchBelowADInplaceOrView guard;
+    return cast_multi(params, false);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    at::AutoDispatchBelowADInplaceOrView guard;
+    // a parameter that took no part in the step has no gradient: cast the ones that have
+    std::vector<Tensor> have;
+    std::vector<size_t> at_;
+    for (size_t k = 0; k < grads.size(); ++k)
+      if (grads[k].defined()) {
+        have.push_back(grads[k].contiguous());
+        at_.push_back(k);
+      }
+    variable_list out(grads.size());
+    if (!have.empty()) {
+      auto r = cast_multi(have, true);
+      for (size_t i = 0; i < at_.size(); ++i) out[at_[i]] = r[i];
+    }
+    return out;
+  }
+};
+std::vector<Tensor> widen_params_ad(at::TensorList params) { return WidenFn::apply(params); }
+
 bool spmm_gemm_supported(int64_t K, int64_t Nf) { return tmgcn_spmm_gemm_supported((int32_t)K, (int32_t)Nf) != 0; }
 bool layer12_supported(int64_t K0, int64_t F, int64_t Nf) { return tmgcn_layer12_supported((int32_t)K0, (int32_t)F, (int32_t)Nf) != 0; }
 bool edge_head_supported(int64_t F, int64_t C) { return tmgcn_edge_head_supported((int32_t)F, (int32_t)C) != 0; }
@@ -930,6 +975,7 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("head_loss(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor arow, Tensor ent, Tensor other, Tensor meta, "
         "Tensor counts, Tensor weight, Tensor(a!) sync, bool want_logits, bool unit_grad) -> (Tensor, Tensor)");
   m.def("unit_gradient(Tensor like) -> Tensor");
+  m.def("widen_params(Tensor[] params) -> Tensor[]");
 }
 
 // ROCm tensors carry the CUDA dispatch key in PyTorch-ROCm
@@ -961,6 +1007,7 @@ TORCH_LIBRARY_IMPL(tmgcn, CUDA, m) {
   m.impl("edge_head", &edge_head_ad);
   m.impl("activation", &activation_ad);
   m.impl("layer12", &layer12_ad);
+  m.impl("widen_params", &widen_params_ad);
   m.impl("weighted_ce", &weighted_ce_ad);
   m.impl("head_loss", &head_loss_ad);
 }
@@ -973,6 +1020,7 @@ TORCH_LIBRARY_IMPL(tmgcn, Autograd, m) {
   m.impl("edge_head", &edge_head_ad);
   m.impl("activation", &activation_ad);
   m.impl("layer12", &layer12_ad);
+  m.impl("widen_params", &widen_params_ad);
   m.impl("weighted_ce", &weighted_ce_ad);
   m.impl("head_loss", &head_loss_ad);
 }
@@ -994,6 +1042,7 @@ TORCH_LIBRARY_IMPL(tmgcn, CPU, m) {
   m.impl("edge_head", &edge_head_ad);
   m.impl("activation", &activation_ad);
   m.impl("layer12", &layer12_ad);
+  m.impl("widen_params", &widen_params_ad);
   m.impl("weighted_ce", &weighted_ce_ad);
   m.impl("head_loss", &head_loss_ad);
 }

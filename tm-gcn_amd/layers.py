@@ -142,12 +142,24 @@ class _Sharding:
         the standalone P3 kernel, which takes a bf16-stored weight as it is (three plane products
         instead of six, ops.HipKernels.gemm); the sharded model still widens, so that the gradient
         is all-reduced in fp32 and rounded once."""
-        w = param if (gemm and self._shard is None and param.dtype == torch.bfloat16) else _w(param)
+        wide = getattr(self, "_wide", None)
+        if gemm and self._shard is None and param.dtype == torch.bfloat16:
+            w = param
+        elif wide and id(param) in wide:
+            w = wide[id(param)]
+        else:
+            w = _w(param)
         if self._shard is not None:
             w = self._shard.shared(w)
             if per_slice:
                 w = w[self._shard.k0:self._shard.k1].contiguous()
         return w
+
+    def _widen(self):
+        """bf16-stored parameters ("bf16 weights"): their fp32 copies for this call in ONE launch, the gradients rounded
+        back in one more (ops.widen_params) — instead of a cast launch per parameter each way."""
+        ps = [p for p in self.parameters(recurse=False) if p.dtype == torch.bfloat16]
+        self._wide = dict(zip(map(id, ps), ops.widen_params(ps))) if (ps and self._shard is None and ps[0].is_cuda) else None
 
     def _edge_index(self, edges, dev):
         if self._shard is None:
@@ -190,6 +202,16 @@ class _Head:
       loss(criterion, target)   criterion(forward(...), target) in ONE launch (ops.head_loss): the per-epoch
                                 statements  `output = gcn(); loss = criterion(output, target)`  of the scripts
                                 (experiment_reddit_our_link_prediction.py:76-77) as one call, gradients included."""
+
+    def _embed(self, At=None, X=None, edges=None):
+        # the widened copies of bf16 parameters live for this call only (the autograd graph keeps what it needs): a
+        # model that kept them until the next call would free the previous step's copies in the middle of that step —
+        # under hipGraph capture that is a free of non-captured memory inside the capture (it crashed capture_end)
+        self._widen()
+        try:
+            return self._embed_impl(At, X, edges)
+        finally:
+            self._wide = None
 
     def forward(self, At=None, X=None, edges=None):
         Z, eidx, U, fold = self._embed(At, X, edges)
@@ -258,7 +280,7 @@ class EmbeddingGCN(_Head, _Deliver, _Sharding, nn.Module):
         """ehf:203-208 — P1 then P2 (sharded: this rank's slices of both)."""
         return ops.spmm(At, self._mt_input(X, self.Mop))
 
-    def _embed(self, At=None, X=None, edges=None):
+    def _embed_impl(self, At=None, X=None, edges=None):
         if _is_recompute_call(At, X, edges):
             AtXt = self.compute_AtXt(_adj(self._own(At), self.N, self.dev), _feat(X, self.dev))
             eidx = self._edge_index(edges, self.dev)
@@ -342,7 +364,7 @@ class EmbeddingGCN2(_Head, _Deliver, _Sharding, nn.Module):
         """ehf:307-312 — P1 then P2 (sharded: this rank's slices of both; X is the whole constant input)."""
         return ops.spmm(At, self._mt_input(X, self.Mop))
 
-    def _embed(self, At=None, X=None, edges=None):
+    def _embed_impl(self, At=None, X=None, edges=None):
         if _is_recompute_call(At, X, edges):
             AtXt = self.compute_AtXt(_adj(self._own(At), self.N, self.dev), _feat(X, self.dev))
             eidx = self._edge_index(edges, self.dev)
@@ -415,7 +437,7 @@ class EmbeddingKWGCN(_Head, _Deliver, _Sharding, nn.Module):
             AX = torch.cat((AX, AX.new_zeros(T_mine - A.T, self.N, AX.shape[-1])), dim=0)
         return AX
 
-    def _embed(self, A=None, X=None, edges=None):
+    def _embed_impl(self, A=None, X=None, edges=None):
         if _is_recompute_call(A, X, edges):
             n_call = A.T if isinstance(A, BatchedCSR) else len(A)
             if n_call > self.T:

@@ -548,6 +548,12 @@ def head_loss_supported(F: int, Cn: int, K: int = 0) -> bool:
     return kernels.name == "hip" and bool(_lib.load().tmgcn_head_loss_supported(F, Cn, K))
 
 
+def widen_params(params):
+    """fp32 copies of bf16-stored parameters in one launch (registered autograd: the gradients are rounded back to
+    bf16 in one launch too)."""
+    return list(kernels.ops.widen_params(list(params))) if params else []
+
+
 def unit_gradient(device) -> torch.Tensor:
     """The constant 1.0 (one 0-dim fp32 tensor per device) to pass as ``loss.backward(gradient=...)``: autograd then
     does not fill a fresh ones_like(loss) every step, and the fused head + loss recognises it by address and skips
