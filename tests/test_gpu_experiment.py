@@ -135,10 +135,25 @@ def test_device_result_takes_host_operands_the_way_the_scripts_use_them():
     assert isinstance(loss, DeviceResult) and loss.is_cuda
     loss_ref = nn.CrossEntropyLoss(weight=class_weights.double())(ref, target)
     assert abs(float(loss) - float(loss_ref)) <= 1e-6 * abs(float(loss_ref))
+    # that loss came from the one-pass head + loss kernel (hosted.FUSE_HEAD_LOSS): its parameter gradients are what
+    # differentiating through the logits gives — and d loss / d logits itself is there when the switch is off
     m.zero_grad()
-    (g_out,) = torch.autograd.grad(loss, out, retain_graph=True)
-    (g_ref,) = torch.autograd.grad(loss_ref, ref)
-    assert_close(g_out, g_ref, 1e-6, "dloss/dlogits")
+    loss.backward(retain_graph=True)
+    fused_grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    from tmgcn_amd import hosted as hosted_mod
+    hosted_mod.FUSE_HEAD_LOSS = False
+    try:
+        loss2 = nn.CrossEntropyLoss(weight=class_weights)(out, target)
+        assert abs(float(loss2) - float(loss)) <= 1e-6 * abs(float(loss))
+        (g_out,) = torch.autograd.grad(loss2, out, retain_graph=True)
+        (g_ref,) = torch.autograd.grad(loss_ref, ref)
+        assert_close(g_out, g_ref, 1e-6, "dloss/dlogits")
+        m.zero_grad()
+        loss2.backward(retain_graph=True)
+        for n, p in m.named_parameters():
+            assert_close(fused_grads[n], p.grad, 2e-6, "fused vs through-the-logits d" + n)
+    finally:
+        hosted_mod.FUSE_HEAD_LOSS = True
     # unweighted, ignore_index targets, and forms the kernel does not cover (torch runs them on the device)
     tgt_ign = target.clone()
     tgt_ign[::7] = -100
@@ -171,20 +186,17 @@ def test_device_result_takes_host_operands_the_way_the_scripts_use_them():
     assert abs(float(MAP) - float(MAP2)) <= 1e-12 and abs(float(MRR) - float(MRR2)) <= 1e-12
 
 
-def test_repeated_large_host_uploads_are_announced_once():
-    """hosted.DeviceResult uploads host operands on every call; for a large tensor that comes back every
-    epoch (the scripts' targets) it says so — once — instead of silently paying PCIe each time."""
-    import warnings
+def test_host_operands_cross_pcie_once():
+    """hosted.DeviceResult keeps the device copy of a host operand on the host tensor: the scripts' targets and class
+    weights are uploaded once, not every epoch; a tensor that is modified in between is uploaded again."""
     from tmgcn_amd import hosted
     out = torch.zeros(300_000, 2, device="cuda").as_subclass(hosted.DeviceResult)
     big = torch.ones(300_000, 2)                                     # 2.4 MB on the host
     small = torch.ones(2)
-    with warnings.catch_warnings(record=True) as seen:
-        warnings.simplefilter("always")
-        for _ in range(6):
-            r = out + big
-            r = r * small
-    assert r.is_cuda
-    mine = [w for w in seen if "uploaded each time" in str(w.message)]
-    assert len(mine) == 1 and issubclass(mine[0].category, RuntimeWarning)
-    assert big._tmgcn_uploads == 6 and not hasattr(small, "_tmgcn_uploads")     # the count lives on the tensor, not in the module
+    for _ in range(6):
+        r = out + big
+        r = r * small
+    assert r.is_cuda and float(r.sum()) == 600_000.0
+    assert big._tmgcn_uploads == 1 and small._tmgcn_uploads == 1
+    big[0, 0] = 5.0                                                  # written to: the stale copy is not served
+    assert float((out + big).sum()) == 600_004.0 and big._tmgcn_uploads == 2

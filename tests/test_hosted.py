@@ -56,15 +56,25 @@ def test_fused_cross_entropy_declines_what_the_kernel_does_not_cover():
     assert _fused_cross_entropy(z, t.float()) is None and _fused_cross_entropy(torch.randn(4, 9), t) is None
 
 
-def test_repeated_upload_warns_once_per_tensor_and_keeps_no_module_state():
-    """The count lives on the host tensor that is being uploaded; nothing process-wide."""
+def test_host_operands_are_uploaded_once_per_content_and_keep_no_module_state():
+    """The device copy and its version stamp live on the host tensor; an unchanged tensor is uploaded once, a tensor
+    written to in between again; a large one that keeps changing warns once."""
     assert not any(n in vars(hosted) for n in ("_UPLOADS", "_warned"))
+    dev = torch.device("meta")                                              # a device that needs no hardware
     big = torch.zeros(300_000)                                              # 1.2 MB > the 1 MB threshold
+    a = hosted._device_copy(big, dev)
+    assert a.device.type == "meta" and hosted._device_copy(big, dev) is a and big._tmgcn_uploads == 1
+    with warnings.catch_warnings(record=True) as got:
+        warnings.simplefilter("always")
+        for _ in range(4):
+            big.add_(1.0)                                                   # the version counter moves: stale copy
+            assert hosted._device_copy(big, dev) is not a
+    assert big._tmgcn_uploads == 5
+    assert len([w for w in got if issubclass(w.category, RuntimeWarning)]) == 1
     small = torch.zeros(10)
     with warnings.catch_warnings(record=True) as got:
         warnings.simplefilter("always")
         for _ in range(5):
-            hosted._note_upload(big)
-            hosted._note_upload(small)
-    assert len([w for w in got if issubclass(w.category, RuntimeWarning)]) == 1
-    assert big._tmgcn_uploads == 5 and not hasattr(small, "_tmgcn_uploads")
+            small.add_(1.0)
+            hosted._device_copy(small, dev)
+    assert not got

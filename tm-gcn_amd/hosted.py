@@ -57,24 +57,35 @@ def _plain_scope():
 
 _FORCE_FLAG_SCOPE = False        # tests flip this to exercise the public-API-only path
 
+# `criterion(gcn(), target)` on the model's own output takes the one-pass head + loss kernel (loss and the gradients of
+# the embedding and of U in one launch, _fused_head_loss) — what the scripts' `loss.backward()` needs.  The one thing it
+# does not provide is d loss / d logits itself (the loss then no longer hangs off the logits in the autograd graph):
+# a caller that differentiates with respect to the output tensor, or puts a hook on it, sets this to False.
+FUSE_HEAD_LOSS = True
 
-def _note_upload(x: torch.Tensor) -> None:
-    """The uploads are a convenience, not free: a host tensor that takes part in every epoch (the scripts'
-    targets) crosses PCIe every epoch.  Say so instead of staying silent: the count lives on the host
-    tensor itself (no module-level bookkeeping), the third upload of the same tensor warns, and the
-    warnings module shows a given call site once."""
-    nbytes = x.numel() * x.element_size()
-    if nbytes < _WARN_BYTES:
-        return
-    n = getattr(x, "_tmgcn_uploads", 0) + 1
+
+def _device_copy(x: torch.Tensor, dev) -> torch.Tensor:
+    """The copy of a host tensor on `dev`, uploaded ONCE per content: the copy is kept on the host tensor itself (no
+    module-level bookkeeping) together with the tensor's version counter, so that the targets and class weights a script
+    hands to its criterion every epoch cross PCIe once (Reddit-LP: a 26 MB target tensor, 0.6 ms per epoch otherwise) and a
+    tensor that was written to in between is uploaded again.  The device copy lives as long as the host tensor does.
+    A tensor of a megabyte or more that KEEPS changing (third upload) gets one RuntimeWarning."""
+    ver = x._version
+    c = getattr(x, "_tmgcn_dev", None)
+    if c is not None and c[0] == ver and c[1].device == dev:
+        return c[1]
+    y = x.to(dev)
     try:
+        n = getattr(x, "_tmgcn_uploads", 0) + 1
         x._tmgcn_uploads = n
-    except AttributeError:           # an object that does not take attributes: nothing to count on
-        return
-    if n == 3:
-        warnings.warn(f"tmgcn_amd: a host tensor of {nbytes / 1e6:.0f} MB is combined with a device-resident result on every "
-                      "call and is uploaded each time (about 20 us per MB); keep it on the device (`.cuda()`) to avoid that",
-                      RuntimeWarning, stacklevel=4)
+        x._tmgcn_dev = (ver, y)
+    except AttributeError:           # an object that does not take attributes: nothing to keep a copy on
+        return y
+    if n == 3 and x.numel() * x.element_size() >= _WARN_BYTES:
+        warnings.warn(f"tmgcn_amd: a host tensor of {x.numel() * x.element_size() / 1e6:.0f} MB that is combined with a "
+                      "device-resident result keeps changing and is uploaded again each time (about 20 us per MB); keep it on "
+                      "the device (`.cuda()`) to avoid that", RuntimeWarning, stacklevel=4)
+    return y
 
 
 def _is_inplace_or_out(func, kwargs) -> bool:
@@ -93,7 +104,24 @@ class DeviceResult(torch.Tensor):
         # torch.Tensor's own (public) default implementation.
         if getattr(_reentry, "on", False):
             return super().__torch_function__(func, types, args, kwargs)
+        if len(args) == 1 and not kwargs and isinstance(args[0], DeviceResult):
+            # one operand, itself a DeviceResult (loss.backward(), out.detach(), loss.item(), …): nothing to move — the
+            # per-epoch `loss.backward()` skips the argument walk below
+            return super().__torch_function__(func, types, args, kwargs)
         with _plain_scope():
+            if func is F.cross_entropy and len(args) >= 2 and isinstance(args[0], DeviceResult) and args[0].device.type != "cpu":
+                # the per-epoch call of every script — criterion(gcn(), target) — without the generic argument walk
+                dev = args[0].device
+                mv = lambda x: _device_copy(x, dev) if (isinstance(x, torch.Tensor) and x.device.type == "cpu") else x
+                args = (args[0], mv(args[1])) + tuple(args[2:])
+                kwargs = {k: mv(v) for k, v in kwargs.items()}
+                fused = (_fused_head_loss(*args, **kwargs)
+                         if FUSE_HEAD_LOSS and getattr(args[0], "_tmgcn_head", None) is not None else None)
+                if fused is None:
+                    fused = _fused_cross_entropy(*args, **kwargs)
+                if fused is not None:
+                    return fused
+                return super().__torch_function__(func, types, args, kwargs)
             dev = None
             for a in tree_leaves((args, kwargs)):               # also inside lists: torch.cat((host, result))
                 if isinstance(a, DeviceResult) and a.device.type != "cpu":
@@ -102,8 +130,7 @@ class DeviceResult(torch.Tensor):
             if dev is not None:
                 def follow(x):
                     if isinstance(x, torch.Tensor) and x.device.type == "cpu":
-                        _note_upload(x)
-                        return x.to(dev)
+                        return _device_copy(x, dev)
                     return x
 
                 if _is_inplace_or_out(func, kwargs):
@@ -147,3 +174,28 @@ def _fused_cross_entropy(input, target, weight=None, size_average=None, ignore_i
     # _plain_scope(): the operands act as plain tensors here; the result is wrapped on the way out.)
     out = weighted_ce(input.contiguous(), target.contiguous(), weight.contiguous(), ignore_index)
     return out.as_subclass(DeviceResult)
+
+
+def _fused_head_loss(input, target, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean",
+                     label_smoothing=0.0):
+    """`criterion(gcn(), target)` where `input` is the model's own output (it carries the embedding, the edge index and U
+    it was formed from, layers._Head.forward): the loss AND its gradients with respect to the embedding and U come from
+    the one-pass kernel (ops.head_loss) instead of differentiating through the logits — the script's statements
+    unchanged.  None when the call is anything but the plain weighted mean cross entropy on a narrow head, or when no
+    gradient is being recorded (then the logits that exist already are the cheaper route)."""
+    from . import ops
+    Z, eidx, U, fold = input._tmgcn_head
+    C = U.shape[-1]
+    if (size_average is not None or reduce is not None or reduction != "mean" or label_smoothing != 0.0
+            or not torch.is_grad_enabled() or not input.requires_grad or (0 <= ignore_index < C)
+            or not isinstance(target, torch.Tensor) or target.dtype != torch.int64 or target.dim() != 1
+            or target.shape[0] != input.shape[0] or input.dim() != 2):
+        return None
+    F_ = (fold if fold is not None else Z).shape[-1]
+    if not ops.head_loss_supported(F_, C, Z.shape[-1] if fold is not None else 0) or eidx.index_dtype != torch.int32:
+        return None
+    if weight is None:
+        weight = torch.ones(C, dtype=torch.float32, device=input.device)
+    elif weight.dtype != torch.float32 or weight.numel() != C:
+        return None
+    return ops.head_loss(Z, eidx, U, target, weight, ignore_index, fold_W=fold).as_subclass(DeviceResult)

@@ -80,12 +80,16 @@ class _Deliver:
     output_device = None
     host_operands = False
 
-    def _deliver(self, out: torch.Tensor) -> torch.Tensor:
+    def _deliver(self, out: torch.Tensor, head=None) -> torch.Tensor:
         if self.output_device is not None:
             out = out.to(self.output_device)
         if self.host_operands:
             from .hosted import DeviceResult
             out = out.as_subclass(DeviceResult)
+            if head is not None and self.output_device is None:
+                # what the logits were formed from: lets `criterion(output, target)` of an untouched script take the
+                # one-pass head + loss kernel (hosted._fused_head_loss) instead of differentiating through the logits
+                out._tmgcn_head = head
         return out
 
 
@@ -215,9 +219,10 @@ class _Head:
 
     def forward(self, At=None, X=None, edges=None):
         Z, eidx, U, fold = self._embed(At, X, edges)
+        head = (Z, eidx, U, fold) if (self._shard is None and self.host_operands) else None
         if fold is not None:
             Z = ops.feature_gemm(Z, fold)                                    # ehf:222
-        return self._deliver(self._head(Z, eidx, U))
+        return self._deliver(self._head(Z, eidx, U), head)
 
     def loss(self, criterion, target: torch.Tensor, At=None, X=None, edges=None, want_logits: bool = False,
              unit_grad: bool = False):
