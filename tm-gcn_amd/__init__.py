@@ -10,7 +10,10 @@ Python host side that keeps the reference's class contract:
 """
 from .csr import BatchedCSR  # noqa: F401
 from . import _lib, ops, layers  # noqa: F401
-from .layers import EmbeddingGCN, EmbeddingGCN2, EmbeddingGCN_reg, EmbeddingKWGCN  # noqa: F401
+from .layers import EmbeddingGCN, EmbeddingGCN2, EmbeddingKWGCN  # noqa: F401
 from .losses import WeightedCrossEntropy  # noqa: F401
 
-__all__ = ["BatchedCSR", "EmbeddingGCN", "EmbeddingGCN2", "EmbeddingGCN_reg", "EmbeddingKWGCN", "WeightedCrossEntropy", "ops", "layers"]
+# The hot path is the three classes above.  Two conveniences from outside that scope exist because a
+# reference script can reach them through `ehf.` — layers.EmbeddingGCN_reg (ehf:359-423, the SEIR regression head) and
+# data.compute_At (ehf:27 calls it unused) — and are exported by `tmgcn_amd.ehf` only: beyond §8, no further work.
+__all__ = ["BatchedCSR", "EmbeddingGCN", "EmbeddingGCN2", "EmbeddingKWGCN", "WeightedCrossEntropy", "ops", "layers"]

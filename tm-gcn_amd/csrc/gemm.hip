@@ -835,14 +835,8 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& h, unsigned& 
 #ifndef X3_SCHED
 #define X3_SCHED 1
 #endif
-// X3_M16 = 1: the same products on v_mfma_f32_16x16x32_bf16 (16 tiles of 16x16 per wave and step, one
-// MFMA consumes all 32 rows of the step) instead of v_mfma_f32_32x32x16_bf16 (4 tiles, two k-halves).
-// Same plane images in LDS, same fragment bytes, same accumulator count; an experiment in board
-// power (the guide reports a higher sustained clock for the 16x16 shape).
-// A/B: profiles/r3*_ab_dw_m16.txt.
-#ifndef X3_M16
-#define X3_M16 0
-#endif
+// (The same products on v_mfma_f32_16x16x32_bf16 — 16 tiles of 16x16 per wave and step — were measured in round 3: the same
+// time within 2 %, a higher clock at twice the MFMA count; profiles/r3c_ab_dw_m16.txt.  Not kept.)
 constexpr int X3_ROWS = 32;
 constexpr int X3_PITCH = 272;             // bytes per feature quad (4 x 64 + 16)
 constexpr int X3_PLANE = 32 * X3_PITCH;   // 128 features
@@ -907,24 +901,6 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
     pb += (int64_t)X3_ROWS * a.Nf;
   };
 
-#if X3_M16
-  f32x4 acc[16], sum[16];  // tile (ka, nb) = acc[8 * ka + nb]: k features 32*wave + 16*ka.., n features 16*nb..
-#pragma unroll
-  for (int t = 0; t < 16; ++t)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[t][i] = sum[t][i] = 0.f;
-  int since_flush = 0;
-  auto flush = [&]() {
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        sum[t][i] += acc[t][i];
-        acc[t][i] = 0.f;
-      }
-    since_flush = 0;
-  };
-#else
   f32x16 acc[4], sum[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -941,21 +917,12 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
       }
     since_flush = 0;
   };
-#endif
 
   unsigned char* wrA = sm + fq * X3_PITCH + kg * 8;
   unsigned char* wrB = wrA + X3_OPERAND;
   // fragment addresses: feature 32*tile + li -> quad 8*tile + li/4, feature-in-quad li%4; k half lh
-#if X3_M16
-  // 16x16x32 fragments: lane = feature-in-tile (lane & 15) + 16 * row group (lane >> 4); a lane holds
-  // rows 8g .. 8g+7 of the step for its feature: 16 bytes at g * 16 inside the feature's 64-byte run
-  const int l16 = lane & 15, g16 = lane >> 4;
-  const unsigned char* rdA = sm + (8 * wave + (l16 >> 2)) * X3_PITCH + (l16 & 3) * 64 + g16 * 16;
-  const unsigned char* rdB = sm + X3_OPERAND + (l16 >> 2) * X3_PITCH + (l16 & 3) * 64 + g16 * 16;
-#else
   const unsigned char* rdA = sm + (8 * wave + (li >> 2)) * X3_PITCH + (li & 3) * 64 + lh * 16;
   const unsigned char* rdB = sm + X3_OPERAND + (li >> 2) * X3_PITCH + (li & 3) * 64 + lh * 16;
-#endif
 
   auto split_store = [&](const float4 (&xa)[4], const float4 (&xb)[4]) {
 #pragma unroll
@@ -973,45 +940,6 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
       *reinterpret_cast<uint2*>(wrB + 2 * X3_PLANE + c * 64) = make_uint2(l0, l1);
     }
   };
-#if X3_M16
-  auto multiply = [&]() {
-    bf16x8 ah[2], am[2], al[2];
-#pragma unroll
-    for (int ka = 0; ka < 2; ++ka) {  // feature 16 more = 4 quads further
-      ah[ka] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(rdA + ka * 4 * X3_PITCH));
-      am[ka] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(rdA + X3_PLANE + ka * 4 * X3_PITCH));
-      al[ka] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(rdA + 2 * X3_PLANE + ka * 4 * X3_PITCH));
-    }
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      const unsigned char* q = rdB + nb * 4 * X3_PITCH;
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q));
-      const bf16x8 bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + X3_PLANE));
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + 2 * X3_PLANE));
-#pragma unroll
-      for (int ka = 0; ka < 2; ++ka) {
-        f32x4& c = acc[8 * ka + nb];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ka], bh, c, 0, 0, 0);  // small terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ka], bl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ka], bm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[ka], bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ka], bm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ka], bh, c, 0, 0, 0);
-      }
-    }
-#if X3_SCHED
-    // the A fragments (6 reads) and B(0) first, then each group of 12 MFMAs preceded by the 3 reads of the next B
-    __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-#pragma unroll
-    for (int nb = 0; nb < 7; ++nb) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-#endif
-    if (++since_flush == X3_FLUSH) flush();
-  };
-#else
   auto multiply = [&]() {
 #pragma unroll
     for (int sh = 0; sh < 2; ++sh) {
@@ -1054,7 +982,6 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
 #endif
     if (++since_flush == X3_FLUSH) flush();
   };
-#endif
 
   int64_t r = r0;
   const int64_t full_end = r0 + ((r1 - r0) / X3_ROWS) * X3_ROWS;  // end of the whole steps
@@ -1089,22 +1016,6 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
   }
   flush();
   float* P = a.part + ((int64_t)blockIdx.x) * a.K * a.Nf;
-#if X3_M16
-#pragma unroll
-  for (int ka = 0; ka < 2; ++ka)
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      const int n = nbase + nb * 16 + (lane & 15);
-      if (n < a.Nf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // 16x16 accumulator: column = lane & 15, rows 4 * (lane >> 4) + i
-          const int kk = kbase + wave * 32 + ka * 16 + 4 * (lane >> 4) + i;
-          if (kk < a.K) P[(int64_t)kk * a.Nf + n] = sum[8 * ka + nb][i];
-        }
-      }
-    }
-  return;
-#endif
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int n = nbase + t * 32 + li;

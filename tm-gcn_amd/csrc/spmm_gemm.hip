@@ -274,11 +274,7 @@ extern "C" int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* co
   a.tiles_per_batch = (br + FBM - 1) / FBM;
   a.n_tiles = nb * a.tiles_per_batch;
   TMGCN_REQUIRE(a.n_tiles < (int64_t)0x7fffffff, "spmm_gemm: too many row tiles");
-#if TMGCN_FUSED_XCD_SWEEPS
-  a.tile_counter = acquire_tile_counters((hipStream_t)stream, TMGCN_FUSED_XCD_SWEEPS);
-#else
   a.tile_counter = acquire_tile_counter((hipStream_t)stream);
-#endif
   TMGCN_REQUIRE(a.tile_counter, "spmm_gemm: cannot set up the tile counter");
   // persistent blocks: up to 4 per CU (LDS 33.8 KB each); tiles are dealt round-robin so the
   // blocks resident at any moment work on neighbouring rows of the same slice

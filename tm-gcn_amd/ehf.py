@@ -7,9 +7,11 @@ script reaches through ``ehf.`` is here under the same name with the same argume
 values — the four model classes (layers.py; the layer runs in the HIP kernels), the metrics
 (metrics.py), and the data functions (data.py):
 
-    EmbeddingGCN  EmbeddingGCN2  EmbeddingKWGCN  EmbeddingGCN_reg
-    load_data  create_node_features  augment_edges  split_data  compute_At
+    EmbeddingGCN  EmbeddingGCN2  EmbeddingKWGCN                       (the hot path: SURVEY §8 a1-a8)
+    load_data  create_node_features  augment_edges  split_data
     compute_f1  compute_MAP_MRR  get_MAP  get_MRR  get_row_MRR  print_f1
+    EmbeddingGCN_reg  compute_At      (beyond §8 — the SEIR regression model and a function the reference itself calls
+                                       unused, ehf:27 — kept so that every `ehf.` name resolves; no kernel work went into them)
 
 The scripts keep targets, class weights and the criterion on the host (``criterion(gcn(),
 target_train)``, …_link_prediction.py:69,79).  The classes exported here therefore return their
