@@ -81,16 +81,36 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
   if (live) {
     const int64_t beg = a.rowptr[r], end = a.rowptr[r + 1];
     const int64_t xoff = (r / a.N) * (int64_t)a.N;
-    for (int64_t p = beg + gl; p < end; p += G) {
-      const float v = a.val[p];
-      float h[KI], y[F];
-      static_assert(KI == 2, "H rows are float2");
-      const float2 hv = *reinterpret_cast<const float2*>(a.H + (xoff + a.col[p]) * KI);
-      h[0] = hv.x;
-      h[1] = hv.y;
-      layer1_row<KI, F>(h, W1, a.act1, y, nullptr);
+    // NB non-zeros of the row per trip: their (col, val) pairs are requested together and then their H rows together —
+    // two dependent round trips per NB non-zeros instead of two per non-zero (these kernels are bound by that chain,
+    // not by bytes).  Positions past the row's end are clamped to its last entry and carry weight 0: every load is
+    // unconditional (a load under a per-lane condition becomes a branch with a full wait).  Same fmaf order per lane.
+    constexpr int NB = 4;
+    for (int64_t p = beg + gl; p < end; p += NB * G) {
+      float v[NB];
+      int c[NB];
 #pragma unroll
-      for (int f = 0; f < F; ++f) acc[f] = fmaf(v, y[f], acc[f]);      // spmm_gemm_small's accumulation
+      for (int u = 0; u < NB; ++u) {
+        const int64_t q = p + u * G;
+        const int64_t qc = q < end ? q : end - 1;
+        const float vv = a.val[qc];
+        c[u] = a.col[qc];
+        v[u] = q < end ? vv : 0.f;
+      }
+      float2 hv[NB];
+      static_assert(KI == 2, "H rows are float2");
+#pragma unroll
+      for (int u = 0; u < NB; ++u) hv[u] = *reinterpret_cast<const float2*>(a.H + (xoff + c[u]) * KI);
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const float h[KI] = {hv[u].x, hv[u].y};
+        float y[F];
+        layer1_row<KI, F>(h, W1, a.act1, y, nullptr);
+        if (p + u * G < end) {                                   // wave-divergent only in the last trip; keeps the chain exact
+#pragma unroll
+          for (int f = 0; f < F; ++f) acc[f] = fmaf(v[u], y[f], acc[f]);      // spmm_gemm_small's accumulation
+        }
+      }
     }
   }
 #pragma unroll
@@ -146,28 +166,47 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
     float t[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) t[n] = 0.f;
-    for (int64_t p = beg + gl; p < end; p += G) {
-      const float v = a.val[p];
-      const int64_t c = xoff + a.col[p];
-      const float2* gz = reinterpret_cast<const float2*>(a.dZ + c * NT);
-      float g[NT];
+    constexpr int NB = 4;                                    // non-zeros per trip, loads unconditional (see the forward kernel)
+    for (int64_t p = beg + gl; p < end; p += NB * G) {
+      float v[NB];
+      int64_t c[NB];
 #pragma unroll
-      for (int i = 0; i < NT / 2; ++i) {
-        const float2 q = gz[i];
-        g[2 * i] = q.x;
-        g[2 * i + 1] = q.y;
+      for (int u = 0; u < NB; ++u) {
+        const int64_t q = p + u * G;
+        const int64_t qc = q < end ? q : end - 1;
+        const float vv = a.val[qc];
+        c[u] = xoff + a.col[qc];
+        v[u] = q < end ? vv : 0.f;
       }
-      if (a.pre2) {                                        // act2 != none: dZ ⊙ act2'(pre2) of the gathered row
-        const float2* pz = reinterpret_cast<const float2*>(a.pre2 + c * NT);
+      float g[NB][NT];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const float2* gz = reinterpret_cast<const float2*>(a.dZ + c[u] * NT);
 #pragma unroll
         for (int i = 0; i < NT / 2; ++i) {
-          const float2 q = pz[i];
-          g[2 * i] *= dact2(q.x);
-          g[2 * i + 1] *= dact2(q.y);
+          const float2 q = gz[i];
+          g[u][2 * i] = q.x;
+          g[u][2 * i + 1] = q.y;
+        }
+      }
+      if (a.pre2) {                                          // act2 != none: dZ ⊙ act2'(pre2) of the gathered rows
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const float2* pz = reinterpret_cast<const float2*>(a.pre2 + c[u] * NT);
+#pragma unroll
+          for (int i = 0; i < NT / 2; ++i) {
+            const float2 q = pz[i];
+            g[u][2 * i] *= dact2(q.x);
+            g[u][2 * i + 1] *= dact2(q.y);
+          }
         }
       }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) t[n] = fmaf(v, g[n], t[n]);
+      for (int u = 0; u < NB; ++u)
+        if (p + u * G < end) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) t[n] = fmaf(v[u], g[u][n], t[n]);
+        }
     }
 #pragma unroll
     for (int o = G >> 1; o > 0; o >>= 1)
@@ -242,11 +281,13 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
   }
 }
 
+// lanes per row: chains of about four non-zeros per lane, walked NB at a time (kernel durations under rocprofv3, captured
+// S1 / S3 steps: 3 nnz/row: G = 1 beats 2 by 18 %; 27 nnz/row: G = 4 — 41 us backward against 48 with one lane per row)
 static int l12_lanes(float avg_nnz_per_row) {
   int G = 8;
   if (avg_nnz_per_row >= 0.f) {
-    G = 1;                                                // chains of about four non-zeros per lane (tools/ab_layer12.py:
-    while (G < 16 && (float)(4 * G) <= avg_nnz_per_row) G <<= 1;   // 3 nnz/row: G = 1 beats 2 by 18 %; 27 nnz/row: G = 4 best)
+    G = 1;
+    while (G < 16 && 4.f * G <= avg_nnz_per_row) G <<= 1;
   }
   return G;
 }
