@@ -239,3 +239,30 @@ def test_unit_gradient_fast_path(T, N, E):
     (ops.head_loss(Zc, idx, Uc, target, weight, unit_grad=True) * 3.0).backward()
     assert_close(Zc.grad, 3.0 * Za.grad, 1e-6, "dZ x 3")
     assert_close(Uc.grad, 3.0 * Ua.grad, 1e-6, "dU x 3")
+
+
+def test_hub_rows_and_skewed_degrees():
+    """One node is an endpoint of a third of all labelled edges in its slice (a row with ~10 k entries next to rows with
+    one or none): the lanes of its group walk thousands of entries each; sums stay in fp64, result within 2e-6."""
+    T, N, F, C, E = 3, 400, 6, 2, 30000
+    g = torch.Generator().manual_seed(21)
+    Z = torch.randn(T, N, F, generator=g).cuda()
+    U = torch.randn(2 * F, C, generator=g).cuda()
+    t = torch.randint(0, T, (E,), generator=g)
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, N, (E,), generator=g)
+    hub = torch.rand(E, generator=g) < 0.33
+    src[hub] = 7                                           # node 7 of every slice is a hub on the src side
+    dst[torch.rand(E, generator=g) < 0.1] = 7              # ... and sometimes on the dst side (self-pairs included)
+    edges = torch.stack([t, src, dst])
+    target = torch.randint(0, C, (E,), generator=g).cuda()
+    weight = torch.tensor([0.9, 0.1]).cuda()
+    idx = ops.EdgeIndex(edges, N, "cuda", T=T)
+    Zr, Ur = Z.clone().requires_grad_(True), U.clone().requires_grad_(True)
+    loss, logits = ops.head_loss(Zr, idx, Ur, target, weight, want_logits=True)
+    loss.backward()
+    ref_logits, ref_loss, ref_dZ, ref_dU, _ = _fp64(Z, None, U, edges, target, weight, N)
+    assert_close(logits, ref_logits, 1e-6, "logits")
+    assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-6 * max(1.0, abs(float(ref_loss)))
+    assert_close(Zr.grad, ref_dZ, 2e-6, "dZ")
+    assert_close(Ur.grad, ref_dU, 2e-6, "dU")

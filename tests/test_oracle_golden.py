@@ -328,6 +328,19 @@ def test_g10_full_chess_pipeline_and_models():
     AtXt = orc.compute_AtXt(Mt, At, X)
     AtXt_val = orc.compute_AtXt(Mt, At_val, Xv)
     ev = torch.from_numpy(g.eval_val)
+    # the C oracle's P2 / P3 halves at real scale (G2 pins them at 60 nodes): ref_spmm on the reference's Ât and ref_gemm
+    # (fp64 accumulation, where ehf:222 is an fp32 matmul) reproduce the 1-layer model's logits on all 584 k rows
+    lib = load_c_oracle()
+    csr = BatchedCSR.from_coo_list(At, N=N)
+    Xt = orc.m_transform(Mt, X).float().contiguous()
+    AtXt_c = torch.empty(T, N, 2)
+    lib.ref_spmm(cptr(csr.rowptr), cptr(csr.col), cptr(csr.val), cptr(Xt), cptr(AtXt_c), T * N, N, 2)
+    assert_close(AtXt_c, AtXt, 2e-6, "C oracle P2 at N = 7301")
+    W0 = torch.from_numpy(d["gcn_W0"]).contiguous()
+    Yc = torch.empty(T, N, W0.shape[1])
+    lib.ref_gemm(cptr(AtXt.contiguous()), cptr(W0), cptr(Yc), T * N, 2, W0.shape[1], 0, 0, 0)
+    with torch.no_grad():
+        assert_close(orc.edge_head(Yc, src, dst, torch.from_numpy(d["gcn_U0"])), d["gcn_logits"], 1e-6, "logits through ref_gemm at N = 7301")
     for name, kind, F, kw in (("gcn", "gcn", [2, 6, 3], {}), ("gcn2", "gcn2", [2, 6, 6, 3], dict(nonlin="selu")),
                               ("gcn2_twice", "gcn2", [2, 6, 6, 3], dict(nonlin="selu", apply_M_twice=True))):
         torch.manual_seed(int(d["seed"]))
