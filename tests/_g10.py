@@ -40,6 +40,11 @@ class G10:
         self.target_val = self.target_all[va]
         self.eval_val = self.edges_val[0] >= self.S_train - self.S_val
         self.X_train, self.X_val = self.X[:self.S_train], self.X[self.S_val:self.S_train + self.S_val]
+        # the baseline's split (experiment_chess_baseline.py:64-81): validation = the S_val slices AFTER the training block
+        vb = (ek >= self.S_train) & (ek < self.S_train + self.S_val)
+        self.edges_val_b = self.edges_all[:, vb].copy()
+        self.edges_val_b[0] -= self.S_train
+        self.X_val_b = self.X[self.S_train:self.S_train + self.S_val]
         self.class_weights = np.array([.33, .33, .33], np.float32)      # experiment_chess_our.py:23
 
     def C(self):

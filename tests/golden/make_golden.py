@@ -370,6 +370,31 @@ def g10():
                 out[f"{name}_logits_val_eval"] = lv_[eval_val].numpy()
                 out[f"{name}_loss_val"] = float(crit(lv_[eval_val], (torch.sign(lv[sv]) + 1).long()[eval_val]))
         print(f"g10: {name} loss {float(loss):.6f}")
+    # experiment_chess_baseline.py:47-90, 101-104 — the baseline without the M-product on the un-transformed C: training
+    # on slices 0..79, validation on the SHORTER window 80..89 (compute_AX zero-pads to the training T, ehf:469-473)
+    Ci, Cv = Cn._indices(), Cn._values()
+    C_train_l = [torch.sparse.DoubleTensor(Ci[1:3, Ci[0] == j], Cv[Ci[0] == j]) for j in range(S_train)]
+    C_val_l = [torch.sparse.DoubleTensor(Ci[1:3, Ci[0] == j], Cv[Ci[0] == j]) for j in range(S_train, S_train + S_val)]
+    Xb_val = X[S_train:S_train + S_val].double()
+    svb = (li[0] >= S_train) & (li[0] < S_train + S_val)
+    edges_val_b = li[:, svb].clone()
+    edges_val_b[0] -= S_train
+    for name, hf in (("kw1", [6, 3]), ("kw2", [6, 6, 3])):
+        torch.manual_seed(71)
+        m = ehf.EmbeddingKWGCN(C_train_l, X_train, edges_train, hf, nonlin2="selu")
+        for n, p in m.named_parameters():
+            out[f"{name}_{n}0"] = p.detach().numpy().copy()
+        logits = m()
+        loss = crit(logits, target_train)
+        m.zero_grad()
+        loss.backward()
+        out[f"{name}_logits"] = logits.detach().numpy()
+        out[f"{name}_loss"] = float(loss)
+        for n, p in m.named_parameters():
+            out[f"{name}_d{n}"] = p.grad.detach().numpy().copy()
+        with torch.no_grad():
+            out[f"{name}_logits_val"] = m(C_val_l, Xb_val, edges_val_b).numpy()
+        print(f"g10: {name} loss {float(loss):.6f}")
     packed = {}
     for nm, S in (("C", Cn), ("Ct", Ct_train)):
         packed.update({f"{nm}_{k}": v for k, v in _pack_sym(S, N).items()})

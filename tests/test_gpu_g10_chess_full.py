@@ -130,3 +130,35 @@ def test_model_from_the_reference_list_of_coo_form(g, built):
     m = MODELS["gcn2"](At, torch.from_numpy(g.X_train), torch.from_numpy(g.edges_train), torch.from_numpy(g.M))
     with torch.no_grad():
         assert_close(m(), d["gcn2_logits"], REL_TOL, "gcn2 logits from the list-of-COO form")
+
+
+@pytest.mark.parametrize("name,hf", [("kw1", [6, 3]), ("kw2", [6, 6, 3])])
+def test_baseline_kwgcn_on_the_device_built_adjacency(g, built, name, hf):
+    """experiment_chess_baseline.py: EmbeddingKWGCN on the un-transformed Ĉ (device-built), training on slices 0..79 and the
+    validation call on the SHORTER window 80..89 — logits, loss, every gradient within 1e-5 of the reference's."""
+    Chat, _, _ = built
+    d = g.d
+    torch.manual_seed(int(d["seed"]))
+    m = ehf.EmbeddingKWGCN(Chat.slices(0, g.T), torch.from_numpy(g.X_train), torch.from_numpy(g.edges_train), hidden_feat=hf,
+                           nonlin2="selu")
+    for n, p in m.named_parameters():
+        assert np.array_equal(p.detach().cpu().numpy(), d[f"{name}_{n}0"]), n
+    crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(g.class_weights).cuda())
+    out = m()
+    loss = crit(out, torch.from_numpy(g.target_train).cuda())
+    m.zero_grad()
+    loss.backward()
+    assert_close(out.detach(), d[name + "_logits"], REL_TOL, name + " logits")
+    assert abs(float(loss.detach()) - float(d[name + "_loss"])) <= 1e-5 * max(1.0, abs(float(d[name + "_loss"])))
+    for n, p in m.named_parameters():
+        assert_close(p.grad, d[f"{name}_d{n}"], REL_TOL, f"{name} d{n}")
+    with torch.no_grad():
+        out_val = m(Chat.slices(g.T, g.T + g.S_val), torch.from_numpy(g.X_val_b), torch.from_numpy(g.edges_val_b))
+    assert_close(out_val, d[name + "_logits_val"], REL_TOL, name + " validation logits (shorter window)")
+    # and the same step through the one-pass head + loss
+    m.zero_grad()
+    loss2 = m.loss(crit, torch.from_numpy(g.target_train).cuda())
+    loss2.backward()
+    assert abs(float(loss2.detach()) - float(d[name + "_loss"])) <= 1e-5 * max(1.0, abs(float(d[name + "_loss"])))
+    for n, p in m.named_parameters():
+        assert_close(p.grad, d[f"{name}_d{n}"], REL_TOL, f"{name} d{n} through gcn.loss()")

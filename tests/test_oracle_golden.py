@@ -364,3 +364,46 @@ def test_g10_full_chess_pipeline_and_models():
             with torch.no_grad():
                 out_val = fwd(p, AtXt_val, vs, vd)
             assert_close(out_val[ev], d[name + "_logits_val_eval"], 1e-6, name + " validation logits (last S_val slices)")
+
+
+def test_g10_full_chess_baseline_kwgcn():
+    """G10, the baseline of experiment_chess_baseline.py: EmbeddingKWGCN (1 and 2 layers) on the reference's un-transformed
+    C of the whole chess data set, training on slices 0..79, the validation call on the SHORTER window 80..89
+    (compute_AX zero-pads to the training T, ehf:469-473) — row a5 at real scale."""
+    from _g10 import G10
+    g = G10()
+    d, T, N = g.d, g.T, g.N
+    rk, ri, rj, rv = g.C()
+    bounds = np.searchsorted(rk, np.arange(g.TT + 1))
+
+    def slice_list(t0, t1):
+        out = []
+        for t in range(t0, t1):
+            sl = slice(bounds[t], bounds[t + 1])
+            out.append(torch.sparse_coo_tensor(torch.from_numpy(np.stack([ri[sl], rj[sl]])), torch.from_numpy(rv[sl].astype(np.float64)), (N, N)))
+        return out
+
+    A, A_val = slice_list(0, T), slice_list(T, T + g.S_val)
+    X, Xv = torch.from_numpy(g.X_train), torch.from_numpy(g.X_val_b)
+    src, dst = orc.flat_edge_index(torch.from_numpy(g.edges_train), N)
+    vs, vd = orc.flat_edge_index(torch.from_numpy(g.edges_val_b), N)
+    tgt = torch.from_numpy(g.target_train)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(g.class_weights))
+    AX = orc.slice_spmm(A, X)
+    AX_val = torch.cat((orc.slice_spmm(A_val, Xv), torch.zeros(T - g.S_val, N, 2)))      # ehf:469-473
+    for name, F in (("kw1", [2, 6, 3]), ("kw2", [2, 6, 6, 3])):
+        torch.manual_seed(int(d["seed"]))
+        p = orc.draw_params("kw", T, F)
+        for n in p:
+            assert np.array_equal(p[n].numpy(), d[f"{name}_{n}0"]), (name, n)
+        ps = {n: v.clone().requires_grad_(True) for n, v in p.items()}
+        out = orc.kwgcn_forward(AX, A, ps["W1"], ps["U"], src, dst, ps.get("W2"), "selu")
+        loss = crit(out, tgt)
+        loss.backward()
+        assert_close(out.detach(), d[name + "_logits"], 2e-6, name + " logits")      # the fixture's C values are fp32-rounded
+        assert abs(float(loss.detach()) - float(d[name + "_loss"])) <= 2e-6 * max(1.0, abs(float(d[name + "_loss"])))
+        for n in p:
+            assert_close(ps[n].grad, d[f"{name}_d{n}"], 5e-6, f"{name} d{n}")
+        with torch.no_grad():
+            out_val = orc.kwgcn_forward(AX_val, A, p["W1"], p["U"], vs, vd, p.get("W2"), "selu")
+        assert_close(out_val, d[name + "_logits_val"], 2e-6, name + " validation logits (shorter window)")
