@@ -70,9 +70,10 @@ def _device_copy(x: torch.Tensor, dev) -> torch.Tensor:
     hands to its criterion every epoch cross PCIe once (Reddit-LP: a 26 MB target tensor, 0.6 ms per epoch otherwise) and a
     tensor that was written to in between is uploaded again.  The device copy lives as long as the host tensor does.
     A tensor of a megabyte or more that KEEPS changing (third upload) gets one RuntimeWarning."""
+    dev = torch.device(dev)
     ver = x._version
     c = getattr(x, "_tmgcn_dev", None)
-    if c is not None and c[0] == ver and c[1].device == dev:
+    if c is not None and c[0] == ver and c[1].device.type == dev.type and (dev.index is None or c[1].device.index == dev.index):
         return c[1]
     y = x.to(dev)
     try:

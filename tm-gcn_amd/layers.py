@@ -195,7 +195,11 @@ def _criterion_spec(criterion, C: int, device):
         return None
     if w.numel() != C or (0 <= ign < C):
         return None
-    return w.detach().to(device=device, dtype=torch.float32).contiguous(), int(ign)
+    w = w.detach()
+    if w.device.type == "cpu":                       # a host-side criterion (the scripts'): its weights cross PCIe once
+        from .hosted import _device_copy
+        w = _device_copy(w, torch.device(device))
+    return w.to(device=device, dtype=torch.float32).contiguous(), int(ign)
 
 
 class _Head:
