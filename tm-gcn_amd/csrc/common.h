@@ -173,6 +173,29 @@ __device__ __forceinline__ float act_grad(float x, int act) {
   }
 }
 
+// act_apply() with the activation decoded ONCE (uniform registers) instead of a switch per element: the same values, bit
+// for bit — x > 0 ? pos·x : neg·(use_exp ? exp(x) − 1 : x), relu's negative side an exact +0 — as selects, so an
+// unrolled loop over elements carries no scalar branch chain and no exec-mask region per element (the per-element
+// switch cost the fused layer kernel 636 scalar and ≈ 400 vector instructions per row; rocprofv3 SQ counters, round 4).
+struct ActApply {
+  float pos, neg;
+  bool use_exp, zero_neg;
+  __device__ __forceinline__ explicit ActApply(int act) {
+    const float scale = 1.0507009873554804934193349852946f;
+    const float alpha = 1.6732632423543772848170429916717f;
+    pos = act == TMGCN_ACT_SELU ? scale : 1.f;
+    neg = act == TMGCN_ACT_SELU ? scale * alpha : (act == TMGCN_ACT_LEAKY ? 0.01f : 1.f);
+    use_exp = act == TMGCN_ACT_SELU;
+    zero_neg = act == TMGCN_ACT_RELU;
+  }
+  __device__ __forceinline__ float operator()(float x) const {
+    float t = x;
+    if (use_exp) t = expf(fminf(x, 0.f)) - 1.f;      // a uniform (scalar) branch: relu / leaky / none skip the exponential
+    const float n = zero_neg ? 0.f : neg * t;
+    return x > 0.f ? pos * x : n;
+  }
+};
+
 // act_grad() with the activation decoded ONCE (uniform registers) instead of a switch per element: the same values,
 // bit for bit — x > 0 ? pos : neg · (use_exp ? exp(x) : 1) — as selects, so a loop over elements stays branch-free
 // (a branch per element also splits the loads around it: every use waits for all of them).

@@ -583,6 +583,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
 // stride per wave — 21 us for 570 k rows of 2 -> 6 with the pre-activation, against 8 us of bytes).
 __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
   extern __shared__ float Ws[];  // [n_w][K][Nfp] (+ [256][Nfp+1] output tile at stage_off)
+  const ActApply act(a.act);    // decoded once: no switch per element (common.h)
   const int Nfp = (a.Nf + 7) & ~7;
   const int64_t batch_rows = a.rows_per_batch ? a.rows_per_batch : a.R;
   const int64_t r_first = (int64_t)blockIdx.x * blockDim.x;
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
         for (int i = 0; i < 8; ++i) {
           if (nb + i < a.Nf) {
             if (a.pre) a.pre[r * a.Nf + nb + i] = acc[i];
-            a.Y[r * a.Nf + nb + i] = act_apply(acc[i], a.act);
+            a.Y[r * a.Nf + nb + i] = act(acc[i]);
           }
         }
       }
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs a) {
     const int row = idx / a.Nf, n = idx - row * a.Nf;
     const float v = t0[row * (Nfp + 1) + n];
     if (pb) pb[idx] = v;
-    yb[idx] = act_apply(v, a.act);
+    yb[idx] = act(v);
   }
 }
 

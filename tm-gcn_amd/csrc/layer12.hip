@@ -48,14 +48,13 @@ __device__ __forceinline__ T pick_at(const T (&v)[N], int i) {
 
 // y[f] = act1(Σ_k h[k]·W1[k][f]) — gemm_small's chain (k ascending from 0), so the same bits
 template <int KI, int F>
-__device__ __forceinline__ void layer1_row(const float (&h)[KI], const float (&W1)[KI][F], int act1, float (&y)[F], float* pre) {
+__device__ __forceinline__ void layer1_row(const float (&h)[KI], const float (&W1)[KI][F], const ActApply& act1, float (&y)[F]) {
 #pragma unroll
   for (int f = 0; f < F; ++f) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < KI; ++k) s = fmaf(h[k], W1[k][f], s);
-    if (pre) pre[f] = s;
-    y[f] = act_apply(s, act1);
+    y[f] = act1(s);
   }
 }
 
@@ -71,6 +70,7 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
   for (int f = 0; f < F; ++f)
 #pragma unroll
     for (int n = 0; n < NT; ++n) W2[f][n] = a.W2[f * NT + n];
+  const ActApply act1(a.act1), act2(a.act2);
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t r = gid / G;
   const int gl = (int)(gid % G);
@@ -103,10 +103,10 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
       for (int u = 0; u < NB; ++u) hv[u] = *reinterpret_cast<const float2*>(a.H + (xoff + c[u]) * KI);
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
-        const float h[KI] = {hv[u].x, hv[u].y};
-        float y[F];
-        layer1_row<KI, F>(h, W1, a.act1, y, nullptr);
-        if (p + u * G < end) {                                   // wave-divergent only in the last trip; keeps the chain exact
+        if (p + u * G < end) {                                   // slots past the row's end: skipped (no layer-1 work for them)
+          const float h[KI] = {hv[u].x, hv[u].y};
+          float y[F];
+          layer1_row<KI, F>(h, W1, act1, y);
 #pragma unroll
           for (int f = 0; f < F; ++f) acc[f] = fmaf(v[u], y[f], acc[f]);      // spmm_gemm_small's accumulation
         }
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
       s = fmaf(acc[f], w, s);
     }
     if (a.pre2_out) a.pre2_out[r * NT + n] = s;
-    a.Z[r * NT + n] = act_apply(s, a.act2);
+    a.Z[r * NT + n] = act2(s);
   }
 }
 

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void spmm_gemm_small_kernel(FusedArgs a) {
   const int gl = (int)(gid % G);
   const bool live = r < a.n_rows;
   const float* X = reinterpret_cast<const float*>(a.X);
+  const ActApply act(a.act);    // decoded once: no switch per element (common.h)
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void spmm_gemm_small_kernel(FusedArgs a) {
 #pragma unroll
     for (int f = 0; f < F; ++f) s = fmaf(acc[f], a.trans_w ? Wb[(int64_t)n * F + f] : Wb[(int64_t)f * a.Nf + n], s);
     if (a.pre) a.pre[r * a.Nf + n] = s;
-    a.Y[r * a.Nf + n] = act_apply(s, a.act);
+    a.Y[r * a.Nf + n] = act(s);
   }
 }
 
