@@ -370,6 +370,21 @@ def g10():
                 out[f"{name}_logits_val_eval"] = lv_[eval_val].numpy()
                 out[f"{name}_loss_val"] = float(crit(lv_[eval_val], (torch.sign(lv[sv]) + 1).long()[eval_val]))
         print(f"g10: {name} loss {float(loss):.6f}")
+    # the scripts' training loop itself (experiment_chess_our.py:97-108): 6 SGD steps (lr .01, momentum .9) of the 2-layer model
+    torch.manual_seed(71)
+    m = models["gcn2"]()
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+    traj = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = crit(m(), target_train)
+        loss.backward()
+        opt.step()
+        traj.append(float(loss))
+    out["gcn2_sgd_losses"] = np.array(traj)
+    for n, p in m.named_parameters():
+        out[f"gcn2_sgd_{n}_final"] = p.detach().numpy().copy()
+    print("g10: gcn2 SGD losses", traj)
     # experiment_chess_baseline.py:47-90, 101-104 — the baseline without the M-product on the un-transformed C: training
     # on slices 0..79, validation on the SHORTER window 80..89 (compute_AX zero-pads to the training T, ehf:469-473)
     Ci, Cv = Cn._indices(), Cn._values()

@@ -84,6 +84,14 @@ def _worker(rank, world, port, name, ret):
         loss.backward()
         for n, q in m.named_parameters():
             close(q.grad, d["d" + n], "d" + n)
+        # gcn.loss(criterion, target) on a sharded model: the unfused statements (every rank evaluates the same loss on
+        # the gathered logits), same value and gradients as criterion(gcn(), target)
+        m.zero_grad()
+        loss_f = m.loss(torch.nn.CrossEntropyLoss(weight=torch.tensor([0.9, 0.1])), i["labels"])
+        close(loss_f.detach(), float(d["loss"]), "loss through gcn.loss()")
+        loss_f.backward()
+        for n, q in m.named_parameters():
+            close(q.grad, d["d" + n], "d" + n + " through gcn.loss()")
         if "logits_val" in d.files:                                         # validation-style call on another window
             v = inputs("val_")
             with torch.no_grad():

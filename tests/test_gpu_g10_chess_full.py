@@ -162,3 +162,39 @@ def test_baseline_kwgcn_on_the_device_built_adjacency(g, built, name, hf):
     assert abs(float(loss2.detach()) - float(d[name + "_loss"])) <= 1e-5 * max(1.0, abs(float(d[name + "_loss"])))
     for n, p in m.named_parameters():
         assert_close(p.grad, d[f"{name}_d{n}"], REL_TOL, f"{name} d{n} through gcn.loss()")
+
+
+def test_training_loop_on_full_chess_follows_the_reference_trajectory(g, built):
+    """experiment_chess_our.py:97-108 at real scale: six SGD steps (lr .01, momentum .9) of the 2-layer model.  The
+    reference's losses are reproduced (i) by the plain loop — criterion(gcn(), target), torch.optim.SGD — and (ii) by the
+    round-4 route: one captured hipGraph per step with layers 1 + 2 fused, the one-pass head + loss, FusedSGD."""
+    from tmgcn_amd.graphs import GraphedTrainStep
+    from tmgcn_amd.optim import FusedSGD
+    _, A_train, _ = built
+    d = g.d
+    tgt = torch.from_numpy(g.target_train).cuda()
+    crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(g.class_weights).cuda())
+
+    def make(opt_cls):
+        torch.manual_seed(int(d["seed"]))
+        m = MODELS["gcn2"](A_train, torch.from_numpy(g.X_train), torch.from_numpy(g.edges_train), torch.from_numpy(g.M))
+        return m, opt_cls(m.parameters(), lr=0.01, momentum=0.9)
+
+    m1, o1 = make(torch.optim.SGD)
+    losses = []
+    for _ in range(6):
+        o1.zero_grad()
+        l = crit(m1(), tgt)
+        l.backward()
+        o1.step()
+        losses.append(float(l.detach()))
+    assert_close(np.array(losses), d["gcn2_sgd_losses"], REL_TOL, "plain loop vs the reference's losses")
+    for n, p in m1.named_parameters():
+        assert_close(p.detach(), d[f"gcn2_sgd_{n}_final"], REL_TOL, f"{n} after 6 steps")
+    m2, o2 = make(FusedSGD)
+    step = GraphedTrainStep(m2, crit, o2, tgt, warmup=3)          # three eager steps, then the captured one replayed
+    assert step.fused
+    got = [float(step()) for _ in range(3)]
+    assert_close(np.array(got), d["gcn2_sgd_losses"][3:], REL_TOL, "captured steps 4-6 vs the reference's losses")
+    for n, p in m2.named_parameters():
+        assert_close(p.detach(), d[f"gcn2_sgd_{n}_final"], REL_TOL, f"{n} after 3 eager + 3 captured steps")
