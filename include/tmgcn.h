@@ -205,7 +205,7 @@ int tmgcn_gemm_dw_act_f32(const float* A, const float* dY, const float* pre_act,
  *   backward  dW1 = Σ_r H[r]ᵀ · ( ((Âᵀ ⋆ dZ')·W2ᵀ)[r] ⊙ act1'(H[r]·W1) ),   dZ' = dZ ⊙ act2'(pre2)
  * H [R][2] is the model's cached constant (AtXt / AX, ehf:293 / 464): the [R][F] intermediates (layer-1 output, its
  * pre-activation, dY, dP) are never stored.  Shared weights W1 [2][F], W2 [F][Nf]; 2 -> even F <= 8 -> even Nf <= 8
- * (tmgcn_layer12_supported).  Same per-lane fmaf chains as tmgcn_gemm_f32 + tmgcn_spmm_gemm_f32 on these widths.
+ * (tmgcn_layer12_supported).  Against tmgcn_gemm_f32 + tmgcn_spmm_gemm_f32: another fp32 summation order per row (<= 1e-6).
  * AX (optional) receives Â ⋆ act1(H·W1) for dW2 = AXᵀ·dZ' (tmgcn_gemm_dw_f32); pre2 the pre-activation of layer 2
  * when act2 is not none.  The backward takes the TRANSPOSED batched CSR. */
 int tmgcn_layer12_supported(int32_t K0, int32_t F, int32_t Nf);
@@ -213,6 +213,9 @@ int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, const float
                           const float* W1, int32_t act1, const float* W2, int32_t act2, int64_t n_rows,
                           int32_t N, int32_t K0, int32_t F, int32_t Nf, float* Z, float* AX, float* pre2,
                           float avg_nnz_per_row, void* stream);
+/* 1 when the fused forward is the faster route for the shape (short rows, or small dense slices whose layer-1 output is
+ * formed once per node in LDS); 0: form act1(H·W1) with tmgcn_gemm_f32 and call tmgcn_spmm_gemm_f32 (same Z up to fp32 summation order). */
+int tmgcn_layer12_fwd_pays(int64_t n_rows, int32_t N, int32_t F, float avg_nnz_per_row);
 int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F);
 int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const float* dZ,
                           const float* pre2, const float* H, const float* W1, int32_t act1, const float* W2,

@@ -607,7 +607,10 @@ def test_weighted_cross_entropy_matches_torch_fp64(E, C):
 
 
 @pytest.mark.parametrize("act1,act2", [("selu", None), ("relu", None), ("leaky", "relu"), (None, "selu")])
-@pytest.mark.parametrize("T,N,deg,F,Nf", [(5, 300, 3.0, 6, 6), (3, 77, 12.0, 6, 2), (4, 500, 0.4, 2, 6), (2, 64, 40.0, 8, 4)])
+@pytest.mark.parametrize("T,N,deg,F,Nf", [(5, 300, 3.0, 6, 6), (3, 77, 12.0, 6, 2), (4, 500, 0.4, 2, 6), (2, 64, 40.0, 8, 4),
+                                          # staged variants (slice in LDS): several blocks per slice with a ragged last
+                                          # chunk, many slices, and a slice just too large for them (72 KB)
+                                          (7, 1000, 27.0, 6, 6), (150, 200, 9.0, 6, 6), (2, 3000, 9.0, 6, 6)])
 def test_layer12_fused_matches_the_two_operators(act1, act2, T, N, deg, F, Nf):
     """ops.layer12 (csrc/layer12.hip: layers 1 + 2 of the narrow 2-layer models in one launch each way) against
     feature_gemm followed by spmm_feature_gemm: the same Z to the last bit or two (same per-lane fmaf chains; a row's
@@ -629,7 +632,9 @@ def test_layer12_fused_matches_the_two_operators(act1, act2, T, N, deg, F, Nf):
     b1, b2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
     Zr = ops.layer12(H, b1, act1, A, b2, act2, fuse=False)
     Zr.backward(dZ)
-    assert_close(Z.detach(), Zr.detach(), 1e-6, "Z")
+    # two fp32 summation orders of a row (27 terms at the densest case: each lane of the fused kernels adds CONSECUTIVE
+    # non-zeros, the two-operator route strided ones): 1.0e-6 measured there, 3e-7 on the 3-per-row cases
+    assert_close(Z.detach(), Zr.detach(), 2e-6, "Z")
     assert_close(a1.grad, b1.grad, 2e-6, "dW1")
     assert_close(a2.grad, b2.grad, 2e-6, "dW2")
     c1, c2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)

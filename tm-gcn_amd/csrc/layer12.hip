@@ -6,12 +6,17 @@
 // construction, ehf:293 / 464), so Y never has to exist.  At these sizes (R = T·N = 570 k rows, 3 non-zeros per
 // row) the separate kernels are bound by the [R][6] tensors they pass to each other, not by arithmetic:
 //   forward   the SpMM gathers 8-byte H rows instead of 24-byte Y rows and applies W1 and the non-linearity to
-//             each gathered row on the fly (12 fmas + 6 activations per non-zero) — the per-lane fmaf chains of
-//             gemm_small and spmm_gemm_small (a row's partial sums are folded over however many lanes each kernel
-//             gives a row, so the results agree to the last bit or two, not always bitwise);
+//             each gathered row on the fly (12 fmas + 6 activations per non-zero) — gemm_small's fmaf chain for
+//             layer 1; a row's non-zeros are summed NB consecutive ones per lane and folded over the lanes of the row,
+//             spmm_gemm_small's strided over its lanes: two fp32 summation orders, 3e-7 apart at 3 per row, 1e-6 at 27;
 //   backward  dY = (Âᵀ ⋆ dZ) · W2ᵀ per row, P = H·W1 recomputed (12 fmas), dP = dY ⊙ act1'(P), and
 //             dW1 = Σ_r H[r]ᵀ·dP[r] accumulated on the spot (fp64, dealt over the lanes of a row, slabs reduced by the
 //             last block): no dY, no pre-activation and no dP tensor, no separate dW1 launch.
+// Small, dense slices (N·width·4 B <= 64 KB and >= 8 non-zeros per row: the AMLSim shape, N = 1 000, 27 per row) take the
+// STAGED variants: a block belongs to one slice, first forms what its rows will gather — act1(H·W1) of every node of the
+// slice (forward), dZ ⊙ act2'(pre2) of every node (backward) — in LDS, once per node instead of once per non-zero,
+// and then gathers from LDS: 24-byte rows at random addresses cost an L1 tag look-up per lane and instruction through
+// the vector memory path (measured 6.5 clocks per non-zero per CU) and a fraction of that from LDS.
 // dW2 = (Â⋆Y)ᵀ·dZ stays the narrow dW kernel (gemm.hip) on the Â⋆Y the forward stores for it (folding its 36 sums into
 // the backward kernel as well was measured: 72 us instead of 37 + 13 — 48 fp64 accumulators per lane; not kept).
 #include "common.h"
@@ -36,6 +41,7 @@ struct L12Args {
   int64_t n_rows;
   int32_t N;
   int32_t act1, act2;
+  int32_t chunks, chunk_rows;   // staged variants: blocks per slice and rows per block
 };
 
 template <int N, typename T>
@@ -44,6 +50,33 @@ __device__ __forceinline__ T pick_at(const T (&v)[N], int i) {
 #pragma unroll
   for (int q = 1; q < N; ++q) r = (i == q) ? v[q] : r;
   return r;
+}
+
+// NB consecutive non-zeros starting at `base`, as unaligned 16-byte loads (four column indices / four values each) while they
+// lie inside the arrays, element loads clamped to the last entry otherwise (the tail of the last rows only).  Every load
+// is unconditional and every column index returned is a valid one: the caller skips the positions past its row's end.
+struct __attribute__((packed, aligned(4))) Int4u { int32_t v[4]; };
+struct __attribute__((packed, aligned(4))) Float4u { float v[4]; };
+
+template <int NB>
+__device__ __forceinline__ void load_entries(const int32_t* col, const float* val, int64_t base, int64_t nnz, int (&c)[NB], float (&v)[NB]) {
+  static_assert(NB % 4 == 0, "four entries per load");
+  if (base + NB <= nnz) {
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) {
+      const Int4u ci = *reinterpret_cast<const Int4u*>(col + base + 4 * q);
+      const Float4u vi = *reinterpret_cast<const Float4u*>(val + base + 4 * q);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[4 * q + u] = ci.v[u], v[4 * q + u] = vi.v[u];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int64_t q = base + u < nnz ? base + u : nnz - 1;
+      c[u] = col[q];
+      v[u] = val[q];
+    }
+  }
 }
 
 // y[f] = act1(Σ_k h[k]·W1[k][f]) — gemm_small's chain (k ascending from 0), so the same bits
@@ -58,7 +91,9 @@ __device__ __forceinline__ void layer1_row(const float (&h)[KI], const float (&W
   }
 }
 
-template <int KI, int F, int NT, int G>
+extern __shared__ float l12_stage[];   // staged variants: [N][F] (forward) / [N][NT] (backward) of the block's slice
+
+template <int KI, int F, int NT, int G, bool STAGED>
 __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
   // uniform operands first (scalar registers), before any store of this kernel
   float W1[KI][F], W2[F][NT];
@@ -71,67 +106,107 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) W2[f][n] = a.W2[f * NT + n];
   const ActApply act1(a.act1), act2(a.act2);
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t r = gid / G;
-  const int gl = (int)(gid % G);
-  const bool live = r < a.n_rows;
-  float acc[F];
+  const int64_t nnz = a.rowptr[a.n_rows];
+  static_assert(KI == 2, "H rows are float2");
+  const int gl = threadIdx.x & (G - 1);
+  int64_t r, r_end, xoff;
+  int64_t r_base = 0;
+  if constexpr (STAGED) {
+    const int slice = blockIdx.x / a.chunks, chunk = blockIdx.x - slice * a.chunks;
+    xoff = (int64_t)slice * a.N;
+    for (int c = threadIdx.x; c < a.N; c += 256) {               // layer 1 of every node of the slice, once
+      const float2 hv = *reinterpret_cast<const float2*>(a.H + (xoff + c) * KI);
+      const float h[KI] = {hv.x, hv.y};
+      float y[F];
+      layer1_row<KI, F>(h, W1, act1, y);
 #pragma unroll
-  for (int f = 0; f < F; ++f) acc[f] = 0.f;
-  if (live) {
-    const int64_t beg = a.rowptr[r], end = a.rowptr[r + 1];
-    const int64_t xoff = (r / a.N) * (int64_t)a.N;
-    // NB non-zeros of the row per trip: their (col, val) pairs are requested together and then their H rows together —
-    // two dependent round trips per NB non-zeros instead of two per non-zero (these kernels are bound by that chain,
-    // not by bytes).  Positions past the row's end are clamped to its last entry and carry weight 0: every load is
-    // unconditional (a load under a per-lane condition becomes a branch with a full wait).  Same fmaf order per lane.
-    constexpr int NB = 4;
-    for (int64_t p = beg + gl; p < end; p += NB * G) {
+      for (int f = 0; f < F; f += 2) *reinterpret_cast<float2*>(l12_stage + c * F + f) = make_float2(y[f], y[f + 1]);
+    }
+    const int first = chunk * a.chunk_rows, last = first + a.chunk_rows < a.N ? first + a.chunk_rows : a.N;
+    int64_t* rps = reinterpret_cast<int64_t*>(l12_stage + a.N * F);      // the block's row pointers
+    for (int i = threadIdx.x; i <= last - first; i += 256) rps[i] = a.rowptr[xoff + first + i];
+    r_base = xoff + first;
+    __syncthreads();
+    r = xoff + first + threadIdx.x / G;
+    r_end = xoff + last;
+  } else {
+    r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    r_end = r < a.n_rows ? r + 1 : r;                            // one row per group
+    xoff = (r / a.N) * (int64_t)a.N;
+  }
+  for (; r < r_end; r += 256 / G) {
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    int64_t beg, end;
+    if constexpr (STAGED) {
+      const int64_t* rps = reinterpret_cast<const int64_t*>(l12_stage + a.N * F);
+      beg = rps[r - r_base], end = rps[r - r_base + 1];
+    } else {
+      beg = a.rowptr[r], end = a.rowptr[r + 1];
+    }
+    // A trip takes NB·G non-zeros of the row, NB CONSECUTIVE ones per lane: their (col, val) pairs are requested together
+    // (16-byte loads) and then their H rows together — two dependent round trips per trip instead of two per non-zero,
+    // and a quarter of the load instructions and address arithmetic of element loads.  All loads are unconditional (a
+    // load under a per-lane condition becomes a branch with a full wait); positions past the row's end are skipped in
+    // the arithmetic.
+    constexpr int NB = STAGED ? 8 : 4;
+    for (int64_t t0 = beg; t0 < end; t0 += NB * G) {
+      const int64_t base = t0 + gl * NB;
       float v[NB];
       int c[NB];
+      load_entries<NB>(a.col, a.val, base, nnz, c, v);
+      if constexpr (STAGED) {
+        float y[NB][F];
 #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int64_t q = p + u * G;
-        const int64_t qc = q < end ? q : end - 1;
-        const float vv = a.val[qc];
-        c[u] = a.col[qc];
-        v[u] = q < end ? vv : 0.f;
-      }
-      float2 hv[NB];
-      static_assert(KI == 2, "H rows are float2");
+        for (int u = 0; u < NB; ++u)
 #pragma unroll
-      for (int u = 0; u < NB; ++u) hv[u] = *reinterpret_cast<const float2*>(a.H + (xoff + c[u]) * KI);
+          for (int f = 0; f < F; f += 2) {
+            const float2 q = *reinterpret_cast<const float2*>(l12_stage + c[u] * F + f);
+            y[u][f] = q.x;
+            y[u][f + 1] = q.y;
+          }
 #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        if (p + u * G < end) {                                   // slots past the row's end: skipped (no layer-1 work for them)
-          const float h[KI] = {hv[u].x, hv[u].y};
-          float y[F];
-          layer1_row<KI, F>(h, W1, act1, y);
+        for (int u = 0; u < NB; ++u)
+          if (base + u < end) {
 #pragma unroll
-          for (int f = 0; f < F; ++f) acc[f] = fmaf(v[u], y[f], acc[f]);      // spmm_gemm_small's accumulation
+            for (int f = 0; f < F; ++f) acc[f] = fmaf(v[u], y[u][f], acc[f]);
+          }
+      } else {
+        float2 hv[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) hv[u] = *reinterpret_cast<const float2*>(a.H + (xoff + c[u]) * KI);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          if (base + u < end) {                                    // positions past the row's end: no layer-1 work for them
+            const float h[KI] = {hv[u].x, hv[u].y};
+            float y[F];
+            layer1_row<KI, F>(h, W1, act1, y);
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] = fmaf(v[u], y[f], acc[f]);
+          }
         }
       }
     }
-  }
 #pragma unroll
-  for (int o = G >> 1; o > 0; o >>= 1)
+    for (int o = G >> 1; o > 0; o >>= 1)
 #pragma unroll
-    for (int f = 0; f < F; ++f) acc[f] += __shfl_xor(acc[f], o);
-  if (!live) return;
-  if (a.AX) {
-    for (int f = gl; f < F; f += G) a.AX[r * F + f] = pick_at<F>(acc, f);
-  }
-  for (int n = gl; n < NT; n += G) {
-    float s = 0.f;
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-      float w = W2[f][0];
-#pragma unroll
-      for (int q = 1; q < NT; ++q) w = (n == q) ? W2[f][q] : w;
-      s = fmaf(acc[f], w, s);
+      for (int f = 0; f < F; ++f) acc[f] += __shfl_xor(acc[f], o);
+    if (a.AX) {
+      for (int f = gl; f < F; f += G) a.AX[r * F + f] = pick_at<F>(acc, f);
     }
-    if (a.pre2_out) a.pre2_out[r * NT + n] = s;
-    a.Z[r * NT + n] = act2(s);
+    for (int n = gl; n < NT; n += G) {
+      float s = 0.f;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        float w = W2[f][0];
+#pragma unroll
+        for (int q = 1; q < NT; ++q) w = (n == q) ? W2[f][q] : w;
+        s = fmaf(acc[f], w, s);
+      }
+      if (a.pre2_out) a.pre2_out[r * NT + n] = s;
+      a.Z[r * NT + n] = act2(s);
+    }
   }
 }
 
@@ -139,7 +214,7 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
 // over the lanes of a group (lane gl owns q = gl + j·G).
 constexpr int kL12MaxBlocks = 1024;
 
-template <int KI, int F, int NT, int G>
+template <int KI, int F, int NT, int G, bool STAGED>
 __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
   constexpr int NO = KI * F;
   constexpr int NPL = (NO + G - 1) / G;
@@ -155,33 +230,66 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) W2[f][n] = a.W2[f * NT + n];
   const ActGrad dact1(a.act1), dact2(a.act2);
+  const int64_t nnz = a.rowptr[a.n_rows];
   const int gl = threadIdx.x & (G - 1);
-  const int64_t n_groups = (int64_t)gridDim.x * 256 / G;
   double acc[NPL];
 #pragma unroll
   for (int j = 0; j < NPL; ++j) acc[j] = 0.0;
-  for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G; r < a.n_rows; r += n_groups) {
-    const int64_t beg = a.rowptr[r], end = a.rowptr[r + 1];
-    const int64_t xoff = (r / a.N) * (int64_t)a.N;
+  int64_t r, r_end, r_step;
+  int64_t r_base = 0;
+  if constexpr (STAGED) {
+    const int slice = blockIdx.x / a.chunks, chunk = blockIdx.x - slice * a.chunks;
+    const int64_t xoff = (int64_t)slice * a.N;
+    for (int c = threadIdx.x; c < a.N; c += 256) {               // dZ ⊙ act2'(pre2) of every node of the slice, once
+      const float2* gz = reinterpret_cast<const float2*>(a.dZ + (xoff + c) * NT);
+      const float2* pz = reinterpret_cast<const float2*>((a.pre2 ? a.pre2 : a.dZ) + (xoff + c) * NT);
+#pragma unroll
+      for (int i = 0; i < NT / 2; ++i) {
+        float2 q = gz[i];
+        if (a.pre2) {
+          const float2 w = pz[i];
+          q.x *= dact2(w.x);
+          q.y *= dact2(w.y);
+        }
+        *reinterpret_cast<float2*>(l12_stage + c * NT + 2 * i) = q;
+      }
+    }
+    const int first = chunk * a.chunk_rows, last = first + a.chunk_rows < a.N ? first + a.chunk_rows : a.N;
+    int64_t* rps = reinterpret_cast<int64_t*>(l12_stage + a.N * NT);      // the block's row pointers
+    for (int i = threadIdx.x; i <= last - first; i += 256) rps[i] = a.rowptr[xoff + first + i];
+    r_base = xoff + first;
+    __syncthreads();
+    r = xoff + first + threadIdx.x / G;
+    r_end = xoff + last;
+    r_step = 256 / G;
+  } else {
+    r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    r_end = a.n_rows;
+    r_step = (int64_t)gridDim.x * 256 / G;
+  }
+  for (; r < r_end; r += r_step) {
+    int64_t beg, end;
+    if constexpr (STAGED) {
+      const int64_t* rps = reinterpret_cast<const int64_t*>(l12_stage + a.N * NT);
+      beg = rps[r - r_base], end = rps[r - r_base + 1];
+    } else {
+      beg = a.rowptr[r], end = a.rowptr[r + 1];
+    }
+    const int64_t xoff = STAGED ? 0 : (r / a.N) * (int64_t)a.N;   // staged: columns index the slice's LDS copy
     float t[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) t[n] = 0.f;
-    constexpr int NB = 4;                                    // non-zeros per trip, loads unconditional (see the forward kernel)
-    for (int64_t p = beg + gl; p < end; p += NB * G) {
+    constexpr int NB = STAGED ? 8 : 4;                       // NB consecutive non-zeros per lane and trip (see the forward kernel)
+    for (int64_t t0 = beg; t0 < end; t0 += NB * G) {
+      const int64_t base = t0 + gl * NB;
       float v[NB];
-      int64_t c[NB];
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int64_t q = p + u * G;
-        const int64_t qc = q < end ? q : end - 1;
-        const float vv = a.val[qc];
-        c[u] = xoff + a.col[qc];
-        v[u] = q < end ? vv : 0.f;
-      }
+      int c[NB];
+      load_entries<NB>(a.col, a.val, base, nnz, c, v);
       float g[NB][NT];
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
-        const float2* gz = reinterpret_cast<const float2*>(a.dZ + c[u] * NT);
+        const float2* gz = STAGED ? reinterpret_cast<const float2*>(l12_stage + c[u] * NT)
+                                  : reinterpret_cast<const float2*>(a.dZ + (xoff + c[u]) * NT);
 #pragma unroll
         for (int i = 0; i < NT / 2; ++i) {
           const float2 q = gz[i];
@@ -189,10 +297,10 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
           g[u][2 * i + 1] = q.y;
         }
       }
-      if (a.pre2) {                                          // act2 != none: dZ ⊙ act2'(pre2) of the gathered rows
+      if (!STAGED && a.pre2) {                                // act2 != none: dZ ⊙ act2'(pre2) of the gathered rows
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-          const float2* pz = reinterpret_cast<const float2*>(a.pre2 + c[u] * NT);
+          const float2* pz = reinterpret_cast<const float2*>(a.pre2 + (xoff + c[u]) * NT);
 #pragma unroll
           for (int i = 0; i < NT / 2; ++i) {
             const float2 q = pz[i];
@@ -203,7 +311,7 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u)
-        if (p + u * G < end) {
+        if (base + u < end) {
 #pragma unroll
           for (int n = 0; n < NT; ++n) t[n] = fmaf(v[u], g[u][n], t[n]);
         }
@@ -283,20 +391,37 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
 
 // lanes per row: chains of about four non-zeros per lane, walked NB at a time (kernel durations under rocprofv3, captured
 // S1 / S3 steps: 3 nnz/row: G = 1 beats 2 by 18 %; 27 nnz/row: G = 4 — 41 us backward against 48 with one lane per row)
-static int l12_lanes(float avg_nnz_per_row) {
+static int l12_lanes(float avg_nnz_per_row, bool staged) {
   int G = 8;
   if (avg_nnz_per_row >= 0.f) {
     G = 1;
-    while (G < 16 && 4.f * G <= avg_nnz_per_row) G <<= 1;
+    if (staged)       // 8 per lane and trip, two trips: 27 nnz/row: G = 2 21.8 / 23.2 us, 4: 25.9 / 24.0 (and 32 B of scratch), 8: 31.2 / 30.8
+      while (G < 16 && 16.f * G < avg_nnz_per_row) G <<= 1;
+    else
+      while (G < 16 && 4.f * G <= avg_nnz_per_row) G <<= 1;
   }
   return G;
 }
 
-template <int F, int NT, bool BWD>
-static void l12_launch_g(const L12Args& a, int G, unsigned blocks, hipStream_t st) {
-#define TMGCN_L12(G_)                                                                                       \
-  if (BWD) hipLaunchKernelGGL((l12_bwd_kernel<2, F, NT, G_>), dim3(blocks), dim3(256), 0, st, a);              \
-  else hipLaunchKernelGGL((l12_fwd_kernel<2, F, NT, G_>), dim3(blocks), dim3(256), 0, st, a);
+// The staged variants (see the head of the file): LDS for one slice, at least 8 non-zeros per row to pay for forming it.
+constexpr int64_t kL12StageBytes = 64 << 10;
+static bool l12_staged(int64_t n_rows, int32_t N, int width, float avg_nnz_per_row) {
+  return avg_nnz_per_row >= 8.f && (int64_t)N * width * 4 <= kL12StageBytes && n_rows / N <= kL12MaxBlocks;
+}
+// blocks per slice: about 640 blocks in all (2.5 per CU; every block forms the whole slice in LDS first, so more blocks
+// means more of that), at least 64 rows each.  Captured AMLSim-shaped step (150 slices of 1 000 nodes, 27 per row), kernel
+// durations under rocprofv3: 4 blocks per slice 21.8 us forward / 23.2 backward, 6: 21.8 / 27.8, 2: 33.8 / 33.4.
+static int l12_chunks(int64_t slices, int32_t N) {
+  int64_t c = 640 / slices, most = (N + 63) / 64;
+  if (c > most) c = most;
+  return (int)(c < 1 ? 1 : c);
+}
+
+template <int F, int NT, bool BWD, bool STAGED>
+static void l12_launch_g(const L12Args& a, int G, unsigned blocks, size_t lds, hipStream_t st) {
+#define TMGCN_L12(G_)                                                                                              \
+  if (BWD) hipLaunchKernelGGL((l12_bwd_kernel<2, F, NT, G_, STAGED>), dim3(blocks), dim3(256), lds, st, a);           \
+  else hipLaunchKernelGGL((l12_fwd_kernel<2, F, NT, G_, STAGED>), dim3(blocks), dim3(256), lds, st, a);
   switch (G) {
     case 1: TMGCN_L12(1) break;
     case 2: TMGCN_L12(2) break;
@@ -307,14 +432,14 @@ static void l12_launch_g(const L12Args& a, int G, unsigned blocks, hipStream_t s
 #undef TMGCN_L12
 }
 
-template <bool BWD>
-static void l12_launch(const L12Args& a, int F, int NT, int G, unsigned blocks, hipStream_t st) {
-#define TMGCN_L12_N(F_)                                                \
-  switch (NT) {                                                        \
-    case 2: l12_launch_g<F_, 2, BWD>(a, G, blocks, st); break;          \
-    case 4: l12_launch_g<F_, 4, BWD>(a, G, blocks, st); break;          \
-    case 6: l12_launch_g<F_, 6, BWD>(a, G, blocks, st); break;          \
-    default: l12_launch_g<F_, 8, BWD>(a, G, blocks, st);                \
+template <bool BWD, bool STAGED>
+static void l12_launch(const L12Args& a, int F, int NT, int G, unsigned blocks, size_t lds, hipStream_t st) {
+#define TMGCN_L12_N(F_)                                                             \
+  switch (NT) {                                                                     \
+    case 2: l12_launch_g<F_, 2, BWD, STAGED>(a, G, blocks, lds, st); break;           \
+    case 4: l12_launch_g<F_, 4, BWD, STAGED>(a, G, blocks, lds, st); break;           \
+    case 6: l12_launch_g<F_, 6, BWD, STAGED>(a, G, blocks, lds, st); break;           \
+    default: l12_launch_g<F_, 8, BWD, STAGED>(a, G, blocks, lds, st);                 \
   }
   switch (F) {
     case 2: TMGCN_L12_N(2) break;
@@ -344,11 +469,25 @@ extern "C" int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, 
   if (n_rows == 0) return TMGCN_OK;
   TMGCN_REQUIRE(rowptr && H && W1 && W2 && Z, "layer12: null pointer");
   TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(H) % 8 == 0, "layer12: H must be 8-byte aligned");
-  L12Args a{rowptr, col, val, H, W1, W2, nullptr, nullptr, Z, AX, pre2, nullptr, nullptr, nullptr, n_rows, N, act1, act2};
-  const int G = l12_lanes(avg_nnz_per_row);
-  const unsigned blocks = (unsigned)((n_rows * G + 255) / 256);
-  l12_launch<false>(a, F, Nf, G, blocks, (hipStream_t)stream);
+  L12Args a{rowptr, col, val, H, W1, W2, nullptr, nullptr, Z, AX, pre2, nullptr, nullptr, nullptr, n_rows, N, act1, act2, 0, 0};
+  const bool staged = l12_staged(n_rows, N, F, avg_nnz_per_row);
+  const int G = l12_lanes(avg_nnz_per_row, staged);
+  if (staged) {
+    a.chunks = l12_chunks(n_rows / N, N);
+    a.chunk_rows = (N + a.chunks - 1) / a.chunks;
+    l12_launch<false, true>(a, F, Nf, G, (unsigned)(n_rows / N * a.chunks), (size_t)N * F * 4 + (a.chunk_rows + 1) * 8, (hipStream_t)stream);
+  } else {
+    l12_launch<false, false>(a, F, Nf, G, (unsigned)((n_rows * G + 255) / 256), 0, (hipStream_t)stream);
+  }
   return check_launch("layer12_fwd");
+}
+
+// 1 when the fused forward is the faster route for this shape: short rows (layer 1 re-applied per gathered row is cheap
+// then), or a shape the staged variant takes (layer 1 once per node); otherwise the caller forms act1(H·W1) itself and
+// calls tmgcn_spmm_gemm_f32 (the same Z up to the fp32 summation order of a row).
+extern "C" int tmgcn_layer12_fwd_pays(int64_t n_rows, int32_t N, int32_t F, float avg_nnz_per_row) {
+  if (N <= 0 || n_rows <= 0) return 0;
+  return ((avg_nnz_per_row >= 0.f && avg_nnz_per_row <= 6.f) || l12_staged(n_rows, N, F, avg_nnz_per_row)) ? 1 : 0;
 }
 
 extern "C" int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F) {
@@ -375,11 +514,18 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
   }
   hipStream_t st = (hipStream_t)stream;
   L12Args a{t_rowptr, t_col, t_val, H, W1, W2, dZ, pre2, nullptr, nullptr, nullptr, dW1, (float*)workspace,
-            acquire_sync_word(st), n_rows, N, act1, act2};
+            acquire_sync_word(st), n_rows, N, act1, act2, 0, 0};
   TMGCN_REQUIRE(a.sync, "layer12_bwd: no hand-off word");
-  const int G = l12_lanes(avg_nnz_per_row);
-  int64_t blocks = (n_rows * G + 255) / 256;
-  if (blocks > kL12MaxBlocks) blocks = kL12MaxBlocks;
-  l12_launch<true>(a, F, Nf, G, (unsigned)blocks, st);
+  const bool staged = l12_staged(n_rows, N, Nf, avg_nnz_per_row);
+  const int G = l12_lanes(avg_nnz_per_row, staged);
+  if (staged) {
+    a.chunks = l12_chunks(n_rows / N, N);
+    a.chunk_rows = (N + a.chunks - 1) / a.chunks;
+    l12_launch<true, true>(a, F, Nf, G, (unsigned)(n_rows / N * a.chunks), (size_t)N * Nf * 4 + (a.chunk_rows + 1) * 8, st);
+  } else {
+    int64_t blocks = (n_rows * G + 255) / 256;
+    if (blocks > kL12MaxBlocks) blocks = kL12MaxBlocks;
+    l12_launch<true, false>(a, F, Nf, G, (unsigned)blocks, 0, st);
+  }
   return check_launch("layer12_bwd");
 }
