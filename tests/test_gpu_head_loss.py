@@ -218,6 +218,24 @@ def test_graphed_step_with_fused_loss_follows_the_eager_trajectory():
     assert step.fused
     got = [float(step()) for _ in range(7)]
     assert_close(np.array(got), d["losses"][3:], REL_TOL, "graph + fused loss, steps 4-10")
+    # several steps per replay (one launch latency for all of them): the same trajectory, every loss kept; both the
+    # fused one-launch SGD and torch's own optimizer
+    from tmgcn_amd.optim import FusedSGD
+    for fused_opt in (False, True):
+        m3, o3 = make()
+        if fused_opt:
+            o3 = FusedSGD(m3.parameters(), lr=0.01, momentum=0.9)
+        step3 = GraphedTrainStep(m3, WeightedCrossEntropy(w).cuda(), o3, tgt, warmup=1, steps_per_replay=3)
+        got3 = []
+        for _ in range(3):
+            last = step3()
+            assert last is step3.losses[-1] and len(step3.losses) == 3
+            got3 += [float(l) for l in step3.losses]
+        assert_close(np.array(got3), d["losses"][1:], REL_TOL, "three steps per replay, steps 2-10")
+        for q2, q3 in zip(m2.parameters(), m3.parameters()):
+            assert_close(q3.detach(), q2.detach(), REL_TOL, "parameters after ten steps")
+    with pytest.raises(ValueError):
+        GraphedTrainStep(m2, WeightedCrossEntropy(w).cuda(), o2, tgt, steps_per_replay=0)
 
 
 @pytest.mark.parametrize("T,N,E", [(4, 30, 800), (6, 2000, 300)])       # dense entries / most rows without an entry

@@ -15,7 +15,11 @@ What keeps the launch count down (rocprofv3 --kernel-trace of an S1 step: profil
   * gradients are released before the capture (`zero_grad(set_to_none=True)`), so that the captured
     backward WRITES each `.grad` into graph-private memory instead of zero-filling and then adding
     into a persistent one (two launches per parameter saved) — PyTorch's whole-network capture recipe;
-  * with `tmgcn_amd.optim.FusedSGD` the optimizer step of all parameters is one launch.
+  * with `tmgcn_amd.optim.FusedSGD` the optimizer step of all parameters is one launch;
+  * `steps_per_replay=k` captures k consecutive steps into the one graph: a replay costs ≈ 8 µs of launch latency
+    whatever it holds (the gap in front of the first kernel in every rocprofv3 trace of a replayed step), a tenth of
+    a Bitcoin-OTC-sized step and a sixth of a Reddit-LP-sized one.  `step()` then advances the model by k epochs
+    and `step.losses` holds the k losses in order.
 """
 from __future__ import annotations
 
@@ -24,8 +28,12 @@ import torch
 
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, criterion, optimizer: torch.optim.Optimizer,
-                 target: torch.Tensor, warmup: int = 3, fused_loss: bool = True, keep_logits: bool = False):
+                 target: torch.Tensor, warmup: int = 3, fused_loss: bool = True, keep_logits: bool = False,
+                 steps_per_replay: int = 1):
         self.model, self.criterion, self.optimizer, self.target = model, criterion, optimizer, target
+        if steps_per_replay < 1:
+            raise ValueError("steps_per_replay must be at least 1")
+        self.steps_per_replay = int(steps_per_replay)
         dev = target.device
         if dev.type != "cuda":
             raise RuntimeError("GraphedTrainStep needs ROCm tensors")
@@ -56,11 +64,18 @@ class GraphedTrainStep:
         # launch when it meets this very tensor
         from . import ops
         self._one = ops.unit_gradient(dev)
+        self.losses = []
         with torch.cuda.graph(self.graph):
-            self.loss, self.output = forward_loss()
-            self.loss.backward(gradient=self._one)
-            optimizer.step()
+            for i in range(self.steps_per_replay):
+                if i:
+                    optimizer.zero_grad(set_to_none=True)      # host side only: the next backward writes fresh gradients
+                self.loss, self.output = forward_loss()
+                self.loss.backward(gradient=self._one)
+                optimizer.step()
+                self.losses.append(self.loss)
 
     def __call__(self) -> torch.Tensor:
+        """One replay = `steps_per_replay` epochs.  Returns the loss of the last of them (a tensor the next replay
+        overwrites); `self.losses` lists all of them, `self.output` is the last step's logits when kept."""
         self.graph.replay()
         return self.loss

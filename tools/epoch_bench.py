@@ -3,7 +3,7 @@
 probe P128) on the MI355X module vs the CPU oracle executed the reference's way — the same code
 as bench.py's `epochs` block (bench.epochs_block), callable for a chosen subset:
 
-    python tools/epoch_bench.py [S1 S2 S3 P128] [--epoch-reps 50] [--cpu-epoch-reps 5] [--modes eager graph fused graph_fused script]
+    python tools/epoch_bench.py [S1 S2 S3 P128] [--epoch-reps 50] [--cpu-epoch-reps 5] [--modes eager graph fused graph_fused graph_fused8 script]
 
 An "epoch" is what the reference scripts do per iteration (experiment_bitcoin_our.py:118-123,
 experiment_reddit_our_link_prediction.py:75-81): zero_grad, gcn(), weighted CE, backward, SGD step."""
@@ -20,7 +20,7 @@ if __name__ == "__main__":
     ap.add_argument("configs", nargs="*", default=["S1", "S2", "S3"])
     ap.add_argument("--epoch-reps", type=int, default=50)
     ap.add_argument("--cpu-epoch-reps", type=int, default=5)
-    ap.add_argument("--modes", nargs="*", default=["eager", "graph", "fused", "graph_fused", "script"])
+    ap.add_argument("--modes", nargs="*", default=["eager", "graph", "fused", "graph_fused", "graph_fused8", "script"])
     a = ap.parse_args()
     args = bench.parse(["--epoch-reps", str(a.epoch_reps), "--cpu-epoch-reps", str(a.cpu_epoch_reps)])
     print(json.dumps(bench.epochs_block(args, tuple(a.configs), tuple(a.modes)), indent=1), flush=True)
