@@ -302,9 +302,11 @@ int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* w
  *   K = 2 ("fold", the 1-layer model ehf:222): Z is AtXt [R][2] and W_fold [2][F] the shared weight;
  *       Z = AtXt·W is recomputed per row, dZ is not stored and dW [2][F] = Σ_r AtXt[r]ᵀ·dZ[r] is returned.
  *   workspace            tmgcn_head_loss_workspace_bytes(F, C, K) bytes
- *   sync                 one int32, ZERO before the first launch; the kernel leaves it zero.  Launches
- *                        that share a sync word must not overlap.  NULL = a word of the library's own pool.
+ *   sync                 TMGCN_SYNC_INTS int32 (the blocks' two-level hand-off counters), ZERO before the first
+ *                        launch; the kernel leaves them zero.  Launches that share a sync block must not overlap.
+ *                        NULL = a block of the library's own pool.
  */
+#define TMGCN_SYNC_INTS 272
 int tmgcn_head_loss_supported(int32_t F, int32_t C, int32_t K);
 int64_t tmgcn_head_loss_workspace_bytes(int32_t F, int32_t C, int32_t K);
 int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t K, const float* U,

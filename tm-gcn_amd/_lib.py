@@ -15,6 +15,7 @@ ACT_IDS = {None: 0, "none": 0, "relu": 1, "leaky": 2, "selu": 3}
 DW_ALGOS = {None: 0, "auto": 0, "f32mfma": 1}   # TMGCN_DW_AUTO / TMGCN_DW_F32MFMA
 GEMM_ALGOS = {None: 0, "auto": 0, "f32mfma": 1}  # TMGCN_GEMM_AUTO / TMGCN_GEMM_F32MFMA
 ABI_VERSION = 4
+SYNC_INTS = 272          # include/tmgcn.h: TMGCN_SYNC_INTS (a hand-off block of the last-block reductions)
 
 
 class TmgcnLibraryError(RuntimeError):

@@ -28,19 +28,38 @@ inline int check_launch(const char* what) {
 unsigned int* acquire_tile_counters(hipStream_t stream, int n);  // n consecutive zeroed counters
 inline unsigned int* acquire_tile_counter(hipStream_t stream) { return acquire_tile_counters(stream, 1); }
 
-// A hand-off word for a kernel whose last block finishes a reduction (pointwise.hip owns the pool): zero when
-// the launch starts, left zero by the launch — no memset node per call.
+// A hand-off block (kSyncInts int32, last_block_ticket) for a kernel whose last block finishes a reduction
+// (pointwise.hip owns the pool): zero when the launch starts, left zero by the launch — no memset node per call.
 int32_t* acquire_sync_word(hipStream_t stream);
 
 // Called by EVERY thread of a block after its slab stores (write-through: 4- / 8-byte relaxed agent-scope atomic
 // stores): drains the stores, meets, takes ONE ticket; true in every thread of the block that drew the last one.
 // That block then reads the slabs with relaxed agent-scope atomic loads (cdna_hip_programming.md §6 Guideline 16,
 // recipe R1: no release / acquire fence when every handed-off byte is stored and loaded write-through).
+// Tickets are drawn in TWO levels: agent-scope atomics on one address are served one after the other by the memory side
+// (the XCDs' L2s are not coherent), ≈ 16 ns each — a kernel whose 1 024 blocks finish together queued for 16 us on a
+// single counter (narrow dW: 13.1 / 17.2 / 26.8 us with 279 / 557 / 1 114 blocks, the same bytes).  So block b draws
+// from counter 1 + b mod 16 of the launch's hand-off block (kSyncInts int32, the counters 64 bytes apart), the last of
+// each of those sixteen groups draws from counter 0, and the last there is the last of all.  The group counters are
+// left zero by their last drawer, counter 0 by the caller (`*sync = 0` in the finishing block).
+constexpr int kSyncGroups = 16, kSyncStride = 16;
+constexpr int kSyncInts = (1 + kSyncGroups) * kSyncStride;
+static_assert(kSyncInts == TMGCN_SYNC_INTS, "include/tmgcn.h states the size of a hand-off block");
 __device__ __forceinline__ bool last_block_ticket(int32_t* sync, int n_blocks, int* lds_flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0)
-    *lds_flag = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_blocks - 1;
+  if (threadIdx.x == 0) {
+    const int g = blockIdx.x % kSyncGroups;
+    const int members = (n_blocks - g + kSyncGroups - 1) / kSyncGroups;     // blocks b < n_blocks with b mod 16 == g
+    int32_t* mine = sync + (1 + g) * kSyncStride;
+    bool last = false;
+    if (__hip_atomic_fetch_add(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+      __hip_atomic_store(mine, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int groups = n_blocks < kSyncGroups ? n_blocks : kSyncGroups;
+      last = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+    }
+    *lds_flag = last;
+  }
   __syncthreads();
   return *lds_flag != 0;
 }
@@ -144,6 +163,31 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], int j) {
       v[3] = r1;
     }
   }
+}
+
+// A thread's share of the last block's slab reduction: Σ slab[c][o] over the slabs c = first, first + stride, … below n,
+// read with sc1 loads (see last_block_ticket), DEPTH of them in flight — issued together and masked, not branched, past
+// the end — and added in slab order (reproducible).  The loads come from memory, about a microsecond a round trip: with
+// 8 in flight the last block of the fused backward spent 6 us adding 1 024 slabs; 32 bring that to two round trips.
+#ifndef TMGCN_FIN_DEPTH
+#define TMGCN_FIN_DEPTH 8
+#endif
+constexpr int kFinisherDepth = TMGCN_FIN_DEPTH;
+
+template <int DEPTH>
+__device__ __forceinline__ double slab_sum_f32(const unsigned* slabs, int n, int first, int stride, int width, int o) {
+  double s = 0.0;
+  for (int c = first; c < n; c += DEPTH * stride) {
+    float v[DEPTH];
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) {
+      const int cc = c + q * stride;
+      v[q] = __uint_as_float(__hip_atomic_load(slabs + (int64_t)(cc < n ? cc : n - 1) * width + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) s += c + q * stride < n ? (double)v[q] : 0.0;
+  }
+  return s;
 }
 
 // e^x on the negative side of SELU and of its derivative (x <= 0): one multiply and the hardware exp2 instead of expf's

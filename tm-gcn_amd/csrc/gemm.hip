@@ -1191,26 +1191,12 @@ __global__ __launch_bounds__(256) void gemm_dw_narrow_kernel(DwArgs a) {
   if (threadIdx.x == 0) *a.sync = 0;
   const unsigned* P = reinterpret_cast<const unsigned*>(a.part);
   if (a.n_batch == 1) {
-    // one output matrix: SUBS = 256 / NO threads per output, each adding the slabs c = sub, sub + SUBS, … (8 loads in
-    // flight, masked rather than branched), then the SUBS partial sums of an output in order
+    // one output matrix: SUBS = 256 / NO threads per output, each adding the slabs c = sub, sub + SUBS, … (slab_sum_f32),
+    // then the SUBS partial sums of an output in order
     constexpr int SUBS = 256 / NO;
     __shared__ double fin[SUBS][NO];
     const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
-    if (sub < SUBS) {
-      double s[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) s[q] = 0.0;
-      for (int c = sub; c < a.chunks; c += 8 * SUBS) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int cc = c + q * SUBS;
-          const float v = __uint_as_float(__hip_atomic_load(P + (int64_t)(cc < a.chunks ? cc : a.chunks - 1) * NO + o,
-                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          s[q] += cc < a.chunks ? (double)v : 0.0;
-        }
-      }
-      fin[sub][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-    }
+    if (sub < SUBS) fin[sub][o] = slab_sum_f32<kFinisherDepth>(P, a.chunks, sub, SUBS, NO, o);
     __syncthreads();
     if (threadIdx.x < NO) {
       double t = 0.0;
@@ -1436,12 +1422,21 @@ static int gemm_dw_launch(const float* A, const float* dY, const float* pre, int
                       reinterpret_cast<uintptr_t>(dY) % 8 == 0;
   TMGCN_REQUIRE(!pre || narrow, "gemm_dw_act: the fused activation gradient needs the narrow kernel (even K, Nf <= 8, 8-byte "
                                  "aligned operands); use tmgcn_act_bwd_f32 + tmgcn_gemm_dw_f32");
-  if (narrow && rpc < 2048) {
-    // the narrow kernel's fixed cost is the K·Nf-value block reduction: fatter chunks (never more
-    // slabs than planned, so the workspace still fits)
+  if (narrow) {
+    // The narrow kernel's fixed costs are per block (the K·Nf-value block reduction, the slab and the hand-off ticket,
+    // and the last block's pass over all slabs), its loop is a stream: about one block per CU while the operand is small
+    // (captured steps, kernel durations under rocprofv3: 570 k rows 11.2 us with 279 blocks, 13.4 with 557; 150 k rows
+    // 7.6 us with 147 blocks, 9.0 with 74), four per CU from 4 M rows on; never more slabs than planned (workspace).
     const int64_t br = rows_per_batch ? rows_per_batch : R;
-    rpc = 2048;
-    chunks = (int)((br + rpc - 1) / rpc);
+    int64_t target = (R < (4ll << 20) ? 256 : 1024) / nb;      // blocks per batch
+    if (target < 1) target = 1;
+    int64_t fat = (br + target - 1) / target;
+    fat = (fat + 31) & ~(int64_t)31;
+    if (fat < 1024) fat = 1024;
+    if (fat > rpc) {
+      rpc = fat;
+      chunks = (int)((br + rpc - 1) / rpc);
+    }
   }
   DwArgs a{A, dY, (float*)workspace, R, K, Nf, rows_per_batch ? rows_per_batch : R, chunks, rpc};
   const unsigned gx = (unsigned)(nb * chunks);

@@ -359,27 +359,13 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!last_block_ticket(a.sync, (int)gridDim.x, &is_last)) return;
   if (threadIdx.x == 0) *a.sync = 0;
-  // the last block: 256 / NO threads per output, each adding its share of the slabs in order (8 loads in flight)
+  // the last block: 256 / NO threads per output, each adding its share of the slabs in order (slab_sum_f32)
   constexpr int SUBS = 256 / NO;
   __shared__ double fin[SUBS][NO];
   const unsigned* P = reinterpret_cast<const unsigned*>(a.part);
   const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
   const int nb = (int)gridDim.x;
-  if (sub < SUBS) {
-    double s[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s[q] = 0.0;
-    for (int c = sub; c < nb; c += 8 * SUBS) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int cc = c + q * SUBS;
-        const float v = __uint_as_float(__hip_atomic_load(P + (int64_t)(cc < nb ? cc : nb - 1) * NO + o, __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT));
-        s[q] += cc < nb ? (double)v : 0.0;
-      }
-    }
-    fin[sub][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-  }
+  if (sub < SUBS) fin[sub][o] = slab_sum_f32<kFinisherDepth>(P, nb, sub, SUBS, NO, o);
   __syncthreads();
   if (threadIdx.x < NO) {
     double tot = 0.0;

@@ -38,7 +38,7 @@ unsigned int* acquire_tile_counters(hipStream_t stream, int n) {
 // of them would have to be 1024 launches apart and still overlap), launches recorded into a hipGraph take a word of
 // the upper half for good (a replayed graph meets only its own words).
 constexpr int kSyncPool = 2048;
-__device__ int g_sync_words[kSyncPool];
+__device__ int g_sync_words[kSyncPool * kSyncInts];
 
 int32_t* acquire_sync_word(hipStream_t stream) {
   static int32_t* base[kMaxDevices] = {nullptr};
@@ -58,9 +58,9 @@ int32_t* acquire_sync_word(hipStream_t stream) {
   }
   if (cs == hipStreamCaptureStatusActive) {
     const unsigned k = next_captured.fetch_add(1);
-    return base[dev] + kSyncPool / 2 + (k % (kSyncPool / 2));   // > 1024 recorded launches: wraps (documented limit)
+    return base[dev] + (int64_t)(kSyncPool / 2 + (k % (kSyncPool / 2))) * kSyncInts;   // > 1024 recorded launches: wraps (documented limit)
   }
-  return base[dev] + (next_eager.fetch_add(1) % (kSyncPool / 2));
+  return base[dev] + (int64_t)(next_eager.fetch_add(1) % (kSyncPool / 2)) * kSyncInts;
 }
 
 void set_error(const char* fmt, ...) {

@@ -418,7 +418,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> head_loss_fwd(const Tensor& Z, const 
               F, " C=", C);
   TORCH_CHECK(tmgcn_head_loss_supported((int32_t)F, (int32_t)C, (int32_t)K), "head_loss: unsupported widths F=", F, " C=", C, " K=", K);
   TORCH_CHECK(eptr.numel() == R + 1 && ent.numel() % 2 == 0 && other.numel() == ent.numel() && meta.numel() == ent.numel() &&
-                  arow.dim() == 2 && arow.size(1) == 4 && sync.numel() >= 1,
+                  arow.dim() == 2 && arow.size(1) == 4 && sync.numel() >= TMGCN_SYNC_INTS,
               "head_loss: plan arrays do not match R=", R);
   TORCH_CHECK(grad || want_loss, "head_loss: nothing asked for");
   const int64_t E = ent.numel() / 2;

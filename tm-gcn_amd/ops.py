@@ -136,7 +136,7 @@ class HeadLossPlan:
         self.arow = torch.stack((active.to(torch.int32), self.eptr[:-1][active], self.eptr[1:][active],
                                  torch.zeros_like(active, dtype=torch.int32)), dim=1).contiguous()
         self.counts = torch.bincount(t[~ignored], minlength=C)[:C].to(torch.int64).contiguous()
-        self.sync = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sync = torch.zeros(_lib.SYNC_INTS, dtype=torch.int32, device=dev)   # include/tmgcn.h: TMGCN_SYNC_INTS
         self.R, self.C, self.ignore_index = R, C, ignore_index
         self._target, self._version = target, target._version
 
