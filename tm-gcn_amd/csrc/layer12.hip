@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
 // over the lanes of a group (lane gl owns q = gl + j·G).
 constexpr int kL12MaxBlocks = 1024;
 
-template <int KI, int F, int NT, int G, bool STAGED>
+template <int KI, int F, int NT, int G, bool STAGED, bool ACT2>
 __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
   constexpr int NO = KI * F;
   constexpr int NPL = (NO + G - 1) / G;
@@ -242,11 +242,11 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
     const int64_t xoff = (int64_t)slice * a.N;
     for (int c = threadIdx.x; c < a.N; c += 256) {               // dZ ⊙ act2'(pre2) of every node of the slice, once
       const float2* gz = reinterpret_cast<const float2*>(a.dZ + (xoff + c) * NT);
-      const float2* pz = reinterpret_cast<const float2*>((a.pre2 ? a.pre2 : a.dZ) + (xoff + c) * NT);
+      const float2* pz = reinterpret_cast<const float2*>((ACT2 ? a.pre2 : a.dZ) + (xoff + c) * NT);
 #pragma unroll
       for (int i = 0; i < NT / 2; ++i) {
         float2 q = gz[i];
-        if (a.pre2) {
+        if constexpr (ACT2) {
           const float2 w = pz[i];
           q.x *= dact2(w.x);
           q.y *= dact2(w.y);
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
           g[u][2 * i + 1] = q.y;
         }
       }
-      if (!STAGED && a.pre2) {                                // act2 != none: dZ ⊙ act2'(pre2) of the gathered rows
+      if constexpr (!STAGED && ACT2) {                                // act2 != none: dZ ⊙ act2'(pre2) of the gathered rows
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
           const float2* pz = reinterpret_cast<const float2*>(a.pre2 + (xoff + c[u]) * NT);
@@ -406,7 +406,10 @@ static int l12_chunks(int64_t slices, int32_t N) {
 template <int F, int NT, bool BWD, bool STAGED>
 static void l12_launch_g(const L12Args& a, int G, unsigned blocks, size_t lds, hipStream_t st) {
 #define TMGCN_L12(G_)                                                                                              \
-  if (BWD) hipLaunchKernelGGL((l12_bwd_kernel<2, F, NT, G_, STAGED>), dim3(blocks), dim3(256), lds, st, a);           \
+  if (BWD) {                                                                                                       \
+    if (a.pre2) hipLaunchKernelGGL((l12_bwd_kernel<2, F, NT, G_, STAGED, true>), dim3(blocks), dim3(256), lds, st, a);  \
+    else hipLaunchKernelGGL((l12_bwd_kernel<2, F, NT, G_, STAGED, false>), dim3(blocks), dim3(256), lds, st, a);        \
+  }                                                                                                                \
   else hipLaunchKernelGGL((l12_fwd_kernel<2, F, NT, G_, STAGED>), dim3(blocks), dim3(256), lds, st, a);
   switch (G) {
     case 1: TMGCN_L12(1) break;
@@ -510,7 +513,7 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
     l12_launch<true, true>(a, F, Nf, G, (unsigned)(n_rows / N * a.chunks), (size_t)N * Nf * 4 + (a.chunk_rows + 1) * 8, st);
   } else {
     int64_t blocks = (n_rows * G + 255) / 256;
-    if (blocks > kL12MaxBlocks) blocks = kL12MaxBlocks;
+    if (blocks > kL12MaxBlocks) blocks = kL12MaxBlocks;      // all resident at 4 waves per SIMD; 1 280 - 2 048 blocks measured slower (32 - 36 us vs 31)
     l12_launch<true, false>(a, F, Nf, G, (unsigned)blocks, 0, st);
   }
   return check_launch("layer12_bwd");
