@@ -169,11 +169,17 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
     double S[2][CS ? CS : 1];
 #pragma unroll
     for (int c = 0; c < (CS ? CS : 1); ++c) S[0][c] = S[1][c] = 0.0;
-    // NB entries per lane and trip (one-lane rows are the sparse regime: two): their stream bytes are requested together, then their rows together — two
-    // dependent round trips per NB entries instead of two per entry.  Positions past the row's end are clamped to its
-    // last entry and skipped afterwards: every load is unconditional (a load under a per-lane condition becomes a
-    // branch with a full wait).
-    constexpr int NB = G == 1 ? 2 : 8;               // (S2, G = 4: 8 at a time 39.6 us, 4 at a time 43.3, one at a time with G = 16 60.1)
+    // NB entries per lane and trip (one-lane rows are the sparse regime: two), strided over the lanes of the row: their
+    // stream bytes are requested together, then their rows together — two dependent round trips per NB entries instead of
+    // two per entry.  Positions past the row's end are clamped to its last entry and skipped afterwards: every load is
+    // unconditional (a load under a per-lane condition becomes a branch with a full wait).  (NB CONSECUTIVE entries per
+    // lane as one 16-byte load — what the layer kernels do — was measured here too: 40.2 instead of 37.5 us on S2; the
+    // entries of a row are ordered by edge, so the lanes of a row gather neighbouring input rows when they take
+    // neighbouring entries, and that coalescing is worth more than the saved load instructions.)
+    // The per-entry terms of a trip are summed in fp32 (at most NB of them, each bounded by the class weight) and join the
+    // fp64 row sums once per trip: the fp64 adds and conversions per entry were a fifth of the kernel's ≈ 100 vector
+    // instructions per entry (rocprofv3 SQ counters: half of its time was VALU).
+    constexpr int NB = G == 1 ? 2 : 8;               // (S2, G = 4: 8 at a time 39.6 us, 4 at a time 43.3, one at a time with G = 16 60.1, two at a time with G = 16 55.2)
     for (int pb = cur.y + gl; pb < cur.z; pb += NB * G) {
       int mb[NB], ob[NB];
 #pragma unroll
@@ -186,6 +192,9 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
       float xb[NB][NIN];
 #pragma unroll
       for (int u = 0; u < NB; ++u) load_in<NIN>(a.Z, ob[u], xb[u]);
+      float Sp[2][CS ? CS : 1], nump = 0.f;
+#pragma unroll
+      for (int c = 0; c < (CS ? CS : 1); ++c) Sp[0][c] = Sp[1][c] = 0.f;
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
       const int p = pb + u * G;
@@ -228,12 +237,14 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
         const float inv = __builtin_amdgcn_rcpf(s);            // 1 ulp
 #pragma unroll
         for (int c = 0; c < CS; ++c) {
-          const double g = valid ? (double)(wt * (ex[c] * inv - (c == t ? 1.f : 0.f))) : 0.0;
-          if (role) S[1][c] += g; else S[0][c] += g;
+          const float g = valid ? wt * (ex[c] * inv - (c == t ? 1.f : 0.f)) : 0.f;   // an ignored entry adds an exact 0, whatever its logits
+          Sp[0][c] += role ? 0.f : g;
+          Sp[1][c] += role ? g : 0.f;
         }
       }
       if (!role) {
-        if (valid) num += (double)(wt * ((mx - zt_t) + __logf(s)));
+        // s is in [1, C]: the hardware log2 needs no denormal handling there (1 ulp)
+        nump += valid ? wt * ((mx - zt_t) + __builtin_amdgcn_logf(s) * 0.693147180559945309f) : 0.f;
         if (a.logits) {
           float* o = a.logits + (int64_t)(a.ent[p] >> 1) * CT;
           if constexpr (CT == 2) {
@@ -246,6 +257,14 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
           }
         }
       }
+      }
+      num += (double)nump;
+      if constexpr (GRAD) {
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+          S[0][c] += (double)Sp[0][c];
+          S[1][c] += (double)Sp[1][c];
+        }
       }
     }
     if constexpr (GRAD) {
