@@ -79,6 +79,21 @@ __device__ __forceinline__ void load_entries(const int32_t* col, const float* va
   }
 }
 
+// The same for entries STRIDED over the G lanes of a row (lane gl takes t0 + gl + u·G): element loads, clamped to the row's
+// last entry.  Neighbouring lanes then hold neighbouring entries, whose columns — sorted inside a row — are close: the
+// gathers of a group fall into few cache lines.  Used by the unstaged kernels when a row has several lanes (the staged ones
+// gather from LDS, one-lane rows have no neighbours): backward at 16 / 8 / 40 non-zeros per row of 8 000 / 7 301 / 20 000 nodes
+// 97 / 54 / 268 us against 108 / 57 / 302 with consecutive entries per lane (rocprofv3 kernel stats, tools/l12_shape_profile.py).
+template <int NB, int G>
+__device__ __forceinline__ void load_entries_strided(const int32_t* col, const float* val, int64_t first, int64_t end, int (&c)[NB], float (&v)[NB]) {
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int64_t q = first + u * G < end ? first + u * G : end - 1;
+    c[u] = col[q];
+    v[u] = val[q];
+  }
+}
+
 // y[f] = act1(Σ_k h[k]·W1[k][f]) — gemm_small's chain (k ascending from 0), so the same bits
 template <int KI, int F>
 __device__ __forceinline__ void layer1_row(const float (&h)[KI], const float (&W1)[KI][F], const ActApply& act1, float (&y)[F]) {
@@ -152,10 +167,13 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
     // the arithmetic.
     constexpr int NB = STAGED ? 8 : 4;
     for (int64_t t0 = beg; t0 < end; t0 += NB * G) {
-      const int64_t base = t0 + gl * NB;
+      constexpr bool STRIDED = !STAGED && G > 1;
+      constexpr int STEP = STRIDED ? G : 1;                   // entry of slot u: base + u·STEP
+      const int64_t base = STRIDED ? t0 + gl : t0 + gl * NB;
       float v[NB];
       int c[NB];
-      load_entries<NB>(a.col, a.val, base, nnz, c, v);
+      if constexpr (STRIDED) load_entries_strided<NB, G>(a.col, a.val, base, end, c, v);
+      else load_entries<NB>(a.col, a.val, base, nnz, c, v);
       if constexpr (STAGED) {
         float y[NB][F];
 #pragma unroll
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
           }
 #pragma unroll
         for (int u = 0; u < NB; ++u)
-          if (base + u < end) {
+          if (base + u * STEP < end) {
 #pragma unroll
             for (int f = 0; f < F; ++f) acc[f] = fmaf(v[u], y[u][f], acc[f]);
           }
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
         for (int u = 0; u < NB; ++u) hv[u] = *reinterpret_cast<const float2*>(a.H + (xoff + c[u]) * KI);
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-          if (base + u < end) {                                    // positions past the row's end: no layer-1 work for them
+          if (base + u * STEP < end) {                                    // positions past the row's end: no layer-1 work for them
             const float h[KI] = {hv[u].x, hv[u].y};
             float y[F];
             layer1_row<KI, F>(h, W1, act1, y);
@@ -281,10 +299,13 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
     for (int n = 0; n < NT; ++n) t[n] = 0.f;
     constexpr int NB = STAGED ? 8 : 4;                       // NB consecutive non-zeros per lane and trip (see the forward kernel)
     for (int64_t t0 = beg; t0 < end; t0 += NB * G) {
-      const int64_t base = t0 + gl * NB;
+      constexpr bool STRIDED = !STAGED && G > 1;
+      constexpr int STEP = STRIDED ? G : 1;                   // entry of slot u: base + u·STEP
+      const int64_t base = STRIDED ? t0 + gl : t0 + gl * NB;
       float v[NB];
       int c[NB];
-      load_entries<NB>(a.col, a.val, base, nnz, c, v);
+      if constexpr (STRIDED) load_entries_strided<NB, G>(a.col, a.val, base, end, c, v);
+      else load_entries<NB>(a.col, a.val, base, nnz, c, v);
       float g[NB][NT];
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
@@ -311,7 +332,7 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u)
-        if (base + u < end) {
+        if (base + u * STEP < end) {
 #pragma unroll
           for (int n = 0; n < NT; ++n) t[n] = fmaf(v[u], g[u][n], t[n]);
         }
