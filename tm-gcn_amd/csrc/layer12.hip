@@ -228,6 +228,117 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
   }
 }
 
+// ---- entry-major forward (sparse, possibly skewed rows: the unstaged one-lane-per-row regime) --------------------------
+// A block owns 256 consecutive rows; their non-zeros are ONE contiguous range of col / val.  The block walks that range
+// entry by entry — thread t takes entries t, t + 256, … of a tile of kEmTile — gathers each entry's H row, applies layer 1
+// and parks (val, y[F]) in LDS; then thread t adds up the entries of ITS row from LDS, in entry order (the fmaf chain of
+// the one-lane-per-row kernel: the same bits).  Against one lane per row:
+//   * three dependent round trips per block whatever the rows look like (row pointers; col / val, coalesced; H rows),
+//     instead of two per trip of four non-zeros of the longest row of a wavefront — the reference's chess data has
+//     3.97 non-zeros per row and 14.9 in the longest of 64 neighbours: 57 us for a forward that took 22 on the synthetic
+//     shape of the same size;
+//   * the layer-1 arithmetic is spread evenly over the lanes (per entry, not per row slot).
+// Tiles of a block follow each other with the next tile's (col, val) already in flight.  Captured steps, kernel durations
+// under rocprofv3: chess 57 -> 37.6 us, the synthetic Bitcoin-OTC shape 21.7 -> 18.2.
+// Rows of two slices may share a block (N >= 256: at most one boundary): an entry's H row is found by comparing its
+// position with the first entry of the second slice.
+constexpr int kEmTile = 1024;      // 512: chess 56.6 us, 2 048: the synthetic shape 26.7 (two blocks per CU)
+
+template <int KI, int F, int NT>
+__global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
+  static_assert(KI == 2, "H rows are float2");
+  __shared__ int64_t rp[257];
+  __shared__ float park[1 + F][kEmTile];             // val, y[0..F): one plane each (neighbouring lanes, neighbouring banks)
+  float W1[KI][F], W2[F][NT];
+#pragma unroll
+  for (int k = 0; k < KI; ++k)
+#pragma unroll
+    for (int f = 0; f < F; ++f) W1[k][f] = a.W1[k * F + f];
+#pragma unroll
+  for (int f = 0; f < F; ++f)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) W2[f][n] = a.W2[f * NT + n];
+  const ActApply act1(a.act1), act2(a.act2);
+  const int t = threadIdx.x;
+  const int64_t first = (int64_t)blockIdx.x * 256;
+  const int64_t r = first + t;
+  const int rows = a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256;
+  {
+    const int64_t q = first + (t < rows ? t : rows);
+    rp[t] = a.rowptr[q];
+    if (t == 0) rp[256] = a.rowptr[first + rows];
+  }
+  __syncthreads();
+  const int64_t base = rp[0];
+  const int n_ent = (int)(rp[rows < 256 ? rows : 256] - base);
+  // the slice boundary inside the block, as an entry position
+  const int64_t slice0 = first / a.N;
+  const int64_t next_first = (slice0 + 1) * a.N;                                  // first row of the next slice
+  const int split = next_first - first < rows ? (int)(rp[next_first - first] - base) : n_ent;
+  const int64_t xoff0 = slice0 * a.N;
+  const int my_lo = (int)(rp[t < rows ? t : rows] - base), my_hi = (int)(rp[t < rows ? t + 1 : rows] - base);
+  float acc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = 0.f;
+  constexpr int PER = kEmTile / 256;
+  int c[PER], c_next[PER];
+  float v[PER], v_next[PER];
+  auto load_cv = [&](int tile, int (&cc)[PER], float (&vv)[PER]) {   // clamped, unconditional loads: coalesced along the entry range
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tile + u * 256 + t;
+      const int64_t q = base + (e < n_ent ? e : (n_ent > 0 ? n_ent - 1 : 0));
+      cc[u] = a.col[q];
+      vv[u] = a.val[q];
+    }
+  };
+  if (n_ent > 0) load_cv(0, c, v);
+  for (int tile = 0; tile < n_ent; tile += kEmTile) {
+    float2 hv[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tile + u * 256 + t;
+      hv[u] = *reinterpret_cast<const float2*>(a.H + ((e < split ? xoff0 : xoff0 + a.N) + c[u]) * KI);
+    }
+    if (tile + kEmTile < n_ent) load_cv(tile + kEmTile, c_next, v_next);      // the next tile's stream, behind this tile's gathers
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = tile + u * 256 + t;
+      if (e < n_ent) {
+        const float h[KI] = {hv[u].x, hv[u].y};
+        float y[F];
+        layer1_row<KI, F>(h, W1, act1, y);
+        park[0][u * 256 + t] = v[u];
+#pragma unroll
+        for (int f = 0; f < F; ++f) park[1 + f][u * 256 + t] = y[f];
+      }
+    }
+    __syncthreads();
+    const int lo = my_lo > tile ? my_lo : tile, hi = my_hi < tile + kEmTile ? my_hi : tile + kEmTile;
+    for (int e = lo; e < hi; ++e) {
+      const float w = park[0][e - tile];
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[f] = fmaf(w, park[1 + f][e - tile], acc[f]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) c[u] = c_next[u], v[u] = v_next[u];
+  }
+  if (t >= rows) return;
+  if (a.AX) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) a.AX[r * F + f] = acc[f];
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) s2 = fmaf(acc[f], W2[f][n], s2);
+    if (a.pre2_out) a.pre2_out[r * NT + n] = s2;
+    a.Z[r * NT + n] = act2(s2);
+  }
+}
+
 // Backward.  Groups of G lanes walk rows r = group, group + n_groups, …; the KI·F fp64 accumulators of dW1 are dealt
 // over the lanes of a group (lane gl owns q = gl + j·G).
 constexpr int kL12MaxBlocks = 1024;
@@ -442,6 +553,23 @@ static void l12_launch_g(const L12Args& a, int G, unsigned blocks, size_t lds, h
 #undef TMGCN_L12
 }
 
+template <int F>
+static void l12_em_launch_n(const L12Args& a, int NT, unsigned blocks, hipStream_t st) {
+  switch (NT) {
+    case 2: hipLaunchKernelGGL((l12_fwd_em_kernel<2, F, 2>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((l12_fwd_em_kernel<2, F, 4>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((l12_fwd_em_kernel<2, F, 6>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((l12_fwd_em_kernel<2, F, 8>), dim3(blocks), dim3(256), 0, st, a);
+  }
+}
+static void l12_em_launch(const L12Args& a, int F, int NT, unsigned blocks, hipStream_t st) {
+  switch (F) {
+    case 2: l12_em_launch_n<2>(a, NT, blocks, st); break;
+    case 4: l12_em_launch_n<4>(a, NT, blocks, st); break;
+    default: l12_em_launch_n<6>(a, NT, blocks, st);
+  }
+}
+
 template <bool BWD, bool STAGED>
 static void l12_launch(const L12Args& a, int F, int NT, int G, unsigned blocks, size_t lds, hipStream_t st) {
 #define TMGCN_L12_N(F_)                                                             \
@@ -486,6 +614,8 @@ extern "C" int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, 
     a.chunks = l12_chunks(n_rows / N, N);
     a.chunk_rows = (N + a.chunks - 1) / a.chunks;
     l12_launch<false, true>(a, F, Nf, G, (unsigned)(n_rows / N * a.chunks), (size_t)N * F * 4 + (a.chunk_rows + 1) * 8, (hipStream_t)stream);
+  } else if (G == 1 && N >= 256 && F <= 6) {
+    l12_em_launch(a, F, Nf, (unsigned)((n_rows + 255) / 256), (hipStream_t)stream);       // entry-major: see l12_fwd_em_kernel
   } else {
     l12_launch<false, false>(a, F, Nf, G, (unsigned)((n_rows * G + 255) / 256), 0, (hipStream_t)stream);
   }
