@@ -339,6 +339,47 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
   }
 }
 
+// The end of a backward block: its dW1 partial sums (NO values, dealt over the G lanes of a row group: lane gl owns
+// q = gl + j·G) folded over the block in a fixed order, stored write-through as the block's slab; the block that draws the
+// last ticket adds all slabs in order and writes dW1.
+template <int NO, int G>
+__device__ __forceinline__ void l12_bwd_finish(const double (&acc)[(NO + G - 1) / G], const L12Args& a) {
+  constexpr int NPL = (NO + G - 1) / G;
+  __shared__ double red[4][NO];
+  __shared__ int is_last;
+  const int gl = threadIdx.x & (G - 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    double v = acc[j];
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) v += __shfl_xor(v, o);
+    const int q = gl + j * G;
+    if (lane < G && q < NO) red[wave][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NO)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(a.part) + (int64_t)blockIdx.x * NO + threadIdx.x,
+                       __float_as_uint((float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x])),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!last_block_ticket(a.sync, (int)gridDim.x, &is_last)) return;
+  if (threadIdx.x == 0) *a.sync = 0;
+  // the last block: 256 / NO threads per output, each adding its share of the slabs in order (slab_sum_f32)
+  constexpr int SUBS = 256 / NO;
+  __shared__ double fin[SUBS][NO];
+  const unsigned* P = reinterpret_cast<const unsigned*>(a.part);
+  const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
+  const int nb = (int)gridDim.x;
+  if (sub < SUBS) fin[sub][o] = slab_sum_f32<kFinisherDepth>(P, nb, sub, SUBS, NO, o);
+  __syncthreads();
+  if (threadIdx.x < NO) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < SUBS; ++q) tot += fin[q][threadIdx.x];
+    a.dW1[threadIdx.x] = (float)tot;
+  }
+}
+
 // Backward.  Groups of G lanes walk rows r = group, group + n_groups, …; the KI·F fp64 accumulators of dW1 are dealt
 // over the lanes of a group (lane gl owns q = gl + j·G).
 constexpr int kL12MaxBlocks = 1024;
@@ -347,8 +388,6 @@ template <int KI, int F, int NT, int G, bool STAGED, bool ACT2>
 __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
   constexpr int NO = KI * F;
   constexpr int NPL = (NO + G - 1) / G;
-  __shared__ double red[4][NO];
-  __shared__ int is_last;
   float W1[KI][F], W2[F][NT];
 #pragma unroll
   for (int k = 0; k < KI; ++k)
@@ -475,36 +514,128 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
       }
     }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  l12_bwd_finish<NO, G>(acc, a);
+}
+
+// ---- entry-major backward (the counterpart of l12_fwd_em_kernel, on the transposed CSR) ---------------------------------
+// Persistent blocks take row blocks rb = blockIdx, blockIdx + gridDim, …; a row block's entries are walked tile by tile —
+// each entry's dZ row (⊙ act2'(pre2) when layer 2 has an activation) parked in LDS with its value —, thread t sums ITS
+// row in entry order (the one-lane-per-row chain: the same bits), finishes the row (·W2ᵀ, act1', H[r]ᵀ·dP into its fp64
+// dW1 partial sums) and the block ends like every backward block (l12_bwd_finish).
+template <int KI, int F, int NT, bool ACT2>
+__global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
+  constexpr int NO = KI * F;
+  __shared__ int64_t rp[257];
+  __shared__ float park[1 + NT][kEmTile];            // val, g[0..NT)
+  float W1[KI][F], W2[F][NT];
 #pragma unroll
-  for (int j = 0; j < NPL; ++j) {
-    double v = acc[j];
+  for (int k = 0; k < KI; ++k)
 #pragma unroll
-    for (int o = 32; o >= G; o >>= 1) v += __shfl_xor(v, o);
-    const int q = gl + j * G;
-    if (lane < G && q < NO) red[wave][q] = v;
+    for (int f = 0; f < F; ++f) W1[k][f] = a.W1[k * F + f];
+#pragma unroll
+  for (int f = 0; f < F; ++f)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) W2[f][n] = a.W2[f * NT + n];
+  const ActGrad dact1(a.act1), dact2(a.act2);
+  const int t = threadIdx.x;
+  double acc[NO];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) acc[j] = 0.0;
+  constexpr int PER = kEmTile / 256;
+  const int64_t n_row_blocks = (a.n_rows + 255) / 256;
+  for (int64_t rb = blockIdx.x; rb < n_row_blocks; rb += gridDim.x) {
+    const int64_t first = rb * 256;
+    const int64_t r = first + t;
+    const int rows = a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256;
+    __syncthreads();                                  // the previous row block's readers of rp are done
+    rp[t] = a.rowptr[first + (t < rows ? t : rows)];
+    if (t == 0) rp[256] = a.rowptr[first + rows];
+    const float2 hv = *reinterpret_cast<const float2*>(a.H + (t < rows ? r : first) * KI);   // this row's H, early
+    __syncthreads();
+    const int64_t base = rp[0];
+    const int n_ent = (int)(rp[rows] - base);
+    const int64_t slice0 = first / a.N;
+    const int64_t next_first = (slice0 + 1) * a.N;
+    const int split = next_first - first < rows ? (int)(rp[next_first - first] - base) : n_ent;
+    const int64_t xoff0 = slice0 * a.N;
+    const int my_lo = (int)(rp[t < rows ? t : rows] - base), my_hi = (int)(rp[t < rows ? t + 1 : rows] - base);
+    float ts[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) ts[n] = 0.f;
+    int c[PER], c_next[PER];
+    float v[PER], v_next[PER];
+    auto load_cv = [&](int tile, int (&cc)[PER], float (&vv)[PER]) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int e = tile + u * 256 + t;
+        const int64_t q = base + (e < n_ent ? e : (n_ent > 0 ? n_ent - 1 : 0));
+        cc[u] = a.col[q];
+        vv[u] = a.val[q];
+      }
+    };
+    if (n_ent > 0) load_cv(0, c, v);
+    for (int tile = 0; tile < n_ent; tile += kEmTile) {
+      float g[PER][NT];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int e = tile + u * 256 + t;
+        const int64_t row = (e < split ? xoff0 : xoff0 + a.N) + c[u];
+        const float2* gz = reinterpret_cast<const float2*>(a.dZ + row * NT);
+#pragma unroll
+        for (int i = 0; i < NT / 2; ++i) {
+          const float2 q = gz[i];
+          g[u][2 * i] = q.x;
+          g[u][2 * i + 1] = q.y;
+        }
+        if constexpr (ACT2) {
+          const float2* pz = reinterpret_cast<const float2*>(a.pre2 + row * NT);
+#pragma unroll
+          for (int i = 0; i < NT / 2; ++i) {
+            const float2 q = pz[i];
+            g[u][2 * i] *= dact2(q.x);
+            g[u][2 * i + 1] *= dact2(q.y);
+          }
+        }
+      }
+      if (tile + kEmTile < n_ent) load_cv(tile + kEmTile, c_next, v_next);
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int e = tile + u * 256 + t;
+        if (e < n_ent) {
+          park[0][u * 256 + t] = v[u];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) park[1 + n][u * 256 + t] = g[u][n];
+        }
+      }
+      __syncthreads();
+      const int lo = my_lo > tile ? my_lo : tile, hi = my_hi < tile + kEmTile ? my_hi : tile + kEmTile;
+      for (int e = lo; e < hi; ++e) {
+        const float w = park[0][e - tile];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) ts[n] = fmaf(w, park[1 + n][e - tile], ts[n]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < PER; ++u) c[u] = c_next[u], v[u] = v_next[u];
+    }
+    if (t < rows) {
+      // dY = t·W2ᵀ, P = H·W1, dP = dY ⊙ act1'(P): as l12_bwd_kernel
+      const float h[KI] = {hv.x, hv.y};
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        float sy = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) sy = fmaf(ts[n], W2[f][n], sy);
+        float pf = 0.f;
+#pragma unroll
+        for (int k = 0; k < KI; ++k) pf = fmaf(h[k], W1[k][f], pf);
+        const float dP = sy * dact1(pf);
+#pragma unroll
+        for (int k = 0; k < KI; ++k) acc[k * F + f] = fma((double)h[k], (double)dP, acc[k * F + f]);
+      }
+    }
   }
-  __syncthreads();
-  if (threadIdx.x < NO)
-    __hip_atomic_store(reinterpret_cast<unsigned*>(a.part) + (int64_t)blockIdx.x * NO + threadIdx.x,
-                       __float_as_uint((float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x])),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (!last_block_ticket(a.sync, (int)gridDim.x, &is_last)) return;
-  if (threadIdx.x == 0) *a.sync = 0;
-  // the last block: 256 / NO threads per output, each adding its share of the slabs in order (slab_sum_f32)
-  constexpr int SUBS = 256 / NO;
-  __shared__ double fin[SUBS][NO];
-  const unsigned* P = reinterpret_cast<const unsigned*>(a.part);
-  const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
-  const int nb = (int)gridDim.x;
-  if (sub < SUBS) fin[sub][o] = slab_sum_f32<kFinisherDepth>(P, nb, sub, SUBS, NO, o);
-  __syncthreads();
-  if (threadIdx.x < NO) {
-    double tot = 0.0;
-#pragma unroll
-    for (int q = 0; q < SUBS; ++q) tot += fin[q][threadIdx.x];
-    a.dW1[threadIdx.x] = (float)tot;
-  }
+  l12_bwd_finish<NO, 1>(acc, a);
 }
 
 // lanes per row: chains of about four non-zeros per lane, walked NB at a time (kernel durations under rocprofv3, captured
@@ -568,6 +699,24 @@ static void l12_em_launch(const L12Args& a, int F, int NT, unsigned blocks, hipS
     case 4: l12_em_launch_n<4>(a, NT, blocks, st); break;
     default: l12_em_launch_n<6>(a, NT, blocks, st);
   }
+}
+
+template <int F, bool ACT2>
+static void l12_bwd_em_launch_n(const L12Args& a, int NT, unsigned blocks, hipStream_t st) {
+  switch (NT) {
+    case 2: hipLaunchKernelGGL((l12_bwd_em_kernel<2, F, 2, ACT2>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((l12_bwd_em_kernel<2, F, 4, ACT2>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((l12_bwd_em_kernel<2, F, 6, ACT2>), dim3(blocks), dim3(256), 0, st, a);
+  }
+}
+static void l12_bwd_em_launch(const L12Args& a, int F, int NT, unsigned blocks, hipStream_t st) {
+#define TMGCN_EM_B(F_) (a.pre2 ? l12_bwd_em_launch_n<F_, true>(a, NT, blocks, st) : l12_bwd_em_launch_n<F_, false>(a, NT, blocks, st))
+  switch (F) {
+    case 2: TMGCN_EM_B(2); break;
+    case 4: TMGCN_EM_B(4); break;
+    default: TMGCN_EM_B(6);
+  }
+#undef TMGCN_EM_B
 }
 
 template <bool BWD, bool STAGED>
@@ -662,6 +811,12 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
     a.chunks = l12_chunks(n_rows / N, N);
     a.chunk_rows = (N + a.chunks - 1) / a.chunks;
     l12_launch<true, true>(a, F, Nf, G, (unsigned)(n_rows / N * a.chunks), (size_t)N * Nf * 4 + (a.chunk_rows + 1) * 8, st);
+  } else if (G == 1 && N >= 256 && F <= 6 && Nf <= 6) {
+    // entry-major (l12_bwd_em_kernel).  Captured steps, kernel durations under rocprofv3: the synthetic Bitcoin-OTC shape
+    // 31.1 -> 27.9 us; the chess data 60 -> 62 (no gain there: 512 / 1 024 / 1 536 / 4 096 blocks 79.8 / 65.7 / 58.8 / 59.5)
+    int64_t blocks = (n_rows + 255) / 256;
+    if (blocks > kL12MaxBlocks) blocks = kL12MaxBlocks;
+    l12_bwd_em_launch(a, F, Nf, (unsigned)blocks, st);
   } else {
     int64_t blocks = (n_rows * G + 255) / 256;
     if (blocks > kL12MaxBlocks) blocks = kL12MaxBlocks;      // all resident at 4 waves per SIMD; 1 280 - 2 048 blocks measured slower (32 - 36 us vs 31)
