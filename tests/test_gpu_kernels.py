@@ -606,6 +606,40 @@ def test_weighted_cross_entropy_matches_torch_fp64(E, C):
         WeightedCrossEntropy(torch.ones(9))(torch.randn(4, 9, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV))
 
 
+@pytest.mark.parametrize("act2", [None, "selu"])
+def test_layer12_entry_major_kernels_on_skewed_rows(act2):
+    """The entry-major layer kernels (sparse rows: a block walks the contiguous entry range of its 256 rows, tile by
+    tile) where a block's rows hold several tiles of entries and others almost none — 250 hub rows of ~13 entries at
+    the start of every slice of 1 300 nodes, one or two entries elsewhere, a slice boundary inside a block, a ragged
+    last block — against the two-operator route; reproducible."""
+    from tmgcn_amd import adjacency
+    rng = np.random.default_rng(11)
+    T, N = 3, 1300
+    ks, is_, js = [], [], []
+    for t in range(T):
+        hub_i = np.repeat(np.arange(250), 13)
+        ks += [np.full(hub_i.size, t), np.full(N, t)]
+        is_ += [hub_i, np.arange(N)]
+        js += [rng.integers(0, N, hub_i.size), np.arange(N)]
+    k, i, j = np.concatenate(ks), np.concatenate(is_), np.concatenate(js)
+    A = adjacency.DeviceCOO.from_edges(k, i, j, rng.uniform(0.1, 1.0, k.size).astype(np.float32), T, N).sort_reduce().to_csr()
+    assert A.avg_nnz_per_row < 4 and int((A.rowptr[256] - A.rowptr[0])) > 2 * 1024      # one lane per row regime; three tiles
+    g = torch.Generator().manual_seed(9)
+    H = torch.randn(T, N, 2, generator=g).to(DEV)
+    W1, W2 = (torch.randn(2, 6, generator=g) * 0.7).to(DEV), (torch.randn(6, 6, generator=g) * 0.7).to(DEV)
+    dZ = torch.randn(T, N, 6, generator=g).to(DEV)
+    out = []
+    for fuse in (True, False, True):
+        a1, a2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+        Z = ops.layer12(H, a1, "selu", A, a2, act2, fuse=fuse)
+        Z.backward(dZ)
+        out.append((Z.detach(), a1.grad, a2.grad))
+    assert_close(out[0][0], out[1][0], 2e-6, "Z")
+    assert_close(out[0][1], out[1][1], 2e-6, "dW1")
+    assert_close(out[0][2], out[1][2], 2e-6, "dW2")
+    assert all(torch.equal(x, y) for x, y in zip(out[0], out[2]))
+
+
 @pytest.mark.parametrize("act1,act2", [("selu", None), ("relu", None), ("leaky", "relu"), (None, "selu")])
 @pytest.mark.parametrize("T,N,deg,F,Nf", [(5, 300, 3.0, 6, 6), (3, 77, 12.0, 6, 2), (4, 500, 0.4, 2, 6), (2, 64, 40.0, 8, 4),
                                           # staged variants (slice in LDS): several blocks per slice with a ragged last
