@@ -17,6 +17,12 @@
 // slice (forward), dZ ⊙ act2'(pre2) of every node (backward) — in LDS, once per node instead of once per non-zero,
 // and then gathers from LDS: 24-byte rows at random addresses cost an L1 tag look-up per lane and instruction through
 // the vector memory path (measured 6.5 clocks per non-zero per CU) and a fraction of that from LDS.
+// Three walks of the rows, chosen per call from the shape (tmgcn_layer12_fwd_f32 / _bwd_f32):
+//   entry-major   sparse rows (< 4 non-zeros per row on average, N >= 256): a block walks the contiguous entry range of
+//                 its 256 rows tile by tile and sums each row from LDS (l12_fwd_em_kernel, l12_bwd_em_kernel) — three
+//                 dependent round trips per block whatever the row lengths; the Bitcoin-OTC shape and real, skewed data;
+//   staged        small dense slices (above);
+//   lanes per row everything else: G = 1 … 16 lanes per row, entries strided over them (l12_fwd_kernel, l12_bwd_kernel).
 // dW2 = (Â⋆Y)ᵀ·dZ stays the narrow dW kernel (gemm.hip) on the Â⋆Y the forward stores for it (folding its 36 sums into
 // the backward kernel as well was measured: 72 us instead of 37 + 13 — 48 fp64 accumulators per lane; not kept).
 #include "common.h"
