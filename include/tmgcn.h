@@ -213,8 +213,9 @@ int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, const float
                           const float* W1, int32_t act1, const float* W2, int32_t act2, int64_t n_rows,
                           int32_t N, int32_t K0, int32_t F, int32_t Nf, float* Z, float* AX, float* pre2,
                           float avg_nnz_per_row, void* stream);
-/* 1 when the fused forward is the faster route for the shape (short rows, or small dense slices whose layer-1 output is
- * formed once per node in LDS); 0: form act1(H·W1) with tmgcn_gemm_f32 and call tmgcn_spmm_gemm_f32 (same Z up to fp32 summation order). */
+/* 1 when the fused forward is the faster route for the shape (slices of >= 256 nodes: the entry-major kernel; small dense
+ * slices whose layer-1 output is formed once per node in LDS; short rows); 0: form act1(H·W1) with tmgcn_gemm_f32 and call
+ * tmgcn_spmm_gemm_f32 (same Z up to fp32 summation order). */
 int tmgcn_layer12_fwd_pays(int64_t n_rows, int32_t N, int32_t F, float avg_nnz_per_row);
 int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F);
 int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const float* dZ,

@@ -18,9 +18,10 @@
 // and then gathers from LDS: 24-byte rows at random addresses cost an L1 tag look-up per lane and instruction through
 // the vector memory path (measured 6.5 clocks per non-zero per CU) and a fraction of that from LDS.
 // Three walks of the rows, chosen per call from the shape (tmgcn_layer12_fwd_f32 / _bwd_f32):
-//   entry-major   sparse rows (< 4 non-zeros per row on average, N >= 256): a block walks the contiguous entry range of
-//                 its 256 rows tile by tile and sums each row from LDS (l12_fwd_em_kernel, l12_bwd_em_kernel) — three
-//                 dependent round trips per block whatever the row lengths; the Bitcoin-OTC shape and real, skewed data;
+//   entry-major   slices of >= 256 nodes that the staged variants do not take — the forward at every density, the backward
+//                 for sparse rows (< 4 non-zeros per row on average): a block walks the contiguous entry range of its 256
+//                 rows tile by tile and sums each row from LDS (l12_fwd_em_kernel, l12_bwd_em_kernel) — three dependent
+//                 round trips per block whatever the row lengths; the Bitcoin-OTC shape and real, skewed data;
 //   staged        small dense slices (above);
 //   lanes per row everything else: G = 1 … 16 lanes per row, entries strided over them (l12_fwd_kernel, l12_bwd_kernel).
 // dW2 = (Â⋆Y)ᵀ·dZ stays the narrow dW kernel (gemm.hip) on the Â⋆Y the forward stores for it (folding its 36 sums into
@@ -703,7 +704,8 @@ static void l12_em_launch(const L12Args& a, int F, int NT, unsigned blocks, hipS
   switch (F) {
     case 2: l12_em_launch_n<2>(a, NT, blocks, st); break;
     case 4: l12_em_launch_n<4>(a, NT, blocks, st); break;
-    default: l12_em_launch_n<6>(a, NT, blocks, st);
+    case 6: l12_em_launch_n<6>(a, NT, blocks, st); break;
+    default: l12_em_launch_n<8>(a, NT, blocks, st);
   }
 }
 
@@ -769,7 +771,7 @@ extern "C" int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, 
     a.chunks = l12_chunks(n_rows / N, N);
     a.chunk_rows = (N + a.chunks - 1) / a.chunks;
     l12_launch<false, true>(a, F, Nf, G, (unsigned)(n_rows / N * a.chunks), (size_t)N * F * 4 + (a.chunk_rows + 1) * 8, (hipStream_t)stream);
-  } else if (G == 1 && N >= 256 && F <= 6) {
+  } else if (N >= 256) {
     l12_em_launch(a, F, Nf, (unsigned)((n_rows + 255) / 256), (hipStream_t)stream);       // entry-major: see l12_fwd_em_kernel
   } else {
     l12_launch<false, false>(a, F, Nf, G, (unsigned)((n_rows * G + 255) / 256), 0, (hipStream_t)stream);
@@ -777,12 +779,14 @@ extern "C" int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, 
   return check_launch("layer12_fwd");
 }
 
-// 1 when the fused forward is the faster route for this shape: short rows (layer 1 re-applied per gathered row is cheap
-// then), or a shape the staged variant takes (layer 1 once per node); otherwise the caller forms act1(H·W1) itself and
-// calls tmgcn_spmm_gemm_f32 (the same Z up to the fp32 summation order of a row).
+// 1 when the fused forward is the faster route for this shape: slices of at least 256 nodes (the entry-major kernel:
+// layer 1 is applied per ENTRY, evenly over the lanes — 5 / 8 / 16 / 40 non-zeros per row of 8 000 - 20 000 nodes: 24.6 / 33.8 /
+// 59.2 / 195.7 us against 46.4 fused with two lanes per row and 50.1 / 72.1 / 234 for the GEMM + fused SpMM pair), a shape
+// the staged variant takes (layer 1 once per node), or short rows; otherwise the caller forms act1(H·W1) itself and calls
+// tmgcn_spmm_gemm_f32 (the same Z up to the fp32 summation order of a row).
 extern "C" int tmgcn_layer12_fwd_pays(int64_t n_rows, int32_t N, int32_t F, float avg_nnz_per_row) {
   if (N <= 0 || n_rows <= 0) return 0;
-  return ((avg_nnz_per_row >= 0.f && avg_nnz_per_row <= 6.f) || l12_staged(n_rows, N, F, avg_nnz_per_row)) ? 1 : 0;
+  return (N >= 256 || (avg_nnz_per_row >= 0.f && avg_nnz_per_row <= 6.f) || l12_staged(n_rows, N, F, avg_nnz_per_row)) ? 1 : 0;
 }
 
 extern "C" int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F) {

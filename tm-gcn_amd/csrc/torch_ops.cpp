@@ -790,10 +790,11 @@ struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
     Tensor AX = need2 ? at::empty({H.size(0), H.size(1), F}, H.options()) : Tensor();
     Tensor pre2 = ((need1 || need2) && act2 != TMGCN_ACT_NONE) ? at::empty_like(Z) : Tensor();
     // The fused forward re-applies W1 and the non-linearity to every GATHERED row: per non-zero, not per row.  That
-    // pays while rows are short (3 non-zeros per row at the Bitcoin-OTC shape: 35 vs 41 us) and when a slice is small
-    // enough for the staged variant, which forms the layer-1 output once per node in LDS (AMLSim shape); otherwise
-    // forming the layer-1 output with the GEMM is cheaper — the same Z to fp32 summation order (tmgcn_layer12_fwd_pays), and the
-    // fused BACKWARD (which recomputes per row) is used in every case, so no pre-activation is kept.
+    // pays in the entry-major kernel (slices of >= 256 nodes: the work is spread per entry), when a slice is small enough
+    // for the staged variant (layer-1 output formed once per node in LDS) and while rows are short; otherwise forming
+    // the layer-1 output with the GEMM is cheaper — the same Z to fp32 summation order (tmgcn_layer12_fwd_pays: the
+    // library's own measurements), and the fused BACKWARD (which recomputes per row) is used in every case, so no
+    // pre-activation is kept.
     if (tmgcn_layer12_fwd_pays(R, (int32_t)N, (int32_t)F, (float)avg)) {
       ok(tmgcn_layer12_fwd_f32((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val), (const float*)ptr(H),
                                (const float*)ptr(W1), (int32_t)act1, (const float*)ptr(W2), (int32_t)act2, R, (int32_t)N,
