@@ -23,13 +23,9 @@ from tmgcn_amd.graphs import GraphedTrainStep  # noqa: E402
 from tmgcn_amd.optim import FusedSGD  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--epochs", type=int, default=200)
-    ap.add_argument("--cpu", type=int, default=0, help="CPU oracle epochs to time (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, nargs="*", default=[8, 32], help="torch thread counts tried for the CPU epoch")
-    ap.add_argument("--only", default=None, help="run only this GPU mode last (for a kernel trace): graph_fused")
-    a = ap.parse_args()
+def run(epochs=200, cpu=0, cpu_threads=(8, 32), only=None):
+    """The record (dict) of one session: see the module docstring.  Also what bench.py's `epochs.chess` holds."""
+    a = argparse.Namespace(epochs=epochs, cpu=cpu, cpu_threads=list(cpu_threads), only=only)
     g = G10()
     k, i, j = g.raw
     t0 = time.perf_counter()
@@ -99,7 +95,18 @@ def main():
             by[th] = round(sorted(ts[1:])[len(ts[1:]) // 2] * 1e3, 1)
         rec["cpu_ms_by_threads"] = by
         rec["cpu_ms"] = min(by.values())
-    print(json.dumps(rec))
+        rec["speedup_best_mode"] = round(rec["cpu_ms"] / min(rec["gpu_ms_graph_fused"], rec["gpu_ms_graph_fused8"]), 1)
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=200)
+    ap.add_argument("--cpu", type=int, default=0, help="CPU oracle epochs to time (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, nargs="*", default=[8, 32], help="torch thread counts tried for the CPU epoch")
+    ap.add_argument("--only", default=None, help="run only this GPU mode last (for a kernel trace): graph_fused")
+    a = ap.parse_args()
+    print(json.dumps(run(a.epochs, a.cpu, a.cpu_threads, a.only)))
 
 
 if __name__ == "__main__":
