@@ -79,3 +79,38 @@ def test_fused_sgd_skips_parameters_without_gradient_and_captures_into_a_graph()
     ref.step()
     for p, q in zip(ps, ref.param_groups[0]["params"]):
         assert_close(p.detach(), q.detach(), 1e-6, "replayed step")
+
+
+def test_fused_sgd_step_hooks_scheduler_and_zero_grad():
+    """FusedSGD.step() skips torch's profiler-range wrapper unless a step hook is registered: hooks fire exactly as on
+    torch.optim.SGD, an LR scheduler drives it, zero_grad() behaves in both modes."""
+    a, b = _params(torch.float32), _params(torch.float32)
+    oa, ob = torch.optim.SGD(a, lr=0.1, momentum=0.9), FusedSGD(b, lr=0.1, momentum=0.9)
+    sa, sb = torch.optim.lr_scheduler.StepLR(oa, step_size=2, gamma=0.5), torch.optim.lr_scheduler.StepLR(ob, step_size=2, gamma=0.5)
+    calls = {"pre": 0, "post": 0}
+    h1 = ob.register_step_pre_hook(lambda opt, args, kwargs: calls.__setitem__("pre", calls["pre"] + 1))
+    h2 = ob.register_step_post_hook(lambda opt, args, kwargs: calls.__setitem__("post", calls["post"] + 1))
+    g = torch.Generator().manual_seed(4)
+    for step in range(5):
+        if step == 3:                       # from here on without hooks: the lean path
+            h1.remove()
+            h2.remove()
+        for p, q in zip(a, b):
+            gr = torch.randn(p.shape, generator=g).cuda()
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+        sa.step()
+        sb.step()
+        assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+        for i, (p, q) in enumerate(zip(a, b)):
+            assert_close(q.detach(), p.detach(), 1e-6, f"step {step} parameter {i}")
+    assert calls == {"pre": 3, "post": 3}
+    ob.zero_grad()
+    assert all(q.grad is None for q in b)
+    for q in b:
+        q.grad = torch.ones_like(q)
+    ob.zero_grad(set_to_none=False)
+    assert all(q.grad is not None and float(q.grad.abs().max()) == 0.0 for q in b)
+    loss = ob.step(closure=lambda: torch.tensor(3.0))
+    assert float(loss) == 3.0

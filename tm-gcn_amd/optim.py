@@ -29,8 +29,29 @@ class FusedSGD(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
                                       nesterov=nesterov, maximize=maximize))
 
-    @torch.no_grad()
+    # torch wraps every optimizer's step() in a profiler range plus a walk over the step hooks, and zero_grad() in another
+    # range: ≈ 35 us of host time per epoch (tools/host_profile_epoch.py), a sixth of an eager epoch of the reference-shaped
+    # configs.  Here step() takes that wrapper only when a step hook is registered (same hook semantics), and zero_grad()
+    # with set_to_none drops the gradients directly.
+    def _patch_step_function(self) -> None:
+        self._zero_grad_profile_name = f"Optimizer.zero_grad#{self.__class__.__name__}.zero_grad"
+
     def step(self, closure=None):
+        from torch.optim import optimizer as _o
+        if (self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _o._global_optimizer_pre_hooks
+                or _o._global_optimizer_post_hooks):
+            return self._hooked_step(closure)
+        return self._step(closure)
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                p.grad = None
+
+    @torch.no_grad()
+    def _step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -58,3 +79,6 @@ class FusedSGD(torch.optim.Optimizer):
                     ops.sgd_step([q.data for q in chunk], grads, bufs, float(group["lr"]), mom, float(group["dampening"]),
                                  float(group["weight_decay"]), bool(group["nesterov"]), bool(group["maximize"]), bool(first))
         return loss
+
+
+FusedSGD._hooked_step = torch.optim.Optimizer.profile_hook_step(FusedSGD._step)
