@@ -105,9 +105,12 @@ class DeviceResult(torch.Tensor):
         # torch.Tensor's own (public) default implementation.
         if getattr(_reentry, "on", False):
             return super().__torch_function__(func, types, args, kwargs)
-        if len(args) == 1 and not kwargs and isinstance(args[0], DeviceResult):
-            # one operand, itself a DeviceResult (loss.backward(), out.detach(), loss.item(), …): nothing to move — the
-            # per-epoch `loss.backward()` skips the argument walk below
+        if len(args) == 1 and isinstance(args[0], DeviceResult) and not any(
+                isinstance(v, (torch.Tensor, list, tuple, dict)) for v in kwargs.values()):
+            # one operand, itself a DeviceResult, and only plain keyword values (loss.backward() arrives as
+            # Tensor.backward(loss, gradient=None, retain_graph=None, create_graph=False, inputs=None); out.detach(),
+            # loss.item(), …): nothing to move — the per-epoch `loss.backward()` skips the argument walk below (three
+            # pytree passes, ≈ 25 us of a 0.3 ms script epoch: tools/host_profile_epoch.py S1 script --callers tree_map)
             return super().__torch_function__(func, types, args, kwargs)
         with _plain_scope():
             if func is F.cross_entropy and len(args) >= 2 and isinstance(args[0], DeviceResult) and args[0].device.type != "cpu":

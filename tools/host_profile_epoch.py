@@ -18,6 +18,7 @@ def main():
     ap.add_argument("mode")
     ap.add_argument("--epochs", type=int, default=300)
     ap.add_argument("--top", type=int, default=45)
+    ap.add_argument("--callers", default=None, help="also print the callers of functions matching this regex")
     a = ap.parse_args()
     import torch
     import bench
@@ -32,7 +33,10 @@ def main():
     pr.disable()
     print(f"# {a.config} {a.mode}: median pass {med * 1e3:.4f} ms/epoch, fastest {best * 1e3:.4f} (under cProfile)")
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(a.top)
+    st = pstats.Stats(pr, stream=s).sort_stats("tottime")
+    st.print_stats(a.top)
+    if a.callers:
+        st.print_callers(a.callers)
     print(s.getvalue())
 
 
