@@ -606,6 +606,32 @@ def test_weighted_cross_entropy_matches_torch_fp64(E, C):
         WeightedCrossEntropy(torch.ones(9))(torch.randn(4, 9, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV))
 
 
+@pytest.mark.parametrize("T,N,nnz", [(1, 300, 0), (3, 256, 0), (1, 300, 5), (2, 256, 700), (3, 257, 900), (1, 256, 768),
+                                     (5, 1024, 15360), (2, 255, 600), (1, 4096, 20000), (9, 513, 4617)])
+def test_layer12_edge_shapes(T, N, nnz):
+    """Shapes at the seams of the row walks of csrc/layer12.hip: empty adjacencies, slices of exactly / just above / just
+    below 256 nodes (the entry-major kernels' block of rows), a single slice, a ragged last block."""
+    from tmgcn_amd import adjacency
+    rng = np.random.default_rng(T * 7919 + N)
+    A = adjacency.DeviceCOO.from_edges(rng.integers(0, T, nnz), rng.integers(0, N, nnz), rng.integers(0, N, nnz),
+                                       rng.uniform(0.1, 1.0, nnz).astype(np.float32), T, N).sort_reduce().to_csr()
+    g = torch.Generator().manual_seed(7)
+    H = torch.randn(T, N, 2, generator=g).to(DEV)
+    W1, W2 = (torch.randn(2, 6, generator=g) * 0.7).to(DEV), (torch.randn(6, 6, generator=g) * 0.7).to(DEV)
+    dZ = torch.randn(T, N, 6, generator=g).to(DEV)
+    outs = []
+    for fuse in (True, False):
+        a1, a2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+        Z = ops.layer12(H, a1, "selu", A, a2, None, fuse=fuse)
+        Z.backward(dZ)
+        outs.append((Z.detach(), a1.grad, a2.grad))
+    for x, y, what in zip(outs[0], outs[1], ("Z", "dW1", "dW2")):
+        if float(y.abs().max()) == 0.0:
+            assert float(x.abs().max()) == 0.0, what
+        else:
+            assert_close(x, y, 2e-6, what)
+
+
 @pytest.mark.parametrize("act2", [None, "selu"])
 def test_layer12_entry_major_kernels_on_skewed_rows(act2):
     """The entry-major layer kernels (sparse rows: a block walks the contiguous entry range of its 256 rows, tile by
