@@ -190,6 +190,52 @@ __device__ __forceinline__ double slab_sum_f32(const unsigned* slabs, int n, int
   return s;
 }
 
+// The hand-off of a slab reduction as a TREE over the two ticket levels of last_block_ticket: the block that draws the last
+// ticket of its group (blocks b ≡ g mod 16) adds the slabs of that group and stores a GROUP slab; the block that draws the
+// last of the sixteen top-level tickets adds the group slabs.  Every reading is one or two round trips whatever the grid
+// (one last block walking 1 024 slabs with 8 loads in flight took 7 round trips, 2 282 slabs 14: why the backward grids
+// were capped at 1 024 blocks), all sums in a fixed order.  Called by every thread of every block after the block's own
+// slab (NO floats, write-through) is stored at part[blockIdx.x]; `part` holds n_blocks + kSyncGroups slabs.  True in the
+// one block that ends up with the totals, in total[0 .. NO) (LDS); that block has also reset the launch's counters.
+template <int NO>
+__device__ __forceinline__ bool slab_tree_finish(unsigned* part, int n_blocks, int32_t* sync, double* total /* LDS [NO] */) {
+  constexpr int SUBS = 256 / NO;
+  __shared__ double tree_fin[SUBS][NO];
+  __shared__ int tree_flag;
+  const int g = blockIdx.x % kSyncGroups;
+  const int members = (n_blocks - g + kSyncGroups - 1) / kSyncGroups;
+  const int groups = n_blocks < kSyncGroups ? n_blocks : kSyncGroups;
+  int32_t* mine = sync + (1 + g) * kSyncStride;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool last = __hip_atomic_fetch_add(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1;
+    if (last) __hip_atomic_store(mine, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tree_flag = last;
+  }
+  __syncthreads();
+  if (!tree_flag) return false;
+  // the group's slabs g, g + 16, …: SUBS threads per output, then the SUBS partial sums in order
+  const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
+  if (sub < SUBS) tree_fin[sub][o] = slab_sum_f32<8>(part + (int64_t)g * NO, members, sub, SUBS, NO * kSyncGroups, o);
+  __syncthreads();
+  if (threadIdx.x < NO) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < SUBS; ++q) t += tree_fin[q][threadIdx.x];
+    __hip_atomic_store(part + (int64_t)(n_blocks + g) * NO + threadIdx.x, __float_as_uint((float)t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) tree_flag = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+  __syncthreads();
+  if (!tree_flag) return false;
+  if (threadIdx.x == 0) __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < NO) total[threadIdx.x] = slab_sum_f32<kSyncGroups>(part + (int64_t)n_blocks * NO, groups, 0, 1, NO, threadIdx.x);
+  __syncthreads();
+  return true;
+}
+
 // e^x on the negative side of SELU and of its derivative (x <= 0): one multiply and the hardware exp2 instead of expf's
 // range reduction and overflow handling (2 VALU operations for about 12 — the fused layer kernels evaluate it per gathered
 // non-zero and were bound by exactly that: 1 180 vector instructions per wave of the Bitcoin-OTC-shaped forward, rocprofv3 SQ

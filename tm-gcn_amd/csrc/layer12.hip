@@ -305,7 +305,8 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int e = tile + u * 256 + t;
-      hv[u] = *reinterpret_cast<const float2*>(a.H + ((e < split ? xoff0 : xoff0 + a.N) + c[u]) * KI);
+      // (positions past the block's last entry were clamped to it: they must take ITS slice — the next one may not exist)
+      hv[u] = *reinterpret_cast<const float2*>(a.H + (((e < n_ent ? e : n_ent - 1) < split ? xoff0 : xoff0 + a.N) + c[u]) * KI);
     }
     if (tile + kEmTile < n_ent) load_cv(tile + kEmTile, c_next, v_next);      // the next tile's stream, behind this tile's gathers
 #pragma unroll
@@ -353,7 +354,6 @@ template <int NO, int G>
 __device__ __forceinline__ void l12_bwd_finish(const double (&acc)[(NO + G - 1) / G], const L12Args& a) {
   constexpr int NPL = (NO + G - 1) / G;
   __shared__ double red[4][NO];
-  __shared__ int is_last;
   const int gl = threadIdx.x & (G - 1);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -369,22 +369,9 @@ __device__ __forceinline__ void l12_bwd_finish(const double (&acc)[(NO + G - 1) 
     __hip_atomic_store(reinterpret_cast<unsigned*>(a.part) + (int64_t)blockIdx.x * NO + threadIdx.x,
                        __float_as_uint((float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x])),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (!last_block_ticket(a.sync, (int)gridDim.x, &is_last)) return;
-  if (threadIdx.x == 0) *a.sync = 0;
-  // the last block: 256 / NO threads per output, each adding its share of the slabs in order (slab_sum_f32)
-  constexpr int SUBS = 256 / NO;
-  __shared__ double fin[SUBS][NO];
-  const unsigned* P = reinterpret_cast<const unsigned*>(a.part);
-  const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
-  const int nb = (int)gridDim.x;
-  if (sub < SUBS) fin[sub][o] = slab_sum_f32<kFinisherDepth>(P, nb, sub, SUBS, NO, o);
-  __syncthreads();
-  if (threadIdx.x < NO) {
-    double tot = 0.0;
-#pragma unroll
-    for (int q = 0; q < SUBS; ++q) tot += fin[q][threadIdx.x];
-    a.dW1[threadIdx.x] = (float)tot;
-  }
+  __shared__ double total[NO];
+  if (!slab_tree_finish<NO>(reinterpret_cast<unsigned*>(a.part), (int)gridDim.x, a.sync, total)) return;
+  if (threadIdx.x < NO) a.dW1[threadIdx.x] = (float)total[threadIdx.x];
 }
 
 // Backward.  Groups of G lanes walk rows r = group, group + n_groups, …; the KI·F fp64 accumulators of dW1 are dealt
@@ -586,7 +573,7 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int e = tile + u * 256 + t;
-        const int64_t row = (e < split ? xoff0 : xoff0 + a.N) + c[u];
+        const int64_t row = ((e < n_ent ? e : n_ent - 1) < split ? xoff0 : xoff0 + a.N) + c[u];   // clamped positions: the last entry's slice
         const float2* gz = reinterpret_cast<const float2*>(a.dZ + row * NT);
 #pragma unroll
         for (int i = 0; i < NT / 2; ++i) {
@@ -790,7 +777,7 @@ extern "C" int tmgcn_layer12_fwd_pays(int64_t n_rows, int32_t N, int32_t F, floa
 }
 
 extern "C" int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F) {
-  return (int64_t)kL12MaxBlocks * K0 * F * (int64_t)sizeof(float);
+  return (int64_t)(kL12MaxBlocks + kSyncGroups) * K0 * F * (int64_t)sizeof(float);    // block slabs + group slabs (slab_tree_finish)
 }
 
 extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const float* dZ,
