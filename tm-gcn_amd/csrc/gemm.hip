@@ -1186,26 +1186,17 @@ __global__ __launch_bounds__(256) void gemm_dw_narrow_kernel(DwArgs a) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(a.part) + (int64_t)blockIdx.x * NO + threadIdx.x,
                        __float_as_uint((float)(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x])),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __shared__ int is_last;
-  if (!last_block_ticket(a.sync, (int)gridDim.x, &is_last)) return;
-  if (threadIdx.x == 0) *a.sync = 0;
-  const unsigned* P = reinterpret_cast<const unsigned*>(a.part);
   if (a.n_batch == 1) {
-    // one output matrix: SUBS = 256 / NO threads per output, each adding the slabs c = sub, sub + SUBS, … (slab_sum_f32),
-    // then the SUBS partial sums of an output in order
-    constexpr int SUBS = 256 / NO;
-    __shared__ double fin[SUBS][NO];
-    const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
-    if (sub < SUBS) fin[sub][o] = slab_sum_f32<kFinisherDepth>(P, a.chunks, sub, SUBS, NO, o);
-    __syncthreads();
-    if (threadIdx.x < NO) {
-      double t = 0.0;
-#pragma unroll
-      for (int q = 0; q < SUBS; ++q) t += fin[q][threadIdx.x];
-      a.dW[threadIdx.x] = (float)t;
-    }
+    // one output matrix: the slabs are added as a tree over the two ticket levels (common.h: slab_tree_finish)
+    __shared__ double total[NO];
+    if (!slab_tree_finish<NO>(reinterpret_cast<unsigned*>(a.part), (int)gridDim.x, a.sync, total)) return;
+    if (threadIdx.x < NO) a.dW[threadIdx.x] = (float)total[threadIdx.x];
   } else {
-    // one weight per slice: few chunks per batch, many outputs — a thread per output walks its chunks in order
+    // one weight per slice: few chunks per batch, many outputs — the last block, a thread per output walking its chunks in order
+    __shared__ int is_last;
+    if (!last_block_ticket(a.sync, (int)gridDim.x, &is_last)) return;
+    if (threadIdx.x == 0) *a.sync = 0;
+    const unsigned* P = reinterpret_cast<const unsigned*>(a.part);
     const int64_t total = (int64_t)a.n_batch * NO;
     for (int64_t idx = threadIdx.x; idx < total; idx += 256) {
       const int64_t b = idx / NO, o = idx - b * NO;
@@ -1393,7 +1384,7 @@ extern "C" int64_t tmgcn_gemm_dw_workspace_bytes(int64_t R, int32_t K, int32_t N
   int64_t nb, rpc;
   int chunks;
   dw_plan(R, rows_per_batch, &nb, &chunks, &rpc);
-  return nb * chunks * (int64_t)K * Nf * (int64_t)sizeof(float);
+  return (nb * chunks + kSyncGroups) * (int64_t)K * Nf * (int64_t)sizeof(float);      // block slabs + the group slabs of slab_tree_finish
 }
 
 static int gemm_dw_launch(const float* A, const float* dY, const float* pre, int32_t act, float* dW, int64_t R, int32_t K,
@@ -1412,7 +1403,7 @@ static int gemm_dw_launch(const float* A, const float* dY, const float* pre, int
     return check_launch("gemm_dw memset");
   }
   TMGCN_REQUIRE(A && dY, "gemm_dw: null pointer");
-  const int64_t need = nb * chunks * (int64_t)K * Nf * (int64_t)sizeof(float);
+  const int64_t need = (nb * chunks + kSyncGroups) * (int64_t)K * Nf * (int64_t)sizeof(float);
   if (!workspace || workspace_bytes < need) {
     set_error("gemm_dw: workspace %lld B < required %lld B", (long long)workspace_bytes,
               (long long)need);
