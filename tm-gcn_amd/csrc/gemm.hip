@@ -1414,16 +1414,16 @@ static int gemm_dw_launch(const float* A, const float* dY, const float* pre, int
   TMGCN_REQUIRE(!pre || narrow, "gemm_dw_act: the fused activation gradient needs the narrow kernel (even K, Nf <= 8, 8-byte "
                                  "aligned operands); use tmgcn_act_bwd_f32 + tmgcn_gemm_dw_f32");
   if (narrow) {
-    // The narrow kernel's fixed costs are per block (the K·Nf-value block reduction, the slab and the hand-off ticket,
-    // and the last block's pass over all slabs), its loop is a stream: about one block per CU while the operand is small
-    // (captured steps, kernel durations under rocprofv3: 570 k rows 11.2 us with 279 blocks, 13.4 with 557; 150 k rows
-    // 7.6 us with 147 blocks, 9.0 with 74), four per CU from 4 M rows on; never more slabs than planned (workspace).
+    // The narrow kernel's fixed costs are per block (the K·Nf-value block reduction, the slab and the hand-off tickets),
+    // its loop is a stream: about two blocks per CU while the operand is small (captured steps, kernel durations under
+    // rocprofv3, slabs reduced as a tree: 570 k rows 9.8 us with 509 blocks, 11.6 with 279 or 1 018; 150 k rows 7.6 - 8.0 us
+    // from 147 to 469 blocks), four per CU from 4 M rows on; never more slabs than planned (workspace).
     const int64_t br = rows_per_batch ? rows_per_batch : R;
-    int64_t target = (R < (4ll << 20) ? 256 : 1024) / nb;      // blocks per batch
+    int64_t target = (R < (4ll << 20) ? 512 : 1024) / nb;      // blocks per batch
     if (target < 1) target = 1;
     int64_t fat = (br + target - 1) / target;
     fat = (fat + 31) & ~(int64_t)31;
-    if (fat < 1024) fat = 1024;
+    if (fat < 256) fat = 256;
     if (fat > rpc) {
       rpc = fat;
       chunks = (int)((br + rpc - 1) / rpc);
