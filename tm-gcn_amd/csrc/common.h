@@ -236,6 +236,63 @@ __device__ __forceinline__ bool slab_tree_finish(unsigned* part, int n_blocks, i
   return true;
 }
 
+// The same tree for slabs of fp64 bit patterns (8-byte write-through stores / loads): the head + loss kernel.
+template <int DEPTH>
+__device__ __forceinline__ double slab_sum_f64(const unsigned long long* slabs, int n, int first, int stride, int width, int o) {
+  double s = 0.0;
+  for (int c = first; c < n; c += DEPTH * stride) {
+    double v[DEPTH];
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) {
+      const int cc = c + q * stride;
+      v[q] = __longlong_as_double((long long)__hip_atomic_load(slabs + (int64_t)(cc < n ? cc : n - 1) * width + o, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT));
+    }
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) s += c + q * stride < n ? v[q] : 0.0;
+  }
+  return s;
+}
+
+template <int NO>
+__device__ __forceinline__ bool slab_tree_finish_f64(unsigned long long* part, int n_blocks, int32_t* sync, double* total /* LDS [NO] */) {
+  constexpr int SUBS = 256 / NO;
+  __shared__ double tree_fin64[SUBS][NO];
+  __shared__ int tree_flag64;
+  const int g = blockIdx.x % kSyncGroups;
+  const int members = (n_blocks - g + kSyncGroups - 1) / kSyncGroups;
+  const int groups = n_blocks < kSyncGroups ? n_blocks : kSyncGroups;
+  int32_t* mine = sync + (1 + g) * kSyncStride;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool last = __hip_atomic_fetch_add(mine, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1;
+    if (last) __hip_atomic_store(mine, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tree_flag64 = last;
+  }
+  __syncthreads();
+  if (!tree_flag64) return false;
+  const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
+  if (sub < SUBS) tree_fin64[sub][o] = slab_sum_f64<8>(part + (int64_t)g * NO, members, sub, SUBS, NO * kSyncGroups, o);
+  __syncthreads();
+  if (threadIdx.x < NO) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < SUBS; ++q) t += tree_fin64[q][threadIdx.x];
+    __hip_atomic_store(part + (int64_t)(n_blocks + g) * NO + threadIdx.x, (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) tree_flag64 = __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+  __syncthreads();
+  if (!tree_flag64) return false;
+  if (threadIdx.x == 0) __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < NO) total[threadIdx.x] = slab_sum_f64<kSyncGroups>(part + (int64_t)n_blocks * NO, groups, 0, 1, NO, threadIdx.x);
+  __syncthreads();
+  return true;
+}
+
 // e^x on the negative side of SELU and of its derivative (x <= 0): one multiply and the hardware exp2 instead of expf's
 // range reduction and overflow handling (2 VALU operations for about 12 — the fused layer kernels evaluate it per gathered
 // non-zero and were bound by exactly that: 1 180 vector instructions per wave of the Bitcoin-OTC-shaped forward, rocprofv3 SQ

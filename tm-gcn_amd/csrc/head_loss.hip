@@ -105,7 +105,6 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
   static_assert(NP <= 128, "slab wider than the finisher");
   __shared__ double red[4][NP];
   __shared__ double fin[PARTS][NPP];
-  __shared__ int is_last;
   const float* __restrict__ U = a.U;
   const int gl = threadIdx.x & (G - 1);
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -346,37 +345,15 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
     __hip_atomic_store(a.part + (int64_t)blockIdx.x * NP + threadIdx.x, (unsigned long long)__double_as_longlong(v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (!last_block_ticket(a.sync, a.main_blocks, &is_last)) return;
-  // the last block: 256 threads = NPP output columns x (256 / NPP) interleaved parts of the slab list; a thread
-  // adds its slabs in order (8 independent chains, folded in a fixed order), the parts are folded in order
-  {
-    const int o = threadIdx.x % NPP, part = threadIdx.x / NPP;
-    const int nb = a.main_blocks;
-    double s[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s[q] = 0.0;
-    if (o < NP) {
-      for (int b = part; b < nb; b += 8 * PARTS) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int bb = b + q * PARTS;               // all eight loads issued, then masked: no branch (and wait) per load
-          const double v = __longlong_as_double((long long)__hip_atomic_load(a.part + (int64_t)(bb < nb ? bb : nb - 1) * NP + o,
-                                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          s[q] += bb < nb ? v : 0.0;
-        }
-      }
-    }
-    fin[part][o] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-  }
-  __syncthreads();
+  // the slabs are added as a tree over the two ticket levels (common.h: slab_tree_finish_f64) — one last block walking the
+  // 1 024 slabs of a Reddit-LP-sized launch with 8 threads per output and 8 loads in flight took 16 round trips
+  __shared__ double totals[NP];
+  if (!slab_tree_finish_f64<NP>(a.part, a.main_blocks, a.sync, totals)) return;
   if (threadIdx.x < NP) {
-    double total = 0.0;
-#pragma unroll
-    for (int q = 0; q < PARTS; ++q) total += fin[q][threadIdx.x];
+    const double total = totals[threadIdx.x];
     fin[0][threadIdx.x] = total;                      // Q totals, for the folded outputs below
     if (threadIdx.x == 0) {
-      if (a.loss) a.loss[0] = (float)(total * invden);
-      *a.sync = 0;                                    // ready for the next launch: no memset node per step
+      if (a.loss) a.loss[0] = (float)(total * invden);      // (the launch's counters are zero again: slab_tree_finish_f64)
     }
     if constexpr (GRAD && K == 0) {
       if (threadIdx.x >= 1) a.dU[threadIdx.x - 1] = (float)(total * invden_g);      // Q = [Q_s; Q_d] is dU's layout
@@ -469,7 +446,7 @@ extern "C" int tmgcn_head_loss_supported(int32_t F, int32_t C, int32_t K) {
 
 extern "C" int64_t tmgcn_head_loss_workspace_bytes(int32_t F, int32_t C, int32_t K) {
   if (!tmgcn_head_loss_supported(F, C, K)) return 0;
-  return (int64_t)kHeadLossMaxBlocks * (1 + 2 * (K ? K : F) * C) * (int64_t)sizeof(double);
+  return (int64_t)(kHeadLossMaxBlocks + kSyncGroups) * (1 + 2 * (K ? K : F) * C) * (int64_t)sizeof(double);   // block slabs + group slabs
 }
 
 extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t K, const float* U,
