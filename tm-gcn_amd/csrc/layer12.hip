@@ -376,7 +376,8 @@ __device__ __forceinline__ void l12_bwd_finish(const double (&acc)[(NO + G - 1) 
 
 // Backward.  Groups of G lanes walk rows r = group, group + n_groups, …; the KI·F fp64 accumulators of dW1 are dealt
 // over the lanes of a group (lane gl owns q = gl + j·G).
-constexpr int kL12MaxBlocks = 1024;
+constexpr int kL12MaxBlocks = 4096;          // slabs the workspace holds
+constexpr int kL12ResidentBlocks = 1024;     // a persistent grid: four blocks per CU
 
 template <int KI, int F, int NT, int G, bool STAGED, bool ACT2>
 __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
@@ -811,12 +812,17 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
   } else if (G == 1 && N >= 256 && F <= 6 && Nf <= 6) {
     // entry-major (l12_bwd_em_kernel).  Captured steps, kernel durations under rocprofv3: the synthetic Bitcoin-OTC shape
     // 31.1 -> 27.9 us; the chess data 60 -> 62 (no gain there: 512 / 1 024 / 1 536 / 4 096 blocks 79.8 / 65.7 / 58.8 / 59.5)
+    // Grid: persistent blocks (all resident, each walking its row blocks one after the other) while a row block is less than
+    // a tile of entries; one block per row block when row blocks hold a tile or more on average — with real skew some hold
+    // several, and chaining those behind each other costs more than the extra slabs (chess, 1 016 entries per row block:
+    // 50.8 us against 61.7; the synthetic shape, 784: 30.0 against 26.6)
     int64_t blocks = (n_rows + 255) / 256;
-    if (blocks > kL12MaxBlocks) blocks = kL12MaxBlocks;
+    const int64_t cap = avg_nnz_per_row * 256.f > 0.9f * kEmTile ? kL12MaxBlocks : kL12ResidentBlocks;
+    if (blocks > cap) blocks = cap;
     l12_bwd_em_launch(a, F, Nf, (unsigned)blocks, st);
   } else {
     int64_t blocks = (n_rows * G + 255) / 256;
-    if (blocks > kL12MaxBlocks) blocks = kL12MaxBlocks;      // all resident at 4 waves per SIMD; 1 280 - 2 048 blocks measured slower (32 - 36 us vs 31)
+    if (blocks > kL12ResidentBlocks) blocks = kL12ResidentBlocks;      // all resident at 4 waves per SIMD; 1 280 - 2 048 blocks measured slower (32 - 36 us vs 31)
     l12_launch<true, false>(a, F, Nf, G, (unsigned)blocks, 0, st);
   }
   return check_launch("layer12_bwd");
