@@ -144,7 +144,12 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
   // (every uniform operand above is read before the first store of this kernel, so that it can live in scalar
   // registers: behind a store the compiler must assume it clobbered and reloads per lane)
   if constexpr (GRAD && K == 0) {                     // rows no labelled edge touches: dZ = 0
-    for (int64_t r = tid; r < a.R; r += nthreads)
+    // the sweep is left to the blocks that walk no active rows when they are the majority (the sparse regime: 186 of 1 024
+    // blocks walk rows at the Bitcoin-OTC shape) — it is off the critical path of the blocks that end in the reduction
+    const bool spare = (int64_t)gridDim.x >= 2 * (int64_t)a.main_blocks;
+    const int64_t z_first = spare ? tid - (int64_t)a.main_blocks * 256 : tid;
+    const int64_t z_step = spare ? nthreads - (int64_t)a.main_blocks * 256 : nthreads;
+    for (int64_t r = z_first; r >= 0 && r < a.R; r += z_step)
       if (a.eptr[r] == a.eptr[r + 1]) {
         float2* o = reinterpret_cast<float2*>(a.dZ + r * FT);
 #pragma unroll
