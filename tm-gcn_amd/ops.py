@@ -14,6 +14,8 @@ product never does).
 """
 from __future__ import annotations
 
+import functools
+
 import ctypes as C
 from typing import Optional
 
@@ -502,8 +504,13 @@ def spmm_feature_gemm(A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, act=None,
     return feature_gemm(spmm(A, X), W, act=act)
 
 
+@functools.lru_cache(maxsize=None)          # asked once per forward call: a shape's answer never changes (1-2 us per ctypes call)
+def _layer12_widths_ok(K0: int, F: int, Nf: int) -> bool:
+    return bool(_lib.load().tmgcn_layer12_supported(K0, F, Nf))
+
+
 def layer12_supported(K0: int, F: int, Nf: int) -> bool:
-    return kernels.name == "hip" and bool(_lib.load().tmgcn_layer12_supported(K0, F, Nf))
+    return kernels.name == "hip" and _layer12_widths_ok(int(K0), int(F), int(Nf))
 
 
 def layer12(H: torch.Tensor, W1: torch.Tensor, act1, A: BatchedCSR, W2: torch.Tensor, act2=None, fuse: Optional[bool] = None):
@@ -544,8 +551,13 @@ def edge_head(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, fuse: Optional
     return torch.matmul(torch.cat((Zf[edges.src.long()], Zf[edges.dst.long()]), dim=1), U)
 
 
+@functools.lru_cache(maxsize=None)
+def _head_loss_widths_ok(F: int, Cn: int, K: int) -> bool:
+    return bool(_lib.load().tmgcn_head_loss_supported(F, Cn, K))
+
+
 def head_loss_supported(F: int, Cn: int, K: int = 0) -> bool:
-    return kernels.name == "hip" and bool(_lib.load().tmgcn_head_loss_supported(F, Cn, K))
+    return kernels.name == "hip" and _head_loss_widths_ok(int(F), int(Cn), int(K))
 
 
 def widen_params(params):
