@@ -316,6 +316,23 @@ int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t K, const fl
                         const float* weight, const float* grad_scale, int64_t R, int64_t E, int32_t F,
                         int32_t C, float* logits, float* loss, float* dZ, float* dU, float* dW,
                         void* workspace, int64_t workspace_bytes, int32_t* sync, void* stream);
+/* The folded 1-layer model's WHOLE training step in one launch: tmgcn_head_loss_f32 with K = 2 (loss, dU, dW as above),
+ * whose last block then applies t.optim.SGD's update (experiment_reddit_our_link_prediction.py:68, 80) to U [2F][C] and
+ * W_fold [2][F] in place — the arithmetic of tmgcn_sgd_step, element for element.  buf_U / buf_W: the momentum buffers
+ * (NULL when momentum == 0); first_step: the buffers are written, not read (torch's first step).  The kernel's own reads of
+ * U and W are complete when the update starts (every other block has handed its slab over). */
+typedef struct TmgcnSgd {
+  float* buf_U;
+  float* buf_W;
+  float lr, momentum, dampening, weight_decay;
+  int32_t nesterov, maximize, first_step;
+} TmgcnSgd;
+int tmgcn_head_loss_sgd_f32(const float* Z, float* W_fold, int32_t K, float* U, const int32_t* eptr, const int32_t* arow,
+                            int64_t n_active, const int32_t* other, const uint8_t* meta, const int64_t* class_count,
+                            const float* weight, int64_t R, int64_t E, int32_t F, int32_t C, float* loss, float* dU,
+                            float* dW, const TmgcnSgd* sgd, void* workspace, int64_t workspace_bytes, int32_t* sync,
+                            void* stream);
+
 /* ---- optimizer step of all parameters in one launch (ABI 4) ------------------------------------
  * torch.optim.SGD(params, lr, momentum, dampening, weight_decay, nesterov, maximize).step() for up to 16 tensors
  * (experiment_reddit_our_link_prediction.py:68, 80):  g (+ wd·p);  buf = first_step ? g : m·buf + (1-d)·g;

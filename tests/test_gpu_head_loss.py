@@ -284,3 +284,68 @@ def test_hub_rows_and_skewed_degrees():
     assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-6 * max(1.0, abs(float(ref_loss)))
     assert_close(Zr.grad, ref_dZ, 2e-6, "dZ")
     assert_close(Ur.grad, ref_dU, 2e-6, "dU")
+
+
+@pytest.mark.parametrize("kw", [dict(lr=0.01, momentum=0.9), dict(lr=0.05), dict(lr=0.02, momentum=0.8, dampening=0.1, weight_decay=0.01, nesterov=False),
+                                dict(lr=0.01, momentum=0.9, nesterov=True)])
+def test_whole_training_step_of_the_folded_model_in_one_launch(kw):
+    """layers.fused_train_step / GraphedTrainStep(fold_optimizer=True): loss, gradients and the SGD update of the folded
+    1-layer model (G2: ehf.EmbeddingGCN, condensed W) in ONE launch — the same losses, parameters, momentum buffers and
+    .grad as criterion(gcn(), target) / backward / FusedSGD.step(), eagerly and as a captured graph (several steps per replay
+    included); combinations the kernel does not cover fall back (None / the unfolded graph)."""
+    from tmgcn_amd.graphs import GraphedTrainStep
+    from tmgcn_amd.layers import fused_train_step
+    from tmgcn_amd.optim import FusedSGD
+    d = golden("g2_gcn_condensed1")
+    X = torch.from_numpy(d["X"])
+    T, N = X.shape[0], X.shape[1]
+    At, M, edges, labels = coo_list(d, "At", T, N), torch.from_numpy(d["M"]), torch.from_numpy(d["edges"]), torch.from_numpy(d["labels"]).cuda()
+    w = torch.tensor([0.9, 0.1])
+
+    def make():
+        torch.manual_seed(int(d["seed"]))
+        m = ehf.EmbeddingGCN(At, X, edges, M, hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
+        return m, FusedSGD(m.parameters(), **kw)
+
+    m1, o1 = make()
+    crit = WeightedCrossEntropy(w).cuda()
+    ref = []
+    for _ in range(9):
+        o1.zero_grad()
+        l = m1.loss(crit, labels)
+        l.backward()
+        o1.step()
+        ref.append(float(l))
+    m2, o2 = make()
+    got = []
+    for _ in range(9):
+        l = fused_train_step(m2, crit, labels, o2)
+        assert l is not None
+        got.append(float(l))
+    assert_close(np.array(got), np.array(ref), 2e-6, "losses, one launch per step")
+    for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
+        assert_close(q.detach(), p.detach(), 2e-6, f"{n} after nine steps")
+        assert_close(q.grad, p.grad, 5e-6, f"{n}.grad of the last step")
+        if kw.get("momentum"):
+            assert_close(o2.state[q]["momentum_buffer"], o1.state[p]["momentum_buffer"], 5e-6, f"momentum buffer of {n}")
+    for k in (1, 3):
+        m3, o3 = make()
+        step = GraphedTrainStep(m3, crit, o3, labels, warmup=3, steps_per_replay=k, fold_optimizer=True)
+        assert step.folded
+        tail = []
+        for _ in range(6 // k):
+            step()
+            tail += [float(x) for x in step.losses]
+        assert_close(np.array(tail), np.array(ref[3:]), 2e-6, f"captured, {k} steps per replay")
+        for p, q in zip(m1.parameters(), m3.parameters()):
+            assert_close(q.detach(), p.detach(), 2e-6, "parameters after 3 + 6 steps")
+    # not covered: torch's own optimizer, or a 2-layer model -> the unfolded route
+    m4, _ = make()
+    assert fused_train_step(m4, crit, labels, torch.optim.SGD(m4.parameters(), lr=0.01)) is None
+    d3 = golden("g6_sgd_gcn2")
+    X3 = torch.from_numpy(d3["X"])
+    m5 = ehf.EmbeddingGCN2(coo_list(d3, "At", X3.shape[0], X3.shape[1]), X3, torch.from_numpy(d3["edges"]), torch.from_numpy(d3["M"]),
+                           hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False, nonlin2="selu")
+    o5 = FusedSGD(m5.parameters(), lr=0.01, momentum=0.9)
+    assert fused_train_step(m5, crit, torch.from_numpy(d3["labels"]).cuda(), o5) is None
+    assert not GraphedTrainStep(m5, crit, o5, torch.from_numpy(d3["labels"]).cuda(), fold_optimizer=True).folded

@@ -61,6 +61,11 @@ struct HeadLossArgs {
   int64_t R;
   int32_t n_active;
   int32_t main_blocks;         // blocks that walk active rows (the others only zero-fill dZ)
+  // fold (K = 2) only: the optimizer step of U and W in the last block (tmgcn_head_loss_sgd_f32); sgd_on = 0 otherwise
+  int32_t sgd_on;
+  TmgcnSgd sgd;
+  float* pU;
+  float* pW;
 };
 
 template <int N, typename T>
@@ -383,6 +388,30 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
         v = fma(Q[(K + k) * CT + c], (double)U[(FT + f) * CT + c], fma(Q[k * CT + c], (double)U[f * CT + c], v));
       a.dW[b] = (float)(v * invden_g);
     }
+    if (a.sgd_on) {
+      // the optimizer step (tmgcn_sgd_step's arithmetic), each thread on the element whose gradient it just formed; the
+      // block meets first: the gradients above read U and W
+      __syncthreads();
+      float* p = nullptr;
+      float* buf = nullptr;
+      int i = 0;
+      if (t < 2 * FT * CT) p = a.pU, buf = a.sgd.buf_U, i = t;
+      else if (t < 2 * FT * CT + K * FT) p = a.pW, buf = a.sgd.buf_W, i = t - 2 * FT * CT;
+      if (p) {
+        const float w0 = p[i];
+        float g = (t < 2 * FT * CT) ? a.dU[i] : a.dW[i];
+        if (a.sgd.maximize) g = -g;
+        if (a.sgd.weight_decay != 0.f) g = fmaf(a.sgd.weight_decay, w0, g);
+        if (a.sgd.momentum != 0.f) {
+          float b;
+          if (a.sgd.first_step) b = g;
+          else b = __fmul_rn(a.sgd.momentum, buf[i]) + (1.f - a.sgd.dampening) * g;
+          buf[i] = b;
+          g = a.sgd.nesterov ? fmaf(a.sgd.momentum, b, g) : b;
+        }
+        p[i] = fmaf(-a.sgd.lr, g, w0);
+      }
+    }
   }
 }
 
@@ -455,6 +484,8 @@ extern "C" int64_t tmgcn_head_loss_workspace_bytes(int32_t F, int32_t C, int32_t
   return (int64_t)(kHeadLossMaxBlocks + kSyncGroups) * (1 + 2 * (K ? K : F) * C) * (int64_t)sizeof(double);   // block slabs + group slabs
 }
 
+static thread_local const TmgcnSgd* g_head_loss_sgd = nullptr;
+
 extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t K, const float* U,
                                     const int32_t* eptr, const int32_t* arow, int64_t n_active, const int32_t* ent,
                                     const int32_t* other, const uint8_t* meta, const int64_t* class_count,
@@ -483,7 +514,10 @@ extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t 
     return TMGCN_ERR_WORKSPACE;
   }
   HeadLossArgs a{Z, W_fold, U, eptr, reinterpret_cast<const int4*>(arow), ent, other, meta, class_count, weight, grad_scale,
-                 logits, dZ, (unsigned long long*)workspace, loss, dU, dW, sync, R, (int32_t)n_active, 0};
+                 logits, dZ, (unsigned long long*)workspace, loss, dU, dW, sync, R, (int32_t)n_active, 0, 0, TmgcnSgd{}, nullptr, nullptr};
+  if (g_head_loss_sgd) {                              // set by tmgcn_head_loss_sgd_f32 for this one call (same thread)
+    a.sgd_on = 1, a.sgd = *g_head_loss_sgd, a.pU = const_cast<float*>(U), a.pW = const_cast<float*>(W_fold);
+  }
   const int G = head_loss_lanes(E, n_active);
   hipStream_t st = (hipStream_t)stream;
   switch (F) {
@@ -493,6 +527,21 @@ extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t 
     default: head_loss_launch_c<8>(a, C, grad, K, G, R, st);
   }
   return check_launch("head_loss");
+}
+
+extern "C" int tmgcn_head_loss_sgd_f32(const float* Z, float* W_fold, int32_t K, float* U, const int32_t* eptr, const int32_t* arow,
+                                        int64_t n_active, const int32_t* other, const uint8_t* meta, const int64_t* class_count,
+                                        const float* weight, int64_t R, int64_t E, int32_t F, int32_t C, float* loss, float* dU,
+                                        float* dW, const TmgcnSgd* sgd, void* workspace, int64_t workspace_bytes, int32_t* sync,
+                                        void* stream) {
+  TMGCN_REQUIRE(K == 2 && W_fold && sgd && dU && dW, "head_loss_sgd: the folded form (K = 2) with dU, dW and the optimizer settings");
+  TMGCN_REQUIRE(sgd->lr >= 0.f && sgd->momentum >= 0.f && sgd->weight_decay >= 0.f, "head_loss_sgd: negative hyper-parameter");
+  TMGCN_REQUIRE(sgd->momentum == 0.f || (sgd->buf_U && sgd->buf_W), "head_loss_sgd: momentum needs both buffers");
+  g_head_loss_sgd = sgd;
+  const int rc = tmgcn_head_loss_f32(Z, W_fold, K, U, eptr, arow, n_active, nullptr, other, meta, class_count, weight, nullptr, R, E, F,
+                                     C, nullptr, loss, nullptr, dU, dW, workspace, workspace_bytes, sync, stream);
+  g_head_loss_sgd = nullptr;
+  return rc;
 }
 
 extern "C" int tmgcn_scale2_f32(const float* g, const float* a, float* out_a, int64_t na, const float* b, float* out_b,

@@ -440,6 +440,50 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> head_loss_fwd(const Tensor& Z, const 
   return {loss, logits, dZ, dU};
 }
 
+// The folded 1-layer model's whole training step in one launch (tmgcn_head_loss_sgd_f32): loss, dW, dU, and the SGD update
+// of W and U in place.  No autograd: the caller is an optimizer-aware step (graphs.GraphedTrainStep(fold_optimizer=True)).
+std::tuple<Tensor, Tensor, Tensor> head_loss_sgd(const Tensor& Z, Tensor W_fold, Tensor U, const Tensor& eptr, const Tensor& arow,
+                                                 const Tensor& other, const Tensor& meta, const Tensor& counts, const Tensor& weight,
+                                                 Tensor sync, const OptTensor& buf_W, const OptTensor& buf_U, double lr, double momentum,
+                                                 double dampening, double weight_decay, bool nesterov, bool maximize, bool first_step) {
+  want(Z, "head_loss_sgd AtXt");
+  want(W_fold, "head_loss_sgd W");
+  want(U, "head_loss_sgd U");
+  want(weight, "head_loss_sgd weight");
+  want(eptr, "head_loss_sgd eptr", at::kInt);
+  want(arow, "head_loss_sgd arow", at::kInt);
+  want(other, "head_loss_sgd other", at::kInt);
+  want(meta, "head_loss_sgd meta", at::kByte);
+  want(counts, "head_loss_sgd class counts", at::kLong);
+  want(sync, "head_loss_sgd sync", at::kInt);
+  TORCH_CHECK(Z.dim() == 2 && U.dim() == 2 && W_fold.dim() == 2 && W_fold.size(0) == Z.size(1), "head_loss_sgd: AtXt [R, 2], W [2, F], U [2F, C]");
+  const int64_t R = Z.size(0), K = Z.size(1), F = W_fold.size(1), C = U.size(1), E = other.numel() / 2;
+  TORCH_CHECK(K == 2 && U.size(0) == 2 * F && weight.numel() == C && counts.numel() == C &&
+                  tmgcn_head_loss_supported((int32_t)F, (int32_t)C, (int32_t)K),
+              "head_loss_sgd: unsupported widths F=", F, " C=", C, " K=", K);
+  TORCH_CHECK(eptr.numel() == R + 1 && meta.numel() == other.numel() && arow.dim() == 2 && arow.size(1) == 4 && sync.numel() >= TMGCN_SYNC_INTS,
+              "head_loss_sgd: plan arrays do not match R=", R);
+  const bool mom = momentum != 0.0;
+  TORCH_CHECK(!mom || (buf_W.has_value() && buf_W->defined() && buf_U.has_value() && buf_U->defined()), "head_loss_sgd: momentum needs both buffers");
+  if (mom) {
+    want(*buf_W, "head_loss_sgd momentum buffer of W");
+    want(*buf_U, "head_loss_sgd momentum buffer of U");
+    TORCH_CHECK(buf_W->numel() == W_fold.numel() && buf_U->numel() == U.numel(), "head_loss_sgd: momentum buffers do not match the parameters");
+  }
+  c10::DeviceGuard g(Z.device());
+  Tensor loss = at::empty({}, Z.options()), dW = at::empty_like(W_fold), dU = at::empty_like(U);
+  const int64_t need = tmgcn_head_loss_workspace_bytes((int32_t)F, (int32_t)C, (int32_t)K);
+  Tensor ws = at::empty({need}, Z.options().dtype(at::kByte));
+  TmgcnSgd sgd{mom ? (float*)buf_U->data_ptr() : nullptr, mom ? (float*)buf_W->data_ptr() : nullptr, (float)lr, (float)momentum,
+               (float)dampening, (float)weight_decay, nesterov ? 1 : 0, maximize ? 1 : 0, first_step ? 1 : 0};
+  ok(tmgcn_head_loss_sgd_f32((const float*)ptr(Z), (float*)W_fold.data_ptr(), (int32_t)K, (float*)U.data_ptr(), (const int32_t*)ptr(eptr),
+                             (const int32_t*)ptr(arow), arow.size(0), (const int32_t*)ptr(other), (const uint8_t*)ptr(meta),
+                             (const int64_t*)ptr(counts), (const float*)ptr(weight), R, E, (int32_t)F, (int32_t)C, (float*)loss.data_ptr(),
+                             (float*)dU.data_ptr(), (float*)dW.data_ptr(), &sgd, ptr(ws), ws.numel(), (int32_t*)sync.data_ptr(), stream_of(Z)),
+     "tmgcn_head_loss_sgd_f32");
+  return {loss, dW, dU};
+}
+
 std::tuple<Tensor, Tensor> scale2(const Tensor& g, const Tensor& a, const Tensor& b) {
   want(g, "scale2 g");
   want(a, "scale2 a");
@@ -976,6 +1020,9 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("weighted_ce(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> Tensor");
   m.def("head_loss(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor arow, Tensor ent, Tensor other, Tensor meta, "
         "Tensor counts, Tensor weight, Tensor(a!) sync, bool want_logits, bool unit_grad) -> (Tensor, Tensor)");
+  m.def("head_loss_sgd(Tensor Z, Tensor(a!) W_fold, Tensor(b!) U, Tensor eptr, Tensor arow, Tensor other, Tensor meta, Tensor counts, "
+        "Tensor weight, Tensor(c!) sync, Tensor(d!)? buf_W, Tensor(e!)? buf_U, float lr, float momentum, float dampening, "
+        "float weight_decay, bool nesterov, bool maximize, bool first_step) -> (Tensor, Tensor, Tensor)");
   m.def("unit_gradient(Tensor like) -> Tensor");
   m.def("widen_params(Tensor[] params) -> Tensor[]");
 }
@@ -997,6 +1044,7 @@ TORCH_LIBRARY_IMPL(tmgcn, CUDA, m) {
   m.impl("wce_fwd", &wce_fwd);
   m.impl("wce_bwd", &wce_bwd);
   m.impl("head_loss_fwd", &head_loss_fwd);
+  m.impl("head_loss_sgd", &head_loss_sgd);
   m.impl("scale2", &scale2);
   m.impl("sgd_step", &sgd_step);
   m.impl("unit_gradient", &unit_gradient);

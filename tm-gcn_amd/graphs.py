@@ -29,7 +29,7 @@ import torch
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, criterion, optimizer: torch.optim.Optimizer,
                  target: torch.Tensor, warmup: int = 3, fused_loss: bool = True, keep_logits: bool = False,
-                 steps_per_replay: int = 1):
+                 steps_per_replay: int = 1, fold_optimizer: bool = False):
         self.model, self.criterion, self.optimizer, self.target = model, criterion, optimizer, target
         if steps_per_replay < 1:
             raise ValueError("steps_per_replay must be at least 1")
@@ -40,6 +40,15 @@ class GraphedTrainStep:
         from . import ops
         self.fused = bool(fused_loss) and hasattr(model, "loss")
         self.keep_logits = keep_logits or not self.fused
+        # fold_optimizer: loss, gradients AND the SGD update in one launch where the model / optimizer pair allows it (the
+        # folded 1-layer model with FusedSGD: layers.fused_train_step) — the whole step of the Reddit-LP config is one kernel
+        self.folded = False
+        if fold_optimizer and self.fused and not self.keep_logits:
+            from .layers import fused_train_step
+            if warmup < 1:
+                raise ValueError("fold_optimizer needs at least one warm-up step (the first SGD step creates the momentum buffers)")
+            probe = fused_train_step(model, criterion, target, optimizer)         # one real step: also the applicability test
+            self.folded = probe is not None
 
         def forward_loss():
             if self.fused:
@@ -49,13 +58,21 @@ class GraphedTrainStep:
             out = model()
             return criterion(out, target), out
 
+        def one_step():
+            if self.folded:
+                from .layers import fused_train_step
+                return fused_train_step(model, criterion, target, optimizer), None
+            optimizer.zero_grad(set_to_none=True)
+            loss, out = forward_loss()
+            loss.backward(gradient=ops.unit_gradient(dev))
+            optimizer.step()
+            return loss, out
+
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, lazy init, plans)
-            for _ in range(warmup):
-                optimizer.zero_grad(set_to_none=True)
-                forward_loss()[0].backward(gradient=ops.unit_gradient(dev))
-                optimizer.step()
+            for _ in range(warmup - (1 if self.folded else 0)):          # (the applicability probe above was a step)
+                one_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
@@ -67,11 +84,14 @@ class GraphedTrainStep:
         self.losses = []
         with torch.cuda.graph(self.graph):
             for i in range(self.steps_per_replay):
-                if i:
-                    optimizer.zero_grad(set_to_none=True)      # host side only: the next backward writes fresh gradients
-                self.loss, self.output = forward_loss()
-                self.loss.backward(gradient=self._one)
-                optimizer.step()
+                if self.folded:
+                    self.loss, self.output = one_step()
+                else:
+                    if i:
+                        optimizer.zero_grad(set_to_none=True)      # host side only: the next backward writes fresh gradients
+                    self.loss, self.output = forward_loss()
+                    self.loss.backward(gradient=self._one)
+                    optimizer.step()
                 self.losses.append(self.loss)
 
     def __call__(self) -> torch.Tensor:

@@ -248,6 +248,37 @@ class _Head:
         return self._deliver(res)
 
 
+def fused_train_step(model, criterion, target: torch.Tensor, optimizer):
+    """``loss = criterion(model(), target); loss.backward(); optimizer.step()`` of the folded 1-layer model
+    (EmbeddingGCN, condensed W, no M⁻¹: ehf:222) as ONE launch (ops.head_loss_sgd): returns the loss of the parameters
+    as they were, with W, U and the optimizer's momentum buffers updated in place and ``.grad`` set — or None when the
+    combination is not the one the kernel covers (then the caller runs the three statements)."""
+    from .optim import FusedSGD
+    if not isinstance(model, _Head) or model._shard is not None or not isinstance(optimizer, FusedSGD) or len(optimizer.param_groups) != 1:
+        return None
+    spec = _criterion_spec(criterion, model.F[-1], model.dev)
+    W, U = getattr(model, "W", None), getattr(model, "U", None)
+    group = optimizer.param_groups[0]
+    if (spec is None or W is None or U is None or W.dtype != torch.float32 or U.dtype != torch.float32
+            or {id(q) for q in group["params"]} != {id(W), id(U)}):
+        return None
+    Z, eidx, U_used, fold = model._embed()
+    if fold is None or fold.data_ptr() != W.data_ptr() or U_used.data_ptr() != U.data_ptr() or not ops.head_loss_supported(W.shape[1], U.shape[-1], Z.shape[-1]):
+        return None
+    mom = float(group["momentum"])
+    bufs, first = [], False
+    for q in (W, U):
+        st = optimizer.state[q]
+        if mom != 0.0 and st.get("momentum_buffer") is None:
+            st["momentum_buffer"] = torch.empty_like(q, memory_format=torch.contiguous_format)
+            first = True
+        bufs.append(st.get("momentum_buffer") if mom != 0.0 else None)
+    loss, dW, dU = ops.head_loss_sgd(Z, eidx, W.data, U.data, target, spec[0], spec[1], bufs[0], bufs[1], group["lr"], mom,
+                                     group["dampening"], group["weight_decay"], group["nesterov"], group["maximize"], first)
+    W.grad, U.grad = dW, dU
+    return loss
+
+
 def _param(t: torch.Tensor, dev, dtype) -> nn.Parameter:
     """A parameter drawn on the CPU generator (reference order/values), stored on the device in
     `dtype` (fp32, or bf16 for the "bf16 weights" config)."""

@@ -532,6 +532,23 @@ def layer12(H: torch.Tensor, W1: torch.Tensor, act1, A: BatchedCSR, W2: torch.Te
                                _lib.ACT_IDS[act1], _lib.ACT_IDS[act2])
 
 
+def head_loss_sgd(AtXt: torch.Tensor, edges: EdgeIndex, W: torch.Tensor, U: torch.Tensor, target: torch.Tensor, weight: torch.Tensor,
+                  ignore_index: int, buf_W: Optional[torch.Tensor], buf_U: Optional[torch.Tensor], lr: float, momentum: float = 0.0,
+                  dampening: float = 0.0, weight_decay: float = 0.0, nesterov: bool = False, maximize: bool = False,
+                  first_step: bool = False):
+    """The folded 1-layer model's WHOLE training step in one launch (csrc/head_loss.hip, tmgcn_head_loss_sgd_f32): the
+    class-weighted mean cross entropy of logits = [AtXt·W][src] ‖ [AtXt·W][dst] · U, its gradients dW, dU, and torch.optim.SGD's
+    update of W and U IN PLACE (momentum buffers updated as well).  Returns (loss, dW, dU), detached.  No autograd: for an
+    optimizer-aware step (graphs.GraphedTrainStep(fold_optimizer=True))."""
+    R = AtXt.shape[0] * AtXt.shape[1]
+    plan = head_loss_plan(edges, R, target, U.shape[-1], ignore_index)
+    w = weight.to(device=AtXt.device, dtype=torch.float32).contiguous()
+    with torch.no_grad():
+        return kernels.ops.head_loss_sgd(AtXt.reshape(R, AtXt.shape[-1]), W, U, plan.eptr, plan.arow, plan.other, plan.meta, plan.counts, w,
+                                         plan.sync, buf_W, buf_U, float(lr), float(momentum), float(dampening), float(weight_decay),
+                                         bool(nesterov), bool(maximize), bool(first_step))
+
+
 def edge_head(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, fuse: Optional[bool] = None) -> torch.Tensor:
     """P4: logits[e] = [Z[src[e]], Z[dst[e]]] · U  (ehf:228-232).  One fused gather-and-dot kernel
     (atomic-free backward) when F <= 256 and C <= 8, else stock gather + matmul."""
