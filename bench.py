@@ -56,6 +56,10 @@ def parse(argv=None):
     p.add_argument("--deg", type=int, default=32)
     p.add_argument("--feat", type=int, default=128)
     p.add_argument("--band", type=int, default=20)
+    p.add_argument("--graph", choices=["er", "powerlaw", "powerlaw_sym"], default="er",
+                   help="adjacency of the S4 layer: er = SURVEY §8d (every row deg+1 entries, the headline); powerlaw = the same N, "
+                        "mean row length and uniform columns with capped-Zipf row lengths (synth.device_powerlaw_csr: hubs of up to "
+                        "100 000 entries); powerlaw_sym = that with every pair stored both ways (forward AND backward skewed)")
     p.add_argument("--exchange", choices=["a2a", "allgather"], default="a2a")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-epochs", action="store_true", help="skip the S1-S3 training-epoch block (N = 1 only)")
@@ -73,6 +77,9 @@ def parse(argv=None):
     p.add_argument("--no-hbm-only", action="store_true",
                    help="skip the roofline.frac_hbm_only leg (N = 1 only): the same edge-slices per launch as 2 slices of "
                         "N x slices/2 nodes, i.e. one multi-GB gather window per slice that the 256 MB Infinity Cache cannot help")
+    p.add_argument("--no-skewed", action="store_true",
+                   help="skip the roofline_skewed leg (N = 1 only): the same layer on --graph powerlaw — the mean row length, N and "
+                        "uniform columns of S4 with capped-Zipf row lengths (hubs of 100 000 entries) — as a child run of this script")
     p.add_argument("--no-verify", action="store_true",
                    help="skip the verify leg (sampled rows of Y / dX and the all-reduced dW against the CPU oracle)")
     p.add_argument("--verify-rows", type=int, default=128, help="sampled rows per slice (Y) and sampled nodes (dX) per rank")
@@ -458,7 +465,7 @@ def build_problem(args, dev, rank, world, exchange, N, kernels_ok=True):
     G, Tl, F = world, args.slices_per_gpu, args.feat
     T = Tl * G
     k0 = rank * Tl
-    A = synth.device_er_csr(Tl, N, args.deg, dev, first_slice=k0)
+    A = synth.device_csr(args.graph, Tl, N, args.deg, dev, first_slice=k0)
     A.transpose()  # backward operand, built once (plan time, not timed)
     M = synth.band_M(T, args.band, "matlab")
     layer = ShardedTMGCNLayer(A, M, T, group=None, exchange=exchange, fuse=False if args.no_fuse else None,
@@ -485,7 +492,7 @@ def build_problem(args, dev, rank, world, exchange, N, kernels_ok=True):
         return synth.device_normal(1, N, F, dev, first_slice=k)[0]
 
     def a_slice(k):                       # one-slice CSR of adjacency slice k
-        return synth.device_er_csr(1, N, args.deg, dev, first_slice=k)
+        return synth.device_csr(args.graph, 1, N, args.deg, dev, first_slice=k)
 
     return dict(A=A, M=M, T=T, Tl=Tl, k0=k0, layer=layer, X=X, W=W, dY=dY, node_sharded=node_sharded,
                 x_slice=x_slice, dy_slice=dy_slice, a_slice=a_slice)
@@ -574,7 +581,13 @@ def run_layer(args, dist, dev, rank, world, exchange, N, steps, warmup, want_tim
                            x_slice=pb["x_slice"], dy_slice=pb["dy_slice"], a_slice=pb["a_slice"], rows=args.verify_rows)
         stage(f"layer[{exchange}, N={N}]: verify {'ok' if ver['ok'] else 'FAILED'} in {ver['seconds']} s: "
               f"Y {ver['max_rel_err_Y']:.2e} dX {ver['max_rel_err_dX']:.2e} dW {ver['max_rel_err_dW']}")
-    return {"elapsed": elapsed, "kt": kt, "nnz_rank": A.nnz, "rows_rank": A.n_rows, "total_nnz": total_nnz,
+    cnt = A.rowptr[1:] - A.rowptr[:-1]
+    row_stats = {"max": int(cnt.max()), "median": int(cnt.median()), "min": int(cnt.min()),
+                 "rows_over_256": int((cnt > 256).sum()),
+                 "share_of_entries_in_rows_over_256": round(float(cnt[cnt > 256].sum()) / max(1, A.nnz), 4),
+                 "share_of_entries_in_longest_tenth_of_rows": round(float(torch.sort(cnt, descending=True).values[:max(1, A.n_rows // 10)].sum()) / max(1, A.nnz), 4)}
+    del cnt
+    return {"elapsed": elapsed, "kt": kt, "nnz_rank": A.nnz, "rows_rank": A.n_rows, "total_nnz": total_nnz, "row_stats": row_stats,
             "collective": layer.collective, "grid_reserve": layer.grid_reserve, "cu_reserve": layer.cu_reserve, "T": pb["T"],
             "gather_chunks": len(layer.gather_chunks(F)) if (layer.collective and exchange == "allgather"
                                                                and layer.gather_chunk_nodes != 0) else None,
@@ -591,7 +604,7 @@ def measure_hbm_only(args, N, Tl, F):
     nodes = N * (Tl // 2)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--nodes", str(nodes),
            "--slices-per-gpu", "2", "--deg", str(args.deg), "--feat", str(args.feat), "--band", str(args.band), "--no-epochs",
-           "--no-cpu-baseline", "--no-verify", "--no-measure-traffic", "--no-hbm-only", "--deadline", "400"]
+           "--no-cpu-baseline", "--no-verify", "--no-measure-traffic", "--no-hbm-only", "--no-skewed", "--deadline", "400"]
     env = {k: v for k, v in os.environ.items()
            if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCTX", "HSA_TOOLS_", "ROCPROFILER_"))}
     stage(f"hbm-only: child run at N={nodes}, 2 slices")
@@ -607,6 +620,42 @@ def measure_hbm_only(args, N, Tl, F):
     return {"nodes": nodes, "slices": 2, "gather_window_gb": round(nodes * F * 4 / 1e9, 2), "frac": cr["frac"], "achieved": cr["achieved"],
             "avg_launch_ms": cr["avg_launch_ms"], "edge_slices_per_launch": cr["edge_slices_per_launch"],
             "ms_per_step": round(c["ms_per_step"], 3), "steps": c["steps"]}
+
+
+def measure_skewed(args):
+    """The headline's graph gives every row exactly deg+1 entries.  The reference's real operand does not (read_data.py:116-127,
+    204-223: the M-product of symmetrised real graphs; its chess data has 13 % of the rows holding 59 % of the entries).  The same
+    layer, N, mean row length and uniform columns with capped-Zipf row lengths (synth.device_powerlaw_csr: a dozen rows of 100 000
+    entries per slice, a tenth of the rows holding 60 % of the entries) as a CHILD run of this script — 3 steps, its own verify
+    leg against the CPU oracle, no other legs — so that a profiler around this process sees the headline's launches only."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--nodes", str(args.nodes),
+           "--slices-per-gpu", str(args.slices_per_gpu), "--deg", str(args.deg), "--feat", str(args.feat), "--band", str(args.band),
+           "--graph", "powerlaw", "--no-epochs", "--no-cpu-baseline", "--no-measure-traffic", "--no-hbm-only", "--no-skewed",
+           "--verify-rows", str(args.verify_rows), "--deadline", "400"]
+    env = {k: v for k, v in os.environ.items()
+           if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCTX", "HSA_TOOLS_", "ROCPROFILER_"))}
+    stage("skewed: child run with --graph powerlaw")
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    except subprocess.TimeoutExpired:
+        return {"error": "the skewed-graph child run timed out"}
+    lines = [l for l in (r.stdout or "").splitlines() if l.startswith("{")]
+    if not lines:
+        return {"error": f"the skewed-graph child run exited {r.returncode}: {(r.stderr or '')[-300:]}"}
+    c = json.loads(lines[-1])
+    cr, v = c["roofline"], c.get("verify") or {}
+    return {"graph": "powerlaw: N, mean row length and uniform columns of S4, capped-Zipf row lengths (alpha 0.8, cap 100 000), long rows at "
+                     "random positions of every slice; the backward operand (the transpose) has Poisson row lengths and re-reads the "
+                     "hubs' rows of dY from cache",
+            "row_lengths": c["config"].get("row_lengths"), "bound": "hbm", "achieved": cr["achieved"], "peak": cr["peak"], "unit": cr["unit"],
+            "frac": cr["frac"], "frac_forward_only": cr["frac_forward_only"], "forward_launch_ms": cr["forward_launch_ms"],
+            "backward_launch_ms": cr["backward_launch_ms"], "bytes_per_edge_slice": cr["bytes_per_edge_slice"],
+            "edge_slices_per_launch": cr["edge_slices_per_launch"], "ms_per_step": round(c["ms_per_step"], 3), "steps": c["steps"],
+            "value": c["value"], "verify_ok": v.get("ok"), "verify": {k: v.get(k) for k in ("max_rel_err_Y", "max_rel_err_dX", "max_rel_err_dW", "seconds")},
+            "child_exit_code": r.returncode,
+            "frac_is": "the headline's formula (SURVEY §8d no-reuse bytes x edge-slices per launch / launch time / 8 TB/s) averaged over the "
+                       "forward (skewed rows) and backward launch; frac_forward_only = the launch that walks the skewed rows"}
 
 
 def hbm_only_fields(h, dom, F):
@@ -649,7 +698,7 @@ def measure_traffic(args):
     import pmc_traffic
     common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--nodes", str(args.nodes), "--slices-per-gpu", str(args.slices_per_gpu),
               "--deg", str(args.deg), "--feat", str(args.feat), "--band", str(args.band), "--no-epochs", "--no-cpu-baseline",
-              "--no-verify", "--no-measure-traffic", "--deadline", "400"]
+              "--no-verify", "--no-measure-traffic", "--no-hbm-only", "--no-skewed", "--no-compare-exchange", "--deadline", "400"]
     # a clean environment for the children: should THIS process itself run under a profiler, its preload /
     # tool variables must not leak into the nested rocprofv3 (which sets its own)
     env = {k: v for k, v in os.environ.items()
@@ -796,6 +845,9 @@ def worker(args):
     hbm_only = None
     if world == 1 and not collective and not args.no_hbm_only and Tl >= 4:
         hbm_only = measure_hbm_only(args, N, Tl, F)
+    skewed = None
+    if world == 1 and not collective and not args.no_skewed and args.graph == "er":
+        skewed = measure_skewed(args)
     if rank == 0:
         # the headline measurement, on stderr, BEFORE the side legs (exchange comparison, epochs, CPU baseline):
         # should one of those die, the record of the run's purpose survives in the log (the JSON line on
@@ -883,7 +935,8 @@ def worker(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S4 TM-GCN layer fwd+bwd: {Tl} slices/GPU (T={res['T']}), N={N}, "
-                                   f"deg={args.deg}+self, F={F}->{F}, band-M b={args.band}, fp32",
+                                   f"deg={args.deg}+self{'' if args.graph == 'er' else ' on average (' + args.graph + ' row lengths)'}, "
+                                   f"F={F}->{F}, band-M b={args.band}, fp32",
                        "exchange": args.exchange if res["collective"] else "none", "grid_reserve": res["grid_reserve"],
                        "cu_reserve": res["cu_reserve"],
                        "edge_slices_per_step": res["total_nnz"]},
@@ -911,6 +964,11 @@ def worker(args):
                      for ex, pl in plans.items()},
             "verify": res["verify"],
         }
+        if args.graph != "er":
+            out["config"]["graph"] = args.graph
+        out["config"]["row_lengths"] = res["row_stats"]
+        if skewed is not None:
+            out["roofline_skewed"] = skewed
         if res["gather_chunks"] is not None:
             out["config"]["gather_chunks"] = res["gather_chunks"]
         if ranks_info is not None:
@@ -936,6 +994,18 @@ def worker(args):
         if world == 1:  # the CPU legs are reported at N = 1 only
             if not args.no_epochs:
                 out["epochs"] = epochs_block(args)
+                # the four epoch times once more as FLAT top-level numbers (a driver that keeps only scalar keys keeps these):
+                # best mode, the untouched-script mode, and the CPU oracle's epoch
+                for name, rec in out["epochs"].items():
+                    if not isinstance(rec, dict) or "error" in rec:
+                        continue
+                    gpu = {k: v for k, v in rec.items() if k.startswith("gpu_ms_") and isinstance(v, float)}
+                    if gpu:
+                        out[f"epoch_ms_{name}"] = min(gpu.values())
+                    if "gpu_ms_script" in rec:
+                        out[f"epoch_ms_script_{name}"] = rec["gpu_ms_script"]
+                    if rec.get("cpu_ms") is not None:
+                        out[f"epoch_ms_cpu_{name}"] = rec["cpu_ms"]
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args)
     # RCCL prints its version banner through C stdio, which is flushed only at exit when stdout is

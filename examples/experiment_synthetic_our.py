@@ -64,7 +64,7 @@ def main():
     gcn = ehf.EmbeddingGCN2(Ahat, X, edges, M, hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False, nonlin2="selu")
     optimizer = torch.optim.SGD(gcn.parameters(), lr=lr, momentum=momentum)
     criterion = WeightedCrossEntropy(torch.tensor([alpha, 1.0 - alpha])).cuda()  # nn.CrossEntropyLoss(weight=...) works too
-    step = GraphedTrainStep(gcn, criterion, optimizer, target) if args.graph else None
+    step = GraphedTrainStep(gcn, criterion, optimizer, target, keep_logits=True) if args.graph else None   # the loop reads step.output
 
     torch.cuda.synchronize()
     tic = time.perf_counter()

@@ -44,13 +44,22 @@ typedef enum {
 /* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
 enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
 
-/* ABI version 4 = version 3 + tmgcn_head_loss_f32 / tmgcn_scale2_f32 (one-pass edge head + loss + gradients).
+/* ABI version 5 = version 4 + tmgcn_pool_stats; the launchers' scratch words (tile counters, hand-off blocks) are kept apart
+ *   per stream (eager launches) and per recorded launch (hipGraph capture), and a launcher that cannot keep two launches
+ *   apart returns TMGCN_ERR_INVALID with the reason instead of re-using a word that may be in flight (csrc/pools.hip).
+ * ABI version 4 = version 3 + tmgcn_head_loss_f32 / tmgcn_scale2_f32 (one-pass edge head + loss + gradients).
  * ABI version 3 = version 2 + tmgcn_mtransform_ld_f32 (column-window M-transform) + tmgcn_adj_mproduct_merge_* (segmented-merge M-product).
  * ABI version 2: no process-wide settings.  What used to be tmgcn_config_set() knobs are
  * per-call arguments (grid_reserve of tmgcn_spmm_gemm_f32, algo of tmgcn_gemm_dw_f32): two callers
  * in one process never see each other's choices. */
 int tmgcn_abi_version(void);
 const char* tmgcn_last_error(void);
+/* State of the library's scratch words on the current device (synchronises the device; diagnostics and tests):
+ *   out[0] streams that hold an eager slot (at most 64)      out[1] / out[4] tile counters handed to recorded launches / capacity
+ *   out[2] / out[5] hand-off blocks handed to recorded launches / capacity
+ *   out[3] int32 words of the hand-off blocks that are NOT zero while the device is idle (must be 0: every launch
+ *          leaves its block zero; anything else means a kernel died mid-flight or two launches shared a block) */
+int tmgcn_pool_stats(int64_t* out, int32_t n);
 
 /* algorithm of tmgcn_gemm_f32 (instruction choice only; both fp32-accurate and reproducible) */
 enum {

@@ -289,11 +289,9 @@ def _pack_sym(S, N):
             "slice_sum": sums}
 
 
-def g10():
-    """The reference's OWN preprocessing on the whole chess data set it ships — all 7 301 players, all 100
-    monthly slices, read_data.py's 'Chess' settings (edge life 10, 20 diagonals, symmetric; 80 / 10 / 10
-    train / val / test slices) — then experiment_chess_our.py's models on the 80-slice training block
-    (T = 80 > no_diag = 20: the band of M is truncated, which fixture G5 at T = 16 never was)."""
+def _chess_reference_setup(tag):
+    """The reference's own preprocessing of data/chess (read_data.py 'Chess' settings) and experiment_chess_our.py's
+    inputs, as a dict of the local names g10() and g11() use."""
     import time
     import warnings
     warnings.simplefilter("ignore")
@@ -321,7 +319,7 @@ def g10():
     C_val = env["func_create_sparse"](Cn, N, TT, T, S_val, T + S_val)
     Ct_train = env["func_MProduct"](C_train, torch.tensor(M))            # :225-227
     Ct_val = env["func_MProduct"](C_val, torch.tensor(M))
-    print(f"g10: reference preprocessing {time.time() - t0:.0f} s; nnz A {A._nnz()}, C {Cn._nnz()}, Ct_train {Ct_train._nnz()}")
+    print(f"{tag}: reference preprocessing {time.time() - t0:.0f} s; nnz A {A._nnz()}, C {Cn._nnz()}, Ct_train {Ct_train._nnz()}")
 
     def slices(S):       # experiment_chess_our.py:54-57 — per-slice matrices WITHOUT an explicit size (ehf:564)
         i, v = S._indices(), S._values()
@@ -342,6 +340,19 @@ def g10():
     eval_val = edges_val[0] >= S_train - S_val
     At_train, At_val = slices(Ct_train), slices(Ct_val)
     crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([.33, .33, .33]))     # experiment_chess_our.py:23, 99
+    return dict(locals())
+
+
+def g10():
+    """The reference's OWN preprocessing on the whole chess data set it ships — all 7 301 players, all 100
+    monthly slices, read_data.py's 'Chess' settings (edge life 10, 20 diagonals, symmetric; 80 / 10 / 10
+    train / val / test slices) — then experiment_chess_our.py's models on the 80-slice training block
+    (T = 80 > no_diag = 20: the band of M is truncated, which fixture G5 at T = 16 never was)."""
+    c = _chess_reference_setup("g10")
+    (TT, N, S_train, S_val, S_test, T, M, t_idx, raw, Cn, Ct_train, Ct_val, X, X_train, X_val, li, lv, sv, edges_train, target_train,
+     edges_val, eval_val, At_train, At_val, crit) = (c[k] for k in (
+        "TT", "N", "S_train", "S_val", "S_test", "T", "M", "t_idx", "raw", "Cn", "Ct_train", "Ct_val", "X", "X_train", "X_val", "li", "lv",
+        "sv", "edges_train", "target_train", "edges_val", "eval_val", "At_train", "At_val", "crit"))
     out = {}
     models = {
         "gcn": lambda: ehf.EmbeddingGCN(At_train, X_train, edges_train, torch.tensor(M), hidden_feat=[6, 3],
@@ -422,8 +433,52 @@ def g10():
          raw_label=raw[:, 2].astype(np.int8), **packed, **out)
 
 
+def g11():
+    """Long-horizon parity: experiment_chess_our.py's training loop (:108-123 — SGD lr .01 momentum .9, class-weighted CE,
+    the 2-layer model) run for 300 epochs on the full chess data from G10's seed with the REAL ehf.EmbeddingGCN2: the loss
+    of every epoch, the script's train / validation accuracy and validation loss at epochs 0 / 100 / 200 / 299 (its
+    `ep % 100 == 0` block, :117-123, plus the last epoch), the argmax class counts there, and the final W1 / W2 / U.
+    Inputs are G10's (tests/golden/g10_chess_full.npz holds the raw edges); this fixture stores outputs only."""
+    import time
+    c = _chess_reference_setup("g11")
+    torch.manual_seed(71)
+    m = ehf.EmbeddingGCN2(c["At_train"], c["X_train"], c["edges_train"], torch.tensor(c["M"]), hidden_feat=[6, 6, 3],
+                          condensed_W=True, use_Minv=False, nonlin2="selu")
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+    crit, target_train = c["crit"], c["target_train"]
+    target_val = (torch.sign(c["lv"][c["sv"]]) + 1).long()
+    ev = c["eval_val"]
+    n_ep = 300
+    losses, marks = [], []
+    t0 = time.time()
+    for ep in range(n_ep):
+        opt.zero_grad()
+        out = m()
+        loss = crit(out, target_train)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        if ep % 100 == 0 or ep == n_ep - 1:
+            with torch.no_grad():
+                guess = torch.argmax(out, dim=1)
+                acc_train = int(torch.sum(guess == target_train)) / len(guess)
+                out_val = m(c["At_val"], c["X_val"], c["edges_val"])        # AFTER the step, as the script does (:117)
+                gv = torch.argmax(out_val, dim=1)
+                acc_val = int(torch.sum(gv[ev] == target_val[ev])) / int(ev.sum())
+                loss_val = float(crit(out_val[ev], target_val[ev]))
+                marks.append([ep, acc_train, acc_val, loss_val] + torch.bincount(guess, minlength=3).tolist()
+                             + torch.bincount(gv[ev], minlength=3).tolist())
+            print(f"g11: ep {ep} loss {float(loss):.6f} acc_train {acc_train:.4f} acc_val {acc_val:.4f} loss_val {loss_val:.6f} "
+                  f"({time.time() - t0:.0f} s)")
+    save("g11_chess_train300", seed=71, epochs=n_ep, lr=0.01, momentum=0.9, losses=np.array(losses),
+         marks=np.array(marks, dtype=np.float64),
+         marks_columns=np.array(["epoch", "acc_train", "acc_val", "loss_val", "train_argmax_0", "train_argmax_1", "train_argmax_2",
+                                 "val_argmax_0", "val_argmax_1", "val_argmax_2"]),
+         **{f"{n}_final": p.detach().numpy().copy() for n, p in m.named_parameters()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:]
-    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g8", g8), ("g10", g10)):
+    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g4", g4), ("g5", g5), ("g6", g6), ("g8", g8), ("g10", g10), ("g11", g11)):
         if not which or name in which:
             fn()

@@ -35,9 +35,10 @@ int main(void) {
   const void* hg[2] = {0, 0};
   int64_t hn[2] = {4, 4};
 
-  if (tmgcn_abi_version() != 4) { printf("FAIL abi version %d\n", tmgcn_abi_version()); return 1; }
+  if (tmgcn_abi_version() != 5) { printf("FAIL abi version %d\n", tmgcn_abi_version()); return 1; }
   if (!tmgcn_last_error()) { printf("FAIL tmgcn_last_error() is NULL\n"); return 1; }
 
+  { int64_t st[6]; BAD(tmgcn_pool_stats(0, 6)); BAD(tmgcn_pool_stats(st, 5)); }             /* null / short output */
   /* P1 */
   BAD(tmgcn_mtransform_f32(0, 4, 4, 0, 0, 0, 4, 4, 3, 0, 0, 0, 16, 0, 0, 0));            /* null M / X / Y */
   BAD(tmgcn_mtransform_f32(0, -1, 4, 0, 0, 0, 4, 4, 3, 0, 0, 0, 16, 0, 0, 0));           /* negative T */

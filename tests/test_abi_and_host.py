@@ -41,7 +41,7 @@ def test_ctypes_table_matches_header():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.tmgcn_abi_version() == 4
+    assert lib.tmgcn_abi_version() == 5
     assert isinstance(lib.tmgcn_last_error(), bytes)
     # argument validation happens before any device work: callable without a GPU
     rc = lib.tmgcn_spmm_csr_batched_f32(None, None, None, None, None, 10, 3, 4, None)
@@ -188,7 +188,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     src = tmp_path / "abi.c"
     src.write_text('#include "tmgcn.h"\n#include <stdio.h>\n'
                    'int main(void) {\n'
-                   '  if (tmgcn_abi_version() != 4) return 1;\n'
+                   '  if (tmgcn_abi_version() != 5) return 1;\n'
                    '  if (tmgcn_spmm_gemm_supported(128, 128) != 1) return 2;\n'
                    '  if (tmgcn_gemm_f32(0, 0, 0, 0, 10, 0, 4, 0, 0, 0, 0, 0, 0) != TMGCN_ERR_INVALID) return 3;\n'
                    '  printf("%s\\n", tmgcn_last_error());\n  return 0;\n}\n')

@@ -23,6 +23,8 @@ def test_mat_link_prediction_example(layers):
     assert "summary: {" in out and '"logits_device": "cuda' in out and "test: MAP" in out
 
 
-def test_synthetic_example():
-    out = _run(os.path.join("examples", "experiment_synthetic_our.py"), "--epochs", "30")
+@pytest.mark.parametrize("extra", [(), ("--graph",)], ids=["eager", "hipgraph"])
+def test_synthetic_example(extra):
+    out = _run(os.path.join("examples", "experiment_synthetic_our.py"), "--epochs", "30", *extra)
     assert "adjacency pipeline on the device" in out
+    assert ("hipGraph replay" if extra else "eager") in out and "precision/recall/f1" in out

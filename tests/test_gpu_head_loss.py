@@ -236,6 +236,18 @@ def test_graphed_step_with_fused_loss_follows_the_eager_trajectory():
             assert_close(q3.detach(), q2.detach(), REL_TOL, "parameters after ten steps")
     with pytest.raises(ValueError):
         GraphedTrainStep(m2, WeightedCrossEntropy(w).cuda(), o2, tgt, steps_per_replay=0)
+    # the one-pass route keeps no logits: asking for them is an error that says so, never a silent None
+    with pytest.raises(RuntimeError, match="keep_logits"):
+        step.output
+    m4, o4 = make()
+    step4 = GraphedTrainStep(m4, WeightedCrossEntropy(w).cuda(), o4, tgt, warmup=3, keep_logits=True)
+    got4 = [float(step4()) for _ in range(7)]
+    assert_close(np.array(got4), d["losses"][3:], REL_TOL, "graph + fused loss + kept logits, steps 4-10")
+    assert step4.output.shape == (tgt.numel(), 2) and step4.output.device.type == "cuda"
+    # capturing the momentum-buffer-creating first step would reset the momentum on every replay: refused
+    m5, o5 = make()
+    with pytest.raises(ValueError, match="momentum"):
+        GraphedTrainStep(m5, WeightedCrossEntropy(w).cuda(), o5, tgt, warmup=0)
 
 
 @pytest.mark.parametrize("T,N,E", [(4, 30, 800), (6, 2000, 300)])       # dense entries / most rows without an entry

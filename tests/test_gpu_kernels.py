@@ -60,6 +60,98 @@ def test_spmm_long_rows_and_bitwise_reproducible():
     assert_close(Y1, ref_spmm(csr, X), REL_TOL, "hub row")
 
 
+def _csr_with_row_lengths(T, N, lengths, seed):
+    """CPU BatchedCSR with the given row lengths ({(slice, row): entries}, every other row 3 entries), random
+    columns (duplicates kept: they add up like uncoalesced COO entries in sparse.mm) and values."""
+    g = torch.Generator().manual_seed(seed)
+    cnt = torch.full((T * N,), 3, dtype=torch.int64)
+    for (k, i), n in lengths.items():
+        cnt[k * N + i] = n
+    rowptr = torch.zeros(T * N + 1, dtype=torch.int64)
+    torch.cumsum(cnt, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    col = torch.randint(0, N, (nnz,), generator=g, dtype=torch.int32)
+    val = torch.randn(nnz, generator=g) / cnt.repeat_interleave(cnt).float().sqrt()
+    return BatchedCSR(rowptr, col, val, T, N)
+
+
+LONG_ROW_CASES = {
+    # rows at and around the split threshold (256 entries, csrc/spmm_row.h) and its 64-entry quarters, several long rows in
+    # one tile, long rows in the last (ragged) tile of a slice, an empty row, and 10^4 / 10^5-entry hubs (tiles the blocks
+    # take first: > 8192 entries)
+    "threshold": (3, 1000, {(0, 0): 256, (0, 1): 257, (0, 2): 258, (0, 3): 320, (0, 64): 511, (0, 65): 512, (0, 66): 513,
+                            (1, 5): 1025, (1, 6): 0, (1, 7): 255, (2, 999): 700, (2, 998): 300, (2, 960): 4097, (1, 999): 257}),
+    "hubs": (2, 100_003, {(0, 17): 100_000, (0, 18): 10_000, (0, 4000): 300, (1, 100_002): 100_000, (1, 50_000): 65_536,
+                          (1, 50_001): 9_000, (1, 0): 20_000, (0, 99_968): 12_345}),
+    "one heavy tile of two": (1, 100, {(0, 70): 20_000}),
+}
+
+
+@pytest.mark.parametrize("case", list(LONG_ROW_CASES))
+@pytest.mark.parametrize("F", [64, 128, 256])
+def test_spmm_long_rows_split_across_waves(case, F):
+    """Rows longer than 256 entries are gathered by the four waves of their block (quarters of the row, partial sums added
+    in wave order) and tiles of more than 8192 entries are processed before the counter-driven loop starts
+    (csrc/spmm_row.h): against the C oracle's row-by-row sum, and reproducible to the bit."""
+    T, N, lengths = LONG_ROW_CASES[case]
+    if F == 256 and N > 10_000:
+        pytest.skip("the wide case is covered on the small shapes")
+    csr = _csr_with_row_lengths(T, N, lengths, seed=F + N)
+    X = torch.randn(T, N, F, generator=torch.Generator().manual_seed(2))
+    A = csr.to(DEV)
+    Y1 = ops.kernels.spmm(A, X.to(DEV))
+    ref = ref_spmm(csr, X)
+    assert_close(Y1, ref, REL_TOL, f"{case} F={F}")
+    rows = torch.tensor([k * N + i for (k, i) in lengths])
+    assert_close(Y1.reshape(T * N, F)[rows.to(DEV)], ref.reshape(T * N, F)[rows], REL_TOL, f"{case} F={F}: the special rows")
+    assert torch.equal(Y1, ops.kernels.spmm(A, X.to(DEV)))
+
+
+@pytest.mark.parametrize("case", list(LONG_ROW_CASES))
+@pytest.mark.parametrize("K,Nf,per_slice", [(128, 128, False), (64, 32, True), (16, 128, False)])
+def test_spmm_gemm_long_rows_split_across_waves(case, K, Nf, per_slice):
+    """The same rows through the fused kernel (its LDS tile is filled by the split too): SpMM intermediate and product
+    against the C oracle, the intermediate bit-equal to the plain kernel's (one row-sum order for both), reproducible."""
+    T, N, lengths = LONG_ROW_CASES[case]
+    csr = _csr_with_row_lengths(T, N, lengths, seed=K + N)
+    g = torch.Generator().manual_seed(K * 3 + Nf)
+    X = torch.randn(T, N, K, generator=g)
+    W = torch.randn(*((T, K, Nf) if per_slice else (K, Nf)), generator=g) * 0.2
+    A = csr.to(DEV)
+    Y, AX, _ = ops.kernels.spmm_gemm(A, X.to(DEV), W.to(DEV), want_ax=True)
+    ref_ax = ref_spmm(csr, X)
+    assert_close(AX, ref_ax, REL_TOL, f"{case}: SpMM intermediate")
+    assert_close(Y, ref_gemm(ref_ax, W, False, per_slice), REL_TOL, f"{case}: fused K={K} Nf={Nf}")
+    assert torch.equal(AX, ops.kernels.spmm(A, X.to(DEV))), "fused and plain kernels sum a row in different orders"
+    Y2, _, _ = ops.kernels.spmm_gemm(A, X.to(DEV), W.to(DEV))
+    assert torch.equal(Y, Y2)
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_layer_on_powerlaw_graph_vs_oracle(symmetric):
+    """The S4-shaped layer (F 128 -> 128) on synth.device_powerlaw_csr (capped-Zipf row lengths; the cap reaches N here):
+    forward and both gradients of ops.spmm_feature_gemm against the C oracle chain, fused and unfused."""
+    T, N, F = 2, 20_000, 128
+    csr = synth.device_powerlaw_csr(T, N, 32, "cpu", symmetric=symmetric)
+    cnt = csr.rowptr[1:] - csr.rowptr[:-1]
+    assert int(cnt.max()) > 5_000 and float(cnt.float().median()) < 40
+    g = torch.Generator().manual_seed(5)
+    X0, W0 = torch.rand(T, N, F, generator=g), torch.randn(F, F, generator=g) * 0.1
+    dY = torch.randn(T, N, F, generator=g)
+    ax = ref_spmm(csr, X0)
+    y_ref = ref_gemm(ax, W0)
+    dx_ref = ref_spmm(csr.transpose(), ref_gemm(dY, W0, trans_w=True))
+    dw_ref = (ax.double().reshape(-1, F).t() @ dY.double().reshape(-1, F)).float()
+    A = csr.to(DEV)
+    for fuse in (True, False):
+        X, W = X0.to(DEV).requires_grad_(True), W0.to(DEV).requires_grad_(True)
+        Y = ops.spmm_feature_gemm(A, X, W, fuse=fuse)
+        Y.backward(dY.to(DEV))
+        assert_close(Y.detach(), y_ref, REL_TOL, f"Y fuse={fuse}")
+        assert_close(X.grad, dx_ref, REL_TOL, f"dX fuse={fuse}")
+        assert_close(W.grad, dw_ref, REL_TOL, f"dW fuse={fuse}")
+
+
 def test_spmm_transpose_is_adjoint():
     T, N, F = 3, 120, 16
     csr = rand_csr(T, N, 6.0, seed=3).to(DEV)
@@ -606,6 +698,30 @@ def test_weighted_cross_entropy_matches_torch_fp64(E, C):
         WeightedCrossEntropy(torch.ones(9))(torch.randn(4, 9, device=DEV), torch.zeros(4, dtype=torch.long, device=DEV))
 
 
+
+def _oracle_layer12(H, W1, act1, A, W2, act2, dZ):
+    """The oracle's restatement of what ops.layer12 computes — layers 1 + 2 of the narrow models the reference's way
+    (ehf:330-335 then the default branch ehf:348-349; EmbeddingKWGCN ehf:486-487): fp32 H·W1, the non-linearity,
+    `.double()`, one fp64 sparse.mm per slice into an fp32 buffer (oracle.slice_spmm), fp32 ·W2, autograd for dW1 / dW2."""
+    from oracle import tmgcn_oracle as orc
+    At = A.to_coo_list(torch.float64)
+    w1, w2 = W1.detach().cpu().clone().requires_grad_(True), W2.detach().cpu().clone().requires_grad_(True)
+    Y = torch.matmul(H.detach().cpu(), w1)
+    Y = (orc.ACTS[act1](Y) if act1 else Y).double()
+    Z = torch.matmul(orc.slice_spmm(At, Y), w2)
+    Z = orc.ACTS[act2](Z) if act2 else Z
+    Z.backward(dZ.detach().cpu())
+    return Z.detach(), w1.grad, w2.grad
+
+
+def _assert_layer12_vs_oracle(got, H, W1, act1, A, W2, act2, dZ, tag):
+    for x, y, what in zip(got, _oracle_layer12(H, W1, act1, A, W2, act2, dZ), ("Z", "dW1", "dW2")):
+        if float(y.abs().max()) == 0.0:
+            assert float(x.abs().max()) == 0.0, f"{tag} {what}: the oracle's result is all zero"
+        else:
+            assert_close(x, y, REL_TOL, f"{tag} {what} vs the oracle")
+
+
 @pytest.mark.parametrize("T,N,nnz", [(1, 300, 0), (3, 256, 0), (1, 300, 5), (2, 256, 700), (3, 257, 900), (1, 256, 768),
                                      (5, 1024, 15360), (2, 255, 600), (1, 4096, 20000), (9, 513, 4617)])
 def test_layer12_edge_shapes(T, N, nnz):
@@ -625,11 +741,13 @@ def test_layer12_edge_shapes(T, N, nnz):
         Z = ops.layer12(H, a1, "selu", A, a2, None, fuse=fuse)
         Z.backward(dZ)
         outs.append((Z.detach(), a1.grad, a2.grad))
-    for x, y, what in zip(outs[0], outs[1], ("Z", "dW1", "dW2")):
+    for x, y, what in zip(outs[0], outs[1], ("Z", "dW1", "dW2")):      # the bit-level check: HIP fused vs HIP two-operator
         if float(y.abs().max()) == 0.0:
             assert float(x.abs().max()) == 0.0, what
         else:
             assert_close(x, y, 2e-6, what)
+    for o, tag in zip(outs, ("fused", "two-operator")):                # the parity check: each against the oracle
+        _assert_layer12_vs_oracle(o, H, W1, "selu", A, W2, None, dZ, tag)
 
 
 @pytest.mark.parametrize("act2", [None, "selu"])
@@ -664,13 +782,17 @@ def test_layer12_entry_major_kernels_on_skewed_rows(act2):
     assert_close(out[0][1], out[1][1], 2e-6, "dW1")
     assert_close(out[0][2], out[1][2], 2e-6, "dW2")
     assert all(torch.equal(x, y) for x, y in zip(out[0], out[2]))
+    _assert_layer12_vs_oracle(out[0], H, W1, "selu", A, W2, act2, dZ, "entry-major fused")
 
 
 @pytest.mark.parametrize("act1,act2", [("selu", None), ("relu", None), ("leaky", "relu"), (None, "selu")])
 @pytest.mark.parametrize("T,N,deg,F,Nf", [(5, 300, 3.0, 6, 6), (3, 77, 12.0, 6, 2), (4, 500, 0.4, 2, 6), (2, 64, 40.0, 8, 4),
                                           # staged variants (slice in LDS): several blocks per slice with a ragged last
                                           # chunk, many slices, and a slice just too large for them (72 KB)
-                                          (7, 1000, 27.0, 6, 6), (150, 200, 9.0, 6, 6), (2, 3000, 9.0, 6, 6)])
+                                          (7, 1000, 27.0, 6, 6), (150, 200, 9.0, 6, 6), (2, 3000, 9.0, 6, 6),
+                                          # at the 64 KB edge of the staged variants: the slice alone is exactly 64 KB / just
+                                          # under it, but slice + row-pointer slab + static arrays are not (unstaged kernels then)
+                                          (2, 2048, 9.0, 8, 8), (2, 2700, 9.0, 6, 6), (3, 2300, 9.0, 6, 6)])
 def test_layer12_fused_matches_the_two_operators(act1, act2, T, N, deg, F, Nf):
     """ops.layer12 (csrc/layer12.hip: layers 1 + 2 of the narrow 2-layer models in one launch each way) against
     feature_gemm followed by spmm_feature_gemm: the same Z to the last bit or two (same per-lane fmaf chains; a row's
@@ -697,6 +819,7 @@ def test_layer12_fused_matches_the_two_operators(act1, act2, T, N, deg, F, Nf):
     assert_close(Z.detach(), Zr.detach(), 2e-6, "Z")
     assert_close(a1.grad, b1.grad, 2e-6, "dW1")
     assert_close(a2.grad, b2.grad, 2e-6, "dW2")
+    _assert_layer12_vs_oracle((Z.detach(), a1.grad, a2.grad), H, W1, act1, A, W2, act2, dZ, "fused")
     c1, c2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
     ops.layer12(H, c1, act1, A, c2, act2, fuse=True).backward(dZ)
     assert torch.equal(c1.grad, a1.grad) and torch.equal(c2.grad, a2.grad)

@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tmgcn.h")
 ACT_IDS = {None: 0, "none": 0, "relu": 1, "leaky": 2, "selu": 3}
 DW_ALGOS = {None: 0, "auto": 0, "f32mfma": 1}   # TMGCN_DW_AUTO / TMGCN_DW_F32MFMA
 GEMM_ALGOS = {None: 0, "auto": 0, "f32mfma": 1}  # TMGCN_GEMM_AUTO / TMGCN_GEMM_F32MFMA
-ABI_VERSION = 4
+ABI_VERSION = 5
 SYNC_INTS = 272          # include/tmgcn.h: TMGCN_SYNC_INTS (a hand-off block of the last-block reductions)
 
 
@@ -30,6 +30,7 @@ _i64 = C.c_int64
 SIGNATURES = {
     "tmgcn_abi_version": (C.c_int, []),
     "tmgcn_last_error": (C.c_char_p, []),
+    "tmgcn_pool_stats": (C.c_int, [_p, _i32]),
     "tmgcn_mtransform_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_mtransform_ld_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
     "tmgcn_spmm_csr_batched_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),

@@ -18,18 +18,21 @@ inline int check_launch(const char* what) {
   return TMGCN_OK;
 }
 
-// Work counters for dynamically scheduled persistent kernels (pointwise.hip owns the pool).
+// Work counters for dynamically scheduled persistent kernels (pools.hip owns them).
 // Persistent blocks draw their next tile from a device counter instead of a static
 // blockIdx-strided assignment: when some blocks are not resident from the start (another
 // kernel — e.g. RCCL's all-to-all on a side stream — holds CUs), the late blocks simply draw
 // fewer tiles instead of serialising a full share behind the others; skewed row lengths balance
-// the same way.  acquire_tile_counter() returns a zeroed counter (memset enqueued on `stream`),
-// rotating through a pool so that launches in flight on different streams do not share one.
-unsigned int* acquire_tile_counters(hipStream_t stream, int n);  // n consecutive zeroed counters
+// the same way.  acquire_tile_counter() returns a zeroed counter (memset enqueued on `stream`) that no launch on
+// another stream, and no recorded launch of another hipGraph, shares (pools.hip); nullptr — with the reason in
+// pool_error() — when it cannot promise that.
+const char* pool_error();
+unsigned int* acquire_tile_counters(hipStream_t stream, int n);  // n <= 64 consecutive zeroed counters
 inline unsigned int* acquire_tile_counter(hipStream_t stream) { return acquire_tile_counters(stream, 1); }
 
 // A hand-off block (kSyncInts int32, last_block_ticket) for a kernel whose last block finishes a reduction
-// (pointwise.hip owns the pool): zero when the launch starts, left zero by the launch — no memset node per call.
+// (pools.hip): zero when the launch starts, left zero by the launch — no memset node per call.  One block per stream
+// for eager launches, one for good per recorded launch; nullptr (reason in pool_error()) when none can be given.
 int32_t* acquire_sync_word(hipStream_t stream);
 
 // Called by EVERY thread of a block after its slab stores (write-through: 4- / 8-byte relaxed agent-scope atomic

@@ -1358,7 +1358,7 @@ static int gemm_launch(const float* A, const void* W, bool w_bf16, float* Y, flo
   }
   // gy consecutive counters of the pool (acquire zeroes one; take gy of them in a row)
   a.tile_counter = acquire_tile_counters(st, (int)gy);
-  TMGCN_REQUIRE(a.tile_counter, "gemm: cannot set up the tile counters");
+  TMGCN_REQUIRE(a.tile_counter, "gemm: no tile counters: %s", pool_error());
   int64_t gx = persistent_grid(gemm_mfma_kernel, 256);
   if (gx > a.n_tiles) gx = a.n_tiles;
   hipLaunchKernelGGL(gemm_mfma_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, a);
@@ -1437,7 +1437,7 @@ static int gemm_dw_launch(const float* A, const float* dY, const float* pre, int
     a.act = act;
     a.n_batch = (int32_t)nb;
     a.sync = acquire_sync_word(st);
-    TMGCN_REQUIRE(a.sync, "gemm_dw: no hand-off word");
+    TMGCN_REQUIRE(a.sync, "gemm_dw: no hand-off block: %s", pool_error());
 #define TMGCN_DWN_L(KT_, NT_)                                                                          \
   if (pre) hipLaunchKernelGGL((gemm_dw_narrow_kernel<KT_, NT_, true>), dim3(gx), dim3(256), 0, st, a); \
   else hipLaunchKernelGGL((gemm_dw_narrow_kernel<KT_, NT_, false>), dim3(gx), dim3(256), 0, st, a);

@@ -499,7 +499,7 @@ extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t 
                 (long long)E, (long long)n_active);
   TMGCN_REQUIRE(Z && U && eptr && arow && other && meta && class_count && weight && workspace, "head_loss: null pointer");
   if (!sync) sync = acquire_sync_word((hipStream_t)stream);
-  TMGCN_REQUIRE(sync, "head_loss: no hand-off word");
+  TMGCN_REQUIRE(sync, "head_loss: no hand-off block: %s", pool_error());
   TMGCN_REQUIRE(!logits || ent, "head_loss: the logits need the entry -> edge index (ent)");
   TMGCN_REQUIRE((K == 0) == (W_fold == nullptr), "head_loss: W_fold must be given exactly when K > 0");
   const bool grad = dU != nullptr;

@@ -647,11 +647,6 @@ static int l12_lanes(float avg_nnz_per_row, bool staged) {
   return G;
 }
 
-// The staged variants (see the head of the file): LDS for one slice, at least 8 non-zeros per row to pay for forming it.
-constexpr int64_t kL12StageBytes = 64 << 10;
-static bool l12_staged(int64_t n_rows, int32_t N, int width, float avg_nnz_per_row) {
-  return avg_nnz_per_row >= 8.f && (int64_t)N * width * 4 <= kL12StageBytes && n_rows / N <= kL12MaxBlocks;
-}
 // blocks per slice: about 640 blocks in all (2.5 per CU; every block forms the whole slice in LDS first, so more blocks
 // means more of that), at least 64 rows each.  Captured AMLSim-shaped step (150 slices of 1 000 nodes, 27 per row), kernel
 // durations under rocprofv3: 4 blocks per slice 21.8 us forward / 23.2 backward, 6: 21.8 / 27.8, 2: 33.8 / 33.4.
@@ -659,6 +654,18 @@ static int l12_chunks(int64_t slices, int32_t N) {
   int64_t c = 640 / slices, most = (N + 63) / 64;
   if (c > most) c = most;
   return (int)(c < 1 ? 1 : c);
+}
+
+// The staged variants (see the head of the file): LDS for one slice, at least 8 non-zeros per row to pay for forming it.
+// Everything the launch asks for has to fit the 64 KB a block gets without hipFuncSetAttribute: the slice ([N][width]
+// floats), the block's row-pointer slab ((chunk_rows + 1) int64) and the kernels' static arrays (the backward's fp64
+// reduction scratch; 4 KB covers every instantiation).  A slice that does not fit takes the unstaged / entry-major kernels.
+constexpr int64_t kL12LdsLimit = 64 << 10, kL12StaticLds = 4 << 10;
+static bool l12_staged(int64_t n_rows, int32_t N, int width, float avg_nnz_per_row) {
+  if (!(avg_nnz_per_row >= 8.f) || n_rows / N > kL12MaxBlocks) return false;
+  const int chunks = l12_chunks(n_rows / N, N);
+  const int64_t chunk_rows = (N + chunks - 1) / chunks;
+  return (int64_t)N * width * 4 + (chunk_rows + 1) * 8 + kL12StaticLds <= kL12LdsLimit;
 }
 
 template <int F, int NT, bool BWD, bool STAGED>
@@ -802,7 +809,7 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
   hipStream_t st = (hipStream_t)stream;
   L12Args a{t_rowptr, t_col, t_val, H, W1, W2, dZ, pre2, nullptr, nullptr, nullptr, dW1, (float*)workspace,
             acquire_sync_word(st), n_rows, N, act1, act2, 0, 0};
-  TMGCN_REQUIRE(a.sync, "layer12_bwd: no hand-off word");
+  TMGCN_REQUIRE(a.sync, "layer12_bwd: no hand-off block: %s", pool_error());
   const bool staged = l12_staged(n_rows, N, Nf, avg_nnz_per_row);
   const int G = l12_lanes(avg_nnz_per_row, staged);
   if (staged) {

@@ -642,7 +642,7 @@ static int dispatch(MtArgs a, hipStream_t st) {
     }
     a.tile_counter = acquire_tile_counters(st, (int)gy);
     if (!a.tile_counter) {
-      set_error("mtransform: cannot set up the tile counters");
+      set_error("mtransform: no tile counters: %s", pool_error());
       return TMGCN_ERR_LAUNCH;
     }
     if (a.T_in <= 128) {

@@ -2,66 +2,11 @@
 // 486) and the library's error plumbing.  Pure HBM streams: 16 B per lane.
 #include <stdarg.h>
 #include <string.h>
-#include <atomic>
 #include "common.h"
 
 namespace tmgcn {
 
 static thread_local char g_err[512] = "";
-
-constexpr int kCounterPool = 4096;  // 64 groups of 64: launches in flight on different streams never share a group
-constexpr int kMaxDevices = 16;
-__device__ unsigned int g_tile_counters[kCounterPool];
-
-
-unsigned int* acquire_tile_counters(hipStream_t stream, int n) {
-  if (n < 1 || n > 64) return nullptr;
-  static unsigned int* base[kMaxDevices] = {nullptr};
-  static std::atomic<unsigned> next{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= kMaxDevices) dev = 0;
-  if (!base[dev]) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tile_counters)) != hipSuccess) return nullptr;
-    base[dev] = static_cast<unsigned int*>(p);
-  }
-  // slots are handed out in aligned groups of 64 so that n consecutive counters never wrap
-  unsigned int* c = base[dev] + (next.fetch_add(1) % (kCounterPool / 64)) * 64;
-  if (hipMemsetAsync(c, 0, sizeof(unsigned int) * n, stream) != hipSuccess) return nullptr;
-  return c;
-}
-
-// Hand-off words of the kernels whose LAST block finishes a reduction (head_loss, the narrow dW): a word is zero
-// when a launch starts and the launch leaves it zero, so no memset node precedes the kernel.  Launches in
-// flight at the same time must not share a word: eager launches walk the lower half of the pool round-robin (two
-// of them would have to be 1024 launches apart and still overlap), launches recorded into a hipGraph take a word of
-// the upper half for good (a replayed graph meets only its own words).
-constexpr int kSyncPool = 2048;
-__device__ int g_sync_words[kSyncPool * kSyncInts];
-
-int32_t* acquire_sync_word(hipStream_t stream) {
-  static int32_t* base[kMaxDevices] = {nullptr};
-  static std::atomic<unsigned> next_eager{0}, next_captured{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= kMaxDevices) dev = 0;
-  if (!base[dev]) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sync_words)) != hipSuccess) return nullptr;
-    base[dev] = static_cast<int32_t*>(p);
-  }
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) {
-    (void)hipGetLastError();
-    cs = hipStreamCaptureStatusNone;
-  }
-  if (cs == hipStreamCaptureStatusActive) {
-    const unsigned k = next_captured.fetch_add(1);
-    return base[dev] + (int64_t)(kSyncPool / 2 + (k % (kSyncPool / 2))) * kSyncInts;   // > 1024 recorded launches: wraps (documented limit)
-  }
-  return base[dev] + (int64_t)(next_eager.fetch_add(1) % (kSyncPool / 2)) * kSyncInts;
-}
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -196,7 +141,7 @@ static unsigned stream_grid(int64_t n) {
 
 using namespace tmgcn;
 
-extern "C" int tmgcn_abi_version(void) { return 4; }
+extern "C" int tmgcn_abi_version(void) { return 5; }
 
 extern "C" const char* tmgcn_last_error(void) { return g_err; }
 

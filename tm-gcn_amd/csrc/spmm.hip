@@ -20,9 +20,6 @@
 #ifndef TMGCN_SPMM_U
 #define TMGCN_SPMM_U 4      // gathers in flight per lane (F >= 64)
 #endif
-#ifndef TMGCN_SPMM_RPB
-#define TMGCN_SPMM_RPB 64   // rows per 256-thread block
-#endif
 
 namespace tmgcn {
 
@@ -31,33 +28,59 @@ namespace tmgcn {
 // streams per wave.  A wave owns one row at a time; the row's (col,val) pairs are
 // fetched 64 at a time with one coalesced load per array and handed to the streams
 // with ds_bpermute (__shfl); each stream gathers whole X rows as 16-B loads, U of
-// them in flight per lane.
+// them in flight per lane.  Rows of more than kLongRow entries are shared by the block's four
+// waves, and the heaviest tiles are taken first (spmm_row.h).
 // ---------------------------------------------------------------------------------
 template <int LPR, int U>
 __global__ __launch_bounds__(256) void spmm_vec4_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float4* __restrict__ X, float4* __restrict__ Y,
-    int64_t n_rows, int32_t N, int32_t F4, int32_t rows_per_block, unsigned int* tile_counter) {
+    int64_t n_rows, int32_t N, int32_t F4, unsigned int* tile_counter) {
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   __shared__ unsigned int s_tile;
-  const int64_t n_tiles = (n_rows + rows_per_block - 1) / rows_per_block;
+  __shared__ float4 s_part[4 * LPR];      // partial sums of a long row, one per wave (spmm_row.h)
+  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+  const TileMap tm{n_rows, n_rows, n_tiles, n_tiles};
+  HeavyScan heavy;
+  heavy.init(rowptr, tm);
+  bool scanning = true;
   for (;;) {
-    // persistent blocks draw 64-row tiles from a device counter (ascending: resident blocks stay
-    // inside one slice of X); see common.h
-    __syncthreads();
-    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
-    __syncthreads();
-    const int64_t tile = s_tile;
-    if (tile >= n_tiles) break;
-    const int64_t r_begin = tile * rows_per_block;
-    int64_t r_end = r_begin + rows_per_block;
+    // this block's share of the heavy tiles first (spmm_row.h); then persistent blocks draw 64-row tiles from a
+    // device counter (ascending: resident blocks stay inside one slice of X); see common.h
+    int64_t tile = -1;
+    if (scanning) {
+      tile = heavy.next(rowptr, tm, lane);
+      scanning = tile >= 0;
+    }
+    if (!scanning) {
+      __syncthreads();
+      if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
+      __syncthreads();
+      tile = s_tile;
+      if (tile >= n_tiles) break;
+    }
+    const int64_t r_begin = tile * kTileRows;
+    int64_t r_end = r_begin + kTileRows;
     if (r_end > n_rows) r_end = n_rows;
-    for (int64_t r = r_begin + wave; r < r_end; r += 4) {
+    TileRows rows;
+    rows.load(rowptr, r_begin, r_end, lane);
+    if (TMGCN_HEAVY_FIRST && !scanning && rows.entries > heavy.thr) continue;   // done in somebody's pass 1
+    for (int rr = wave; rr < (int)(r_end - r_begin); rr += 4) {
+      if ((rows.long_mask >> rr) & 1) continue;
+      const int64_t r = r_begin + rr;
       const int64_t slice = r / N;
-      const float4 acc = gather_row<LPR, U>(col, val, X + slice * (int64_t)N * F4, rowptr[r],
-                                            rowptr[r + 1], F4, lane);
+      const float4 acc = gather_row<LPR, U>(col, val, X + slice * (int64_t)N * F4, readlane64(rows.beg, rr),
+                                            readlane64(rows.end, rr), F4, lane);
       if (lane < LPR && lane < F4) store_f4(&Y[r * F4 + lane], acc);
+    }
+    for (uint64_t m = rows.long_mask; m; m &= m - 1) {          // long rows: all four waves on each
+      const int rr = __builtin_ctzll(m);
+      const int64_t r = r_begin + rr;
+      const int64_t slice = r / N;
+      const float4 acc = gather_long_row<LPR, U>(col, val, X + slice * (int64_t)N * F4, readlane64(rows.beg, rr),
+                                                 readlane64(rows.end, rr), F4, lane, wave, s_part);
+      if (wave == (rr & 3) && lane < LPR && lane < F4) store_f4(&Y[r * F4 + lane], acc);
     }
   }
 }
@@ -215,11 +238,10 @@ extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int3
     const int F4 = F / 4;
     int lpr = 4;
     while (lpr < F4) lpr <<= 1;
-    const int rows_per_block = TMGCN_SPMM_RPB;
-    const int64_t n_tiles = (n_rows + rows_per_block - 1) / rows_per_block;
+    const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
     TMGCN_REQUIRE(n_tiles < (int64_t)0x7fffffff, "spmm: too many row tiles");
     unsigned int* counter = acquire_tile_counter(st);
-    TMGCN_REQUIRE(counter, "spmm: cannot set up the tile counter");
+    TMGCN_REQUIRE(counter, "spmm: no tile counter: %s", pool_error());
     const float4* X4 = reinterpret_cast<const float4*>(X);
     float4* Y4 = reinterpret_cast<float4*>(Y);
 #define TMGCN_VEC_CASE(L, UU)                                                                \
@@ -227,7 +249,7 @@ extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int3
     int64_t gx = 2 * (int64_t)persistent_grid(spmm_vec4_kernel<L, UU>, 256);                 \
     if (gx > n_tiles) gx = n_tiles;                                                          \
     hipLaunchKernelGGL((spmm_vec4_kernel<L, UU>), dim3((unsigned)gx), dim3(256), 0, st,      \
-                       rowptr, col, val, X4, Y4, n_rows, N, F4, rows_per_block, counter);    \
+                       rowptr, col, val, X4, Y4, n_rows, N, F4, counter);                    \
     break;                                                                                   \
   }
     switch (lpr) {

@@ -58,29 +58,45 @@ struct FusedArgs {
 template <int LPR, int U, int NJ>  // NJ = K / 8 (K is a multiple of 8 here)
 __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedArgs a) {
   __shared__ float As[FBM * FLDA];
+  __shared__ float4 s_part[4 * LPR];      // partial sums of a long row, one per wave (spmm_row.h)
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 31;
   const int lh = lane >> 5;
   const int F4 = a.K / 4;
   constexpr int nj = NJ;
   const int n0 = wave * 32;
-  const int64_t batch_rows = a.rows_per_batch ? a.rows_per_batch : a.n_rows;
+  const TileMap tm{a.n_rows, a.rows_per_batch ? a.rows_per_batch : a.n_rows, a.tiles_per_batch, a.n_tiles};
 
   float wreg[NJ][4];
   int64_t cur_batch = -1;
   __shared__ unsigned int s_tile;
+  HeavyScan heavy;
+  heavy.init(a.rowptr, tm);
+  bool scanning = true;
 
   for (;;) {
-    // next tile from the device counter (ascending, so resident blocks stay inside one slice)
-    if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter, 1u);
-    __syncthreads();
-    const int64_t tile = s_tile;
-    if (tile >= a.n_tiles) break;
-    const int64_t batch = tile / a.tiles_per_batch;
-    const int64_t row0 = batch * batch_rows + (tile % a.tiles_per_batch) * FBM;
-    int64_t row_end = (batch + 1) * batch_rows;
-    if (row_end > a.n_rows) row_end = a.n_rows;
+    // next tile: first this block's share of the heavy tiles (spmm_row.h), then from the device counter
+    // (ascending, so resident blocks stay inside one slice)
+    int64_t tile = -1;
+    if (scanning) {
+      tile = heavy.next(a.rowptr, tm, lane);
+      scanning = tile >= 0;
+    }
+    if (!scanning) {
+      if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter, 1u);
+      __syncthreads();
+      tile = s_tile;
+      if (tile >= a.n_tiles) break;
+    }
+    int64_t batch, row0, row_end;
+    tile_extent(tm, tile, batch, row0, row_end);
+    TileRows rows;
+    rows.load(a.rowptr, row0, row_end, lane);
+    if (TMGCN_HEAVY_FIRST && !scanning && rows.entries > heavy.thr) {   // done in somebody's pass 1
+      __syncthreads();                                                 // (s_tile is rewritten at the top)
+      continue;
+    }
 
     if (batch != cur_batch) {
       const float* Wb = a.W + (a.rows_per_batch ? batch * a.w_batch_stride : 0);
@@ -98,18 +114,30 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
       cur_batch = batch;
     }
 
-    // ---- phase 1: gather 16 rows per wave into the LDS tile
+    // ---- phase 1: gather 16 rows per wave into the LDS tile; long rows afterwards, on all four waves
     for (int rr = wave; rr < FBM; rr += 4) {
       const int64_t r = row0 + rr;
+      const bool lng = (rows.long_mask >> rr) & 1;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < row_end) {
+      if (r < row_end && !lng) {
         const int64_t slice = r / a.N;
-        acc = gather_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, a.rowptr[r],
-                                 a.rowptr[r + 1], F4, lane);
+        acc = gather_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, readlane64(rows.beg, rr),
+                                 readlane64(rows.end, rr), F4, lane);
       }
-      if (lane < LPR && lane < F4) {
+      if (!lng && lane < LPR && lane < F4) {
         *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
         if (a.AX && r < row_end) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
+      }
+    }
+    for (uint64_t m = rows.long_mask; m; m &= m - 1) {
+      const int rr = __builtin_ctzll(m);
+      const int64_t r = row0 + rr;
+      const int64_t slice = r / a.N;
+      const float4 acc = gather_long_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, readlane64(rows.beg, rr),
+                                                 readlane64(rows.end, rr), F4, lane, wave, s_part);
+      if (wave == (rr & 3) && lane < LPR && lane < F4) {
+        *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
+        if (a.AX) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
       }
     }
     __syncthreads();
@@ -276,7 +304,7 @@ extern "C" int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* co
   a.n_tiles = nb * a.tiles_per_batch;
   TMGCN_REQUIRE(a.n_tiles < (int64_t)0x7fffffff, "spmm_gemm: too many row tiles");
   a.tile_counter = acquire_tile_counter((hipStream_t)stream);
-  TMGCN_REQUIRE(a.tile_counter, "spmm_gemm: cannot set up the tile counter");
+  TMGCN_REQUIRE(a.tile_counter, "spmm_gemm: no tile counter: %s", pool_error());
   // persistent blocks: up to 4 per CU (LDS 33.8 KB each); tiles are dealt round-robin so the
   // blocks resident at any moment work on neighbouring rows of the same slice
   hipStream_t st = (hipStream_t)stream;

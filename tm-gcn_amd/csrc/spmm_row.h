@@ -69,4 +69,125 @@ __device__ __forceinline__ float4 gather_row(const int32_t* __restrict__ col,
   return acc;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Skewed row lengths (the reference's real operand is the M-product of symmetrised real graphs, read_data.py:116-127,
+// 204-223: a few rows hold most of the entries).  Two measures, shared by the plain and the GEMM-fused kernel, neither
+// needs a plan or an atomic and both keep every row sum in a fixed order:
+//   * a row longer than kLongRow entries is gathered by ALL FOUR waves of the block — consecutive quarters of its
+//     entry range (a multiple of 64 each), the four partial sums added in wave order through LDS — instead of
+//     keeping one wave busy while the tile's other rows and the block's MFMA phase wait for it;
+//   * tiles with more than max(kHeavyMin, 8x the launch's mean) entries are taken FIRST: before a block starts
+//     drawing tiles from the launch's counter it scans the extents of tiles blockIdx.x, blockIdx.x + grid, ... (64 per
+//     coalesced load) and processes the heavy ones it finds; the counter-driven loop then skips them (same predicate,
+//     recomputed from the row extents it loads anyway).  A 100 000-entry hub — milliseconds even on four waves —
+//     therefore runs at the start of the launch, under everything else, never as its tail.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef TMGCN_LONG_ROW
+#define TMGCN_LONG_ROW 256
+#endif
+#ifndef TMGCN_HEAVY_FIRST
+#define TMGCN_HEAVY_FIRST 1
+#endif
+constexpr int kTileRows = 64;                 // rows per tile of both kernels
+constexpr int kLongRow = TMGCN_LONG_ROW;
+constexpr int64_t kHeavyMin = 8192;
+
+__device__ __forceinline__ int64_t readlane64(int64_t v, int l) {   // l wave-uniform
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffff), l);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+  return ((int64_t)hi << 32) | lo;
+}
+
+// tile -> rows: tiles restart at every batch (one W per slice) or run over all rows (tiles_per_batch = n_tiles)
+struct TileMap {
+  int64_t n_rows, batch_rows, tiles_per_batch, n_tiles;
+};
+__device__ __forceinline__ void tile_extent(const TileMap& m, int64_t tile, int64_t& batch, int64_t& row0, int64_t& row_end) {
+  batch = tile / m.tiles_per_batch;
+  row0 = batch * m.batch_rows + (tile - batch * m.tiles_per_batch) * kTileRows;
+  row_end = (batch + 1) * m.batch_rows;
+  if (row_end > m.n_rows) row_end = m.n_rows;
+}
+
+// Pass 1 of a block: its share of the heavy tiles, found 64 extents at a time.  All state is block-uniform (every wave
+// computes the same ballots from the same loads).
+struct HeavyScan {
+  int64_t thr, base, win;
+  uint64_t pending;
+  __device__ __forceinline__ void init(const int64_t* __restrict__ rowptr, const TileMap& m) {
+    const int64_t mean = (rowptr[m.n_rows] - rowptr[0]) / m.n_tiles;
+    thr = 8 * mean > kHeavyMin ? 8 * mean : kHeavyMin;
+    base = TMGCN_HEAVY_FIRST ? (int64_t)blockIdx.x : m.n_tiles;
+    win = 0;
+    pending = 0;
+  }
+  __device__ __forceinline__ int64_t next(const int64_t* __restrict__ rowptr, const TileMap& m, int lane) {   // -1: done
+    while (pending == 0) {
+      if (base >= m.n_tiles) return -1;
+      const int64_t t = base + (int64_t)lane * gridDim.x;
+      int64_t ent = 0;
+      if (t < m.n_tiles) {
+        int64_t b, r0, r1;
+        tile_extent(m, t, b, r0, r1);
+        if (r0 + kTileRows < r1) r1 = r0 + kTileRows;
+        ent = rowptr[r1] - rowptr[r0];
+      }
+      pending = __ballot(ent > thr);
+      win = base;
+      base += (int64_t)kWave * gridDim.x;
+    }
+    const int l = __builtin_ctzll(pending);
+    pending &= pending - 1;
+    return win + (int64_t)l * gridDim.x;
+  }
+};
+
+// Extents of the tile's rows, one coalesced load pair per wave: lane l holds row row0 + l (empty past row_end).
+struct TileRows {
+  int64_t beg, end;
+  uint64_t long_mask;   // rows with more than kLongRow entries
+  int64_t entries;      // of the whole tile
+  __device__ __forceinline__ void load(const int64_t* __restrict__ rowptr, int64_t row0, int64_t row_end, int lane) {
+    const int64_t r = row0 + lane;
+    beg = 0;
+    end = 0;
+    if (r < row_end) {
+      beg = rowptr[r];
+      end = rowptr[r + 1];
+    }
+    long_mask = __ballot(end - beg > kLongRow);
+    const int last = (int)((row_end - row0 < kTileRows ? row_end - row0 : kTileRows) - 1);
+    entries = readlane64(end, last) - readlane64(beg, 0);
+  }
+};
+
+// A long row on four waves: wave w gathers quarter w, the partial sums meet in `part` ([4][LPR] float4 of LDS) and
+// lanes < LPR of EVERY wave return ((p0 + p1) + p2) + p3.  Called by all 256 threads; two block barriers.
+template <int LPR, int U>
+__device__ __forceinline__ float4 gather_long_row(const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                  const float4* __restrict__ Xs, int64_t beg, int64_t end, int F4, int lane,
+                                                  int wave, float4* part) {
+  const int64_t q = (((end - beg + 3) >> 2) + (kWave - 1)) & ~(int64_t)(kWave - 1);
+  int64_t b = beg + wave * q, e = b + q;
+  if (b > end) b = end;
+  if (e > end) e = end;
+  const float4 p = gather_row<LPR, U>(col, val, Xs, b, e, F4, lane);
+  if (lane < LPR) part[wave * LPR + lane] = p;
+  __syncthreads();
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < LPR) {
+    s = part[lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 t = part[w * LPR + lane];
+      s.x += t.x;
+      s.y += t.y;
+      s.z += t.z;
+      s.w += t.w;
+    }
+  }
+  __syncthreads();
+  return s;
+}
+
 }  // namespace tmgcn

@@ -6,7 +6,7 @@ asynchronous, allocation-free and sync-free, so the whole step captures into one
 
     step = GraphedTrainStep(gcn, criterion, optimizer, target)
     for ep in range(no_epochs):
-        loss = step()            # replays; `step.output` holds the logits of that step (if kept)
+        loss = step()            # replays; with keep_logits=True `step.output` holds the logits of that step
 
 What keeps the launch count down (rocprofv3 --kernel-trace of an S1 step: profiles/):
   * `fused_loss=True` (default when the model offers it): `gcn.loss(criterion, target)` — the edge head,
@@ -40,6 +40,12 @@ class GraphedTrainStep:
         from . import ops
         self.fused = bool(fused_loss) and hasattr(model, "loss")
         self.keep_logits = keep_logits or not self.fused
+        # The first step of a momentum optimizer CREATES its buffers (buf = g): captured, every replay would restart the
+        # momentum.  So at least one eager step must precede the capture whenever such state is still missing.
+        if warmup < 1 and any(g.get("momentum", 0) != 0 and any(p.requires_grad and "momentum_buffer" not in optimizer.state.get(p, {})
+                                                                 for p in g["params"]) for g in optimizer.param_groups):
+            raise ValueError("GraphedTrainStep: warmup=0 with a momentum optimizer whose buffers do not exist yet — the capture "
+                             "would record the buffer-creating first step and every replay would reset the momentum")
         # fold_optimizer: loss, gradients AND the SGD update in one launch where the model / optimizer pair allows it (the
         # folded 1-layer model with FusedSGD: layers.fused_train_step) — the whole step of the Reddit-LP config is one kernel
         self.folded = False
@@ -85,14 +91,23 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             for i in range(self.steps_per_replay):
                 if self.folded:
-                    self.loss, self.output = one_step()
+                    self.loss, self._output = one_step()
                 else:
                     if i:
                         optimizer.zero_grad(set_to_none=True)      # host side only: the next backward writes fresh gradients
-                    self.loss, self.output = forward_loss()
+                    self.loss, self._output = forward_loss()
                     self.loss.backward(gradient=self._one)
                     optimizer.step()
                 self.losses.append(self.loss)
+
+    @property
+    def output(self) -> torch.Tensor:
+        """Logits of the last captured step (overwritten by every replay).  Only with keep_logits=True: the one-pass
+        head + loss route never materialises them."""
+        if self._output is None:
+            raise RuntimeError("GraphedTrainStep.output: the logits were not kept (the fused head + loss launch does not "
+                               "materialise them); construct the step with keep_logits=True")
+        return self._output
 
     def __call__(self) -> torch.Tensor:
         """One replay = `steps_per_replay` epochs.  Returns the loss of the last of them (a tensor the next replay

@@ -248,3 +248,82 @@ def device_normal(T: int, N: int, F: int, device, first_slice: int = 0, salt: in
         g.manual_seed(104729 * (first_slice + k) + 31 * salt + 5)
         Y[k].normal_(0.0, 1.0, generator=g)
     return Y
+
+
+# ---------------------------------------------------------------------------------------
+# S4 with skewed degrees: the shape of the reference's REAL operand
+# ---------------------------------------------------------------------------------------
+# The reference's adjacency is the M-product of up to 20 symmetrised, edge-life-windowed slices of a
+# real graph (read_data.py:88-127, 204-223): its one shipped data set (chess) has half its rows at one
+# entry and 13 % of the rows holding 59 % of the entries.  device_er_csr gives every row exactly deg+1
+# entries — the kernels' best case.  This generator keeps N, the mean row length and the uniform random
+# columns of S4 and draws the row lengths from a capped Zipf law instead.
+_POWERLAW_CACHE: dict = {}
+
+
+def powerlaw_degrees(N: int, mean_deg: float, alpha: float = 0.8, hub_cap: int = 100_000) -> np.ndarray:
+    """Out-degrees (self loop not counted) of N rows, descending: floor(min(c · rank^-alpha, cap)) with c
+    solved by bisection so that they sum to about mean_deg · N; cap = min(hub_cap, N).  With the defaults
+    at N = 2 M / mean 32: a handful of rows at the 100 000 cap, ~10 % of the rows holding ~60 % of the
+    entries, the shortest rows at 7."""
+    key = (N, float(mean_deg), float(alpha), int(hub_cap))
+    if key not in _POWERLAW_CACHE:
+        cap = float(min(hub_cap, N))
+        w = np.arange(1, N + 1, dtype=np.float64) ** (-alpha)
+        target = mean_deg * N
+        lo, hi = 0.0, max(1.0, target / w[-1])
+        for _ in range(80):
+            c = 0.5 * (lo + hi)
+            if np.minimum(c * w, cap).sum() < target:
+                lo = c
+            else:
+                hi = c
+        _POWERLAW_CACHE[key] = np.floor(np.minimum(hi * w, cap)).astype(np.int64)
+    return _POWERLAW_CACHE[key]
+
+
+def device_powerlaw_csr(T: int, N: int, deg: int, device, first_slice: int = 0, alpha: float = 0.8,
+                        hub_cap: int = 100_000, symmetric: bool = False) -> BatchedCSR:
+    """T slices with the mean row length of device_er_csr (deg random neighbours + the self loop) but
+    capped-Zipf row lengths (powerlaw_degrees), the long rows at random positions of every slice, columns
+    uniform, duplicates kept, values 1/row length, columns sorted inside each row.  Slice k is seeded
+    with first_slice + k.
+    symmetric=False  skewed OUT-degree only: the transposed operand (backward) has Poisson row lengths
+    symmetric=True   each random pair stored both ways, as the reference's symmetrised slices are
+                     (read_data.py:88-111): hub rows are hub columns, forward and backward both skewed"""
+    base = powerlaw_degrees(N, deg / 2 if symmetric else deg, alpha, hub_cap)
+    base_d = torch.from_numpy(base).to(device)
+    g = torch.Generator(device=device)
+    ar = torch.arange(N, device=device, dtype=torch.int64)
+    rowptrs, cols, vals = [], [], []
+    off = 0
+    for k in range(T):
+        g.manual_seed(2000003 * (first_slice + k) + 29)
+        d = base_d[torch.randperm(N, generator=g, device=device)]
+        r = torch.repeat_interleave(ar, d)
+        c = torch.randint(0, N, (int(r.numel()),), generator=g, device=device, dtype=torch.int64)
+        if symmetric:
+            r, c = torch.cat([r, c, ar]), torch.cat([c, r, ar])
+        else:
+            r, c = torch.cat([r, ar]), torch.cat([c, ar])
+        key = torch.sort(r * N + c).values
+        del r, c
+        r = key // N
+        cols.append((key - r * N).to(torch.int32))
+        cnt = torch.bincount(r, minlength=N)
+        del key, r
+        vals.append(torch.repeat_interleave(1.0 / cnt.to(torch.float32), cnt))
+        rp = torch.cumsum(cnt, 0) + off
+        rowptrs.append(rp)
+        off = int(rp[-1])
+    rowptr = torch.cat([torch.zeros(1, dtype=torch.int64, device=device)] + rowptrs)
+    return BatchedCSR(rowptr, torch.cat(cols), torch.cat(vals), T, N)
+
+
+def device_csr(kind: str, T: int, N: int, deg: int, device, first_slice: int = 0) -> BatchedCSR:
+    """The S4 adjacency by name: "er" (the headline), "powerlaw", "powerlaw_sym"."""
+    if kind == "er":
+        return device_er_csr(T, N, deg, device, first_slice)
+    if kind in ("powerlaw", "powerlaw_sym"):
+        return device_powerlaw_csr(T, N, deg, device, first_slice, symmetric=kind == "powerlaw_sym")
+    raise ValueError(f"unknown graph kind {kind!r}")

@@ -30,7 +30,7 @@ for n in names:
 
 T, N, F, deg = (int(os.environ.get("AB_T", 4)), int(os.environ.get("AB_N", 2_000_000)), int(os.environ.get("AB_F", 128)),
                 int(os.environ.get("AB_DEG", 32)))
-A = synth.device_er_csr(T, N, deg, "cuda")
+A = synth.device_csr(os.environ.get("AB_GRAPH", "er"), T, N, deg, "cuda")       # er | powerlaw | powerlaw_sym
 X = torch.rand(T, N, F, device="cuda")
 W = torch.randn(F, F, device="cuda") * 0.1
 Y = torch.empty_like(X)
