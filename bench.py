@@ -990,7 +990,7 @@ def worker(args):
                                   "fp32_equivalent_tflops": fp32_tf,
                                   "dtype": "bf16 planes of an exact 3-way fp32 split (v_mfma_f32_32x32x16_bf16), fp32 accumulate",
                                   "note": "6 bf16 MFMA products per fp32 term; runs at the 1400 W board cap with the shader clock "
-                                          "pulled down (profiles/r02t_power_probe.jsonl)"}
+                                          "pulled down (profiles/archive/r02t_power_probe.jsonl)"}
         if world == 1:  # the CPU legs are reported at N = 1 only
             if not args.no_epochs:
                 out["epochs"] = epochs_block(args)

@@ -44,7 +44,7 @@ typedef enum {
 /* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
 enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
 
-/* ABI version 5 = version 4 + tmgcn_pool_stats; the launchers' scratch words (tile counters, hand-off blocks) are kept apart
+/* ABI version 5 = version 4 + tmgcn_pool_stats + the row_blocks partition argument of tmgcn_layer12_fwd/bwd_f32; the launchers' scratch words (tile counters, hand-off blocks) are kept apart
  *   per stream (eager launches) and per recorded launch (hipGraph capture), and a launcher that cannot keep two launches
  *   apart returns TMGCN_ERR_INVALID with the reason instead of re-using a word that may be in flight (csrc/pools.hip).
  * ABI version 4 = version 3 + tmgcn_head_loss_f32 / tmgcn_scale2_f32 (one-pass edge head + loss + gradients).
@@ -216,12 +216,19 @@ int tmgcn_gemm_dw_act_f32(const float* A, const float* dY, const float* pre_act,
  * pre-activation, dY, dP) are never stored.  Shared weights W1 [2][F], W2 [F][Nf]; 2 -> even F <= 8 -> even Nf <= 8
  * (tmgcn_layer12_supported).  Against tmgcn_gemm_f32 + tmgcn_spmm_gemm_f32: another fp32 summation order per row (<= 1e-6).
  * AX (optional) receives Â ⋆ act1(H·W1) for dW2 = AXᵀ·dZ' (tmgcn_gemm_dw_f32); pre2 the pre-activation of layer 2
- * when act2 is not none.  The backward takes the TRANSPOSED batched CSR. */
+ * when act2 is not none.  The backward takes the TRANSPOSED batched CSR.
+ * row_blocks / n_row_blocks (optional, both 0 = blocks of 256 consecutive rows): a partition of the rows for the
+ *   entry-major kernels — n_row_blocks + 1 ascending first-row indices from 0 to n_rows, at most 256 rows per block
+ *   (N >= 256: a block then holds at most one slice boundary).  A caller that knows its row lengths cuts the blocks so
+ *   that none holds more than about two 1 024-entry tiles (csr.BatchedCSR.row_blocks): with real, skewed data the
+ *   longest block otherwise sets the launch time.  The forward's and the backward's partitions are independent (the
+ *   backward's is over the TRANSPOSED rows); results do not depend on the partition in the forward (whole rows) and
+ *   are bit-reproducible for a given partition in the backward (dW1 is summed per block, blocks in order). */
 int tmgcn_layer12_supported(int32_t K0, int32_t F, int32_t Nf);
 int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* H,
                           const float* W1, int32_t act1, const float* W2, int32_t act2, int64_t n_rows,
                           int32_t N, int32_t K0, int32_t F, int32_t Nf, float* Z, float* AX, float* pre2,
-                          float avg_nnz_per_row, void* stream);
+                          float avg_nnz_per_row, const int64_t* row_blocks, int32_t n_row_blocks, void* stream);
 /* 1 when the fused forward is the faster route for the shape (slices of >= 256 nodes: the entry-major kernel; small dense
  * slices whose layer-1 output is formed once per node in LDS; short rows); 0: form act1(H·W1) with tmgcn_gemm_f32 and call
  * tmgcn_spmm_gemm_f32 (same Z up to fp32 summation order). */
@@ -230,8 +237,8 @@ int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F);
 int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const float* dZ,
                           const float* pre2, const float* H, const float* W1, int32_t act1, const float* W2,
                           int32_t act2, int64_t n_rows, int32_t N, int32_t K0, int32_t F, int32_t Nf,
-                          float* dW1, float avg_nnz_per_row, void* workspace, int64_t workspace_bytes,
-                          void* stream);
+                          float* dW1, float avg_nnz_per_row, const int64_t* row_blocks, int32_t n_row_blocks,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- P5: pointwise non-linearity between layers (ehf:284-289, 332-334, 486) -------
  *   fwd: y = act(x);   bwd: dx = dy * act'(x)   (x = the pre-activation input)

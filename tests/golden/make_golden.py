@@ -437,7 +437,9 @@ def g11():
     """Long-horizon parity: experiment_chess_our.py's training loop (:108-123 — SGD lr .01 momentum .9, class-weighted CE,
     the 2-layer model) run for 300 epochs on the full chess data from G10's seed with the REAL ehf.EmbeddingGCN2: the loss
     of every epoch, the script's train / validation accuracy and validation loss at epochs 0 / 100 / 200 / 299 (its
-    `ep % 100 == 0` block, :117-123, plus the last epoch), the argmax class counts there, and the final W1 / W2 / U.
+    `ep % 100 == 0` block, :117-123, plus the last epoch), the argmax class counts there, the final W1 / W2 / U, and the
+    parameters + momentum buffers in front of epochs 100 / 200 / 280 (so that the CPU oracle can be pinned on the late
+    part of the trajectory without walking all of it).
     Inputs are G10's (tests/golden/g10_chess_full.npz holds the raw edges); this fixture stores outputs only."""
     import time
     c = _chess_reference_setup("g11")
@@ -449,9 +451,13 @@ def g11():
     target_val = (torch.sign(c["lv"][c["sv"]]) + 1).long()
     ev = c["eval_val"]
     n_ep = 300
-    losses, marks = [], []
+    losses, marks, ckpt = [], [], {}
     t0 = time.time()
     for ep in range(n_ep):
+        if ep in (100, 200, 280):        # the state BEFORE epoch `ep`: parameters and SGD momentum buffers (a checker can resume here)
+            for n, q in m.named_parameters():
+                ckpt[f"ckpt{ep}_{n}"] = q.detach().numpy().copy()
+                ckpt[f"ckpt{ep}_mom_{n}"] = opt.state[q]["momentum_buffer"].numpy().copy()
         opt.zero_grad()
         out = m()
         loss = crit(out, target_train)
@@ -474,7 +480,7 @@ def g11():
          marks=np.array(marks, dtype=np.float64),
          marks_columns=np.array(["epoch", "acc_train", "acc_val", "loss_val", "train_argmax_0", "train_argmax_1", "train_argmax_2",
                                  "val_argmax_0", "val_argmax_1", "val_argmax_2"]),
-         **{f"{n}_final": p.detach().numpy().copy() for n, p in m.named_parameters()})
+         **ckpt, **{f"{n}_final": p.detach().numpy().copy() for n, p in m.named_parameters()})
 
 
 if __name__ == "__main__":

@@ -99,12 +99,13 @@ int main(void) {
   /* layers 1 + 2 fused */
   NOP(tmgcn_layer12_supported(3, 6, 6));
   NOP(tmgcn_layer12_fwd_pays(0, 0, 6, 1.f));
-  BAD(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 3, 6, 6, 0, 0, 0, 1.f, 0));                       /* widths unsupported */
-  BAD(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 6, 6, 0, 0, 0, 1.f, 0));                       /* null pointers */
-  BAD(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 5, 4, 2, 6, 6, 0, 0, 0, 1.f, 0));                       /* rows not a multiple of N */
-  NOP(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 2, 6, 6, 0, 0, 0, 1.f, 0));                       /* nothing to do */
-  BAD(tmgcn_layer12_bwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 5, 6, 0, 1.f, 0, 0, 0));                 /* odd width */
-  BAD(tmgcn_layer12_bwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 6, 6, 0, 1.f, 0, 0, 0));                 /* null pointers */
+  BAD(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 3, 6, 6, 0, 0, 0, 1.f, 0, 0, 0));                 /* widths unsupported */
+  BAD(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 6, 6, 0, 0, 0, 1.f, 0, 0, 0));                 /* null pointers */
+  BAD(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 5, 4, 2, 6, 6, 0, 0, 0, 1.f, 0, 0, 0));                 /* rows not a multiple of N */
+  NOP(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 2, 6, 6, 0, 0, 0, 1.f, 0, 0, 0));                 /* nothing to do */
+  BAD(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 6, 6, 0, 0, 0, 1.f, 0, 3, 0));                 /* a block count without a partition */
+  BAD(tmgcn_layer12_bwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 5, 6, 0, 1.f, 0, 0, 0, 0, 0));           /* odd width */
+  BAD(tmgcn_layer12_bwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 6, 6, 0, 1.f, 0, 0, 0, 0, 0));           /* null pointers */
   if (tmgcn_layer12_bwd_workspace_bytes(2, 6) <= 0) { ++failures; printf("FAIL layer12 workspace size\n"); }
   BAD(tmgcn_scale2_f32(0, 0, 0, 4, 0, 0, 4, 0));
   BAD(tmgcn_cast_multi(0, 0, 0, 2, 0, 0));                                                 /* null host arrays */

@@ -57,7 +57,7 @@ def _worker(rank, world, port, exchange, F0, F1, condensed, act, pipeline, ret, 
         Y.backward(dY0[k0:k1].contiguous().cuda())
         torch.cuda.synchronize()
 
-        def close(a, b, what, tol=1e-5):      # the stated bar; measured <= 3e-7 (profiles/r3e_tolerance_summary.json)
+        def close(a, b, what, tol=1e-5):      # the stated bar; measured <= 3e-7 (profiles/archive/r3e_tolerance_summary.json)
             err = float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
             if rank == 0:
                 from _util import record_tolerance

@@ -1,0 +1,125 @@
+"""GPU: fixture G11 — a LONG training run against the reference.  experiment_chess_our.py trains 10 000 epochs and scores
+every 100 (:108-123); G6 / G10 pin 10 / 6 SGD steps.  G11 is 300 epochs of the script's loop with the real
+ehf.EmbeddingGCN2 on the full chess data (tests/golden/make_golden.py g11): the loss of every epoch, the script's train /
+validation accuracy and validation loss at epochs 0 / 100 / 200 / 299, the argmax class counts, the final W1 / W2 / U.
+
+Two routes walk all 300 epochs on the device-built adjacency: the plain loop (criterion(gcn(), target), torch.optim.SGD)
+and the captured one (GraphedTrainStep: layers 1 + 2 fused, one-pass head + loss, FusedSGD, one hipGraph per epoch).
+Stated tolerance for a trajectory (rounding differences are fed back through 300 momentum-SGD steps, so the 1e-5 bar of a
+single step does not apply): every loss within 1e-3 of the reference's (relative), the script's accuracies within 0.5 %
+(absolute), the argmax class counts within 0.5 % of the edges, validation loss within 1e-3, final parameters within 1e-2
+of max|ref|.  The MEASURED deviations (max per 100 epochs) go to the tolerance record — they sit far below the bounds."""
+import numpy as np
+import pytest
+import torch
+
+from _g10 import G10
+from _util import golden, max_rel_err, record_tolerance
+import tmgcn_amd.layers as ehf
+from tmgcn_amd import adjacency
+
+pytestmark = pytest.mark.gpu
+LOSS_TOL, ACC_TOL, PARAM_TOL = 1e-3, 5e-3, 1e-2
+
+
+@pytest.fixture(scope="module")
+def setup():
+    g = G10()
+    k, i, j = g.raw
+    Chat, _ = adjacency.build_adjacency(k, i, j, np.ones(len(k), np.float32), g.TT, g.N, M=None, window=10)
+    A_train = adjacency.m_product_csr(Chat.slices(0, g.T), g.M)
+    A_val = adjacency.m_product_csr(Chat.slices(g.S_val, g.S_val + g.T), g.M)
+    return g, golden("g11_chess_train300"), A_train, A_val
+
+
+def _model(g, d, A_train):
+    torch.manual_seed(int(d["seed"]))
+    return ehf.EmbeddingGCN2(A_train, torch.from_numpy(g.X_train), torch.from_numpy(g.edges_train), torch.from_numpy(g.M),
+                             hidden_feat=[6, 6, 3], condensed_W=True, use_Minv=False, nonlin2="selu")
+
+
+def _check_run(tag, g, d, A_val, m, losses, outs_at):
+    ref = d["losses"]
+    rel = np.abs(np.array(losses) - ref) / np.abs(ref)
+    for a in range(0, len(ref), 100):
+        record_tolerance(f"G11 {tag}: max relative loss deviation, epochs {a}-{a + 99}", float(rel[a:a + 100].max()), LOSS_TOL, "max|Δloss|/loss")
+    assert float(rel.max()) <= LOSS_TOL, f"{tag}: loss deviates by {rel.max():.2e} at epoch {int(rel.argmax())}"
+    tgt = torch.from_numpy(g.target_train).cuda()
+    tgt_val, ev = torch.from_numpy(g.target_val).cuda(), torch.from_numpy(g.eval_val).cuda()
+    crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(g.class_weights).cuda())
+    cols = list(d["marks_columns"])
+    for row in d["marks"]:
+        mk = dict(zip(cols, row))
+        ep = int(mk["epoch"])
+        if ep not in outs_at:
+            continue
+        out, out_val = outs_at[ep]
+        guess, gv = out.argmax(1), out_val.argmax(1)
+        acc_train = int((guess == tgt).sum()) / len(tgt)
+        acc_val = int((gv[ev] == tgt_val[ev]).sum()) / int(ev.sum())
+        loss_val = float(crit(out_val[ev], tgt_val[ev]))
+        for what, got, want, tol in (("acc_train", acc_train, mk["acc_train"], ACC_TOL), ("acc_val", acc_val, mk["acc_val"], ACC_TOL),
+                                     ("loss_val", loss_val, mk["loss_val"], LOSS_TOL * mk["loss_val"])):
+            record_tolerance(f"G11 {tag}: {what} at epoch {ep}", abs(got - want), tol, "|Δ|")
+            assert abs(got - want) <= tol, f"{tag} epoch {ep}: {what} {got} vs the reference's {want}"
+        cnt = torch.bincount(guess, minlength=3).cpu().numpy()
+        cnt_v = torch.bincount(gv[ev], minlength=3).cpu().numpy()
+        assert np.abs(cnt - [mk[f"train_argmax_{c}"] for c in range(3)]).max() <= ACC_TOL * len(tgt), f"{tag} epoch {ep}: train argmax counts {cnt}"
+        assert np.abs(cnt_v - [mk[f"val_argmax_{c}"] for c in range(3)]).max() <= ACC_TOL * int(ev.sum()), f"{tag} epoch {ep}: val argmax counts {cnt_v}"
+    for n, q in m.named_parameters():
+        err = max_rel_err(q.detach(), d[f"{n}_final"])
+        record_tolerance(f"G11 {tag}: {n} after 300 epochs", err, PARAM_TOL)
+        assert err <= PARAM_TOL, f"{tag}: {n} after 300 epochs {err:.2e}"
+
+
+def _val(g, m, A_val):
+    with torch.no_grad():      # the script's validation call (:117): layer 1 on the validation block, layer 2 on self.At (ehf:348)
+        return m(A_val, torch.from_numpy(g.X_val), torch.from_numpy(g.edges_val)).detach().clone()
+
+
+def test_plain_loop_follows_the_reference_for_300_epochs(setup):
+    g, d, A_train, A_val = setup
+    m = _model(g, d, A_train)
+    for n, q in m.named_parameters():
+        assert np.array_equal(q.detach().cpu().numpy(), golden("g10_chess_full")[f"gcn2_{n}0"]), n    # same draw as G10
+    tgt = torch.from_numpy(g.target_train).cuda()
+    crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(g.class_weights).cuda())
+    opt = torch.optim.SGD(m.parameters(), lr=float(d["lr"]), momentum=float(d["momentum"]))
+    losses, outs_at = [], {}
+    for ep in range(int(d["epochs"])):
+        opt.zero_grad()
+        out = m()
+        loss = crit(out, tgt)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+        if ep % 100 == 0 or ep == int(d["epochs"]) - 1:
+            outs_at[ep] = (out.detach().clone(), _val(g, m, A_val))
+    _check_run("plain loop", g, d, A_val, m, losses, outs_at)
+
+
+def test_captured_step_follows_the_reference_for_300_epochs(setup):
+    from tmgcn_amd.graphs import GraphedTrainStep
+    from tmgcn_amd.optim import FusedSGD
+    g, d, A_train, A_val = setup
+    m = _model(g, d, A_train)
+    tgt = torch.from_numpy(g.target_train).cuda()
+    crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(g.class_weights).cuda())
+    opt = FusedSGD(m.parameters(), lr=float(d["lr"]), momentum=float(d["momentum"]))
+    n_ep = int(d["epochs"])
+    losses, outs_at = [], {}
+    # epoch 0 eagerly through the one-pass head + loss (also the step's warm-up: the first SGD step creates the momentum
+    # buffers), every later epoch is one replay of the captured step
+    opt.zero_grad(set_to_none=True)
+    loss, out = m.loss(crit, tgt, want_logits=True)
+    loss.backward()
+    opt.step()
+    losses.append(float(loss.detach()))
+    outs_at[0] = (out.detach().clone(), _val(g, m, A_val))
+    step = GraphedTrainStep(m, crit, opt, tgt, warmup=0, keep_logits=True)
+    assert step.fused
+    for ep in range(1, n_ep):
+        losses.append(float(step()))
+        if ep % 100 == 0 or ep == n_ep - 1:
+            outs_at[ep] = (step.output.detach().clone(), _val(g, m, A_val))
+    _check_run("captured step", g, d, A_val, m, losses, outs_at)

@@ -699,27 +699,45 @@ def test_weighted_cross_entropy_matches_torch_fp64(E, C):
 
 
 
-def _oracle_layer12(H, W1, act1, A, W2, act2, dZ):
+def _oracle_layer12(H, W1, act1, A, W2, act2, dZ, dtype=torch.float32):
     """The oracle's restatement of what ops.layer12 computes — layers 1 + 2 of the narrow models the reference's way
     (ehf:330-335 then the default branch ehf:348-349; EmbeddingKWGCN ehf:486-487): fp32 H·W1, the non-linearity,
-    `.double()`, one fp64 sparse.mm per slice into an fp32 buffer (oracle.slice_spmm), fp32 ·W2, autograd for dW1 / dW2."""
+    `.double()`, one fp64 sparse.mm per slice into an fp32 buffer (oracle.slice_spmm), fp32 ·W2, autograd for dW1 / dW2.
+    dtype=float64: the same math with fp64 weights and buffers (the "truth" fp32 reduction noise is judged against)."""
     from oracle import tmgcn_oracle as orc
     At = A.to_coo_list(torch.float64)
-    w1, w2 = W1.detach().cpu().clone().requires_grad_(True), W2.detach().cpu().clone().requires_grad_(True)
-    Y = torch.matmul(H.detach().cpu(), w1)
-    Y = (orc.ACTS[act1](Y) if act1 else Y).double()
-    Z = torch.matmul(orc.slice_spmm(At, Y), w2)
-    Z = orc.ACTS[act2](Z) if act2 else Z
-    Z.backward(dZ.detach().cpu())
+    w1, w2 = W1.detach().cpu().to(dtype).requires_grad_(True), W2.detach().cpu().to(dtype).requires_grad_(True)
+    orc.BUFFER_DTYPE = dtype
+    try:
+        Y = torch.matmul(H.detach().cpu().to(dtype), w1)
+        Y = (orc.ACTS[act1](Y) if act1 else Y).double()
+        Z = torch.matmul(orc.slice_spmm(At, Y), w2)
+        Z = orc.ACTS[act2](Z) if act2 else Z
+        Z.backward(dZ.detach().cpu().to(dtype))
+    finally:
+        orc.BUFFER_DTYPE = torch.float32
     return Z.detach(), w1.grad, w2.grad
 
 
 def _assert_layer12_vs_oracle(got, H, W1, act1, A, W2, act2, dZ, tag):
-    for x, y, what in zip(got, _oracle_layer12(H, W1, act1, A, W2, act2, dZ), ("Z", "dW1", "dW2")):
+    """The bar of tests/test_gpu_configs.py: within 1e-5 of the reference-way fp32 oracle — or, only where that fp32
+    result is ITSELF more than 1e-5 from the fp64 truth of the same math (dW1 / dW2 are sums over T·N rows: the
+    reference's fp32 reduction order is good to a few 1e-5 at 30 000 rows), within 1e-6 of the truth and at least ten
+    times closer to it than the reference is."""
+    ref32 = _oracle_layer12(H, W1, act1, A, W2, act2, dZ)
+    truth = None
+    for x, y, what, k in zip(got, ref32, ("Z", "dW1", "dW2"), range(3)):
         if float(y.abs().max()) == 0.0:
             assert float(x.abs().max()) == 0.0, f"{tag} {what}: the oracle's result is all zero"
-        else:
-            assert_close(x, y, REL_TOL, f"{tag} {what} vs the oracle")
+            continue
+        e_ref = max_rel_err(x, y)
+        if e_ref <= REL_TOL:
+            continue
+        truth = truth or _oracle_layer12(H, W1, act1, A, W2, act2, dZ, torch.float64)
+        e_truth, e_ref_truth = max_rel_err(x, truth[k]), max_rel_err(y, truth[k])
+        assert e_ref_truth > REL_TOL and e_truth <= 1e-6 and 10 * e_truth <= e_ref_truth, \
+            f"{tag} {what}: vs the oracle (fp32) {e_ref:.2e}, vs the fp64 truth {e_truth:.2e} (the oracle itself {e_ref_truth:.2e})"
+
 
 
 @pytest.mark.parametrize("T,N,nnz", [(1, 300, 0), (3, 256, 0), (1, 300, 5), (2, 256, 700), (3, 257, 900), (1, 256, 768),

@@ -407,3 +407,67 @@ def test_g10_full_chess_baseline_kwgcn():
         with torch.no_grad():
             out_val = orc.kwgcn_forward(AX_val, A, p["W1"], p["U"], vs, vd, p.get("W2"), "selu")
         assert_close(out_val, d[name + "_logits_val"], 2e-6, name + " validation logits (shorter window)")
+
+
+def test_g11_oracle_follows_the_reference_training_run_early_and_late():
+    """Fixture G11: experiment_chess_our.py's loop (:108-123 — SGD lr .01 momentum .9, class-weighted CE, 2-layer model)
+    run for 300 epochs with the REAL ehf.EmbeddingGCN2 on the full chess data.  The oracle is pinned on the run where the
+    weights have moved, not only at initialisation: the first 12 epochs from the seed, and the last 20 epochs resumed from
+    the fixture's state in front of epoch 280 (parameters + momentum buffers) — every loss, the script's validation
+    numbers of epoch 299 and the final parameters.  (The whole run is walked on the device: tests/test_gpu_g11_*.)"""
+    import scipy.sparse as sp
+    from _g10 import G10
+    g = G10()
+    d = golden("g11_chess_train300")
+    T, N = g.T, g.N
+    k, i, j = g.raw
+    raw = [sp.coo_matrix((np.ones(int((k == t).sum())), (i[k == t], j[k == t])), shape=(N, N)).tocsr() for t in range(g.TT)]
+    C = synth.normalise(synth.edge_life(synth.symmetrise(raw), 10))
+    M = synth.band_M(T, 20, "python")
+    At = synth.to_coo_list(synth.m_product(C[:T], M))
+    At_val = synth.to_coo_list(synth.m_product(C[g.S_val:g.S_val + T], M))
+    Mt = torch.from_numpy(g.M)
+    AtXt = orc.compute_AtXt(Mt, At, torch.from_numpy(g.X_train))
+    AtXt_val = orc.compute_AtXt(Mt, At_val, torch.from_numpy(g.X_val))
+    src, dst = orc.flat_edge_index(torch.from_numpy(g.edges_train), N)
+    vs, vd = orc.flat_edge_index(torch.from_numpy(g.edges_val), N)
+    tgt, tgt_val, ev = torch.from_numpy(g.target_train), torch.from_numpy(g.target_val), torch.from_numpy(g.eval_val)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.from_numpy(g.class_weights))
+    names = ("W1", "W2", "U")
+
+    def run(params, epochs, momentum=None):
+        ps = [torch.nn.Parameter(params[n].clone()) for n in names]
+        opt = torch.optim.SGD(ps, lr=float(d["lr"]), momentum=float(d["momentum"]))
+        if momentum is not None:
+            for q, n in zip(ps, names):
+                opt.state[q]["momentum_buffer"] = momentum[n].clone()
+        losses = []
+        for _ in range(epochs):
+            opt.zero_grad()
+            out = orc.gcn2_forward(AtXt, At, Mt, ps[0], ps[1], ps[2], src, dst, nonlin="selu")
+            loss = crit(out, tgt)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        return ps, np.array(losses), out.detach()
+
+    torch.manual_seed(int(d["seed"]))
+    p0 = orc.draw_params("gcn2", T, [2, 6, 6, 3])
+    _, early, _ = run(p0, 12)
+    assert_close(early, d["losses"][:12], 1e-6, "G11 losses of epochs 0-11 from the seed")
+    ck = {n: torch.from_numpy(d[f"ckpt280_{n}"]) for n in names}
+    mom = {n: torch.from_numpy(d[f"ckpt280_mom_{n}"]) for n in names}
+    ps, late, out = run(ck, 20, mom)
+    assert_close(late, d["losses"][280:], 1e-6, "G11 losses of epochs 280-299 resumed from the fixture's state")
+    for q, n in zip(ps, names):
+        assert_close(q.detach(), d[f"{n}_final"], 1e-6, f"G11 {n} after epoch 299")
+    mark = {c: v for c, v in zip(d["marks_columns"], d["marks"][-1])}
+    assert int(mark["epoch"]) == 299
+    with torch.no_grad():
+        guess = out.argmax(1)
+        assert abs(int((guess == tgt).sum()) / len(tgt) - mark["acc_train"]) < 1e-12
+        out_val = orc.gcn2_forward(AtXt_val, At, Mt, ps[0], ps[1], ps[2], vs, vd, nonlin="selu")    # layer 2 on the TRAINING adjacency (ehf:348)
+        gv = out_val.argmax(1)
+        assert abs(int((gv[ev] == tgt_val[ev]).sum()) / int(ev.sum()) - mark["acc_val"]) < 1e-12
+        assert abs(float(crit(out_val[ev], tgt_val[ev])) - mark["loss_val"]) <= 1e-6 * mark["loss_val"]
+        assert np.array_equal(np.bincount(gv[ev].numpy(), minlength=3), [mark[f"val_argmax_{c}"] for c in range(3)])

@@ -1,0 +1,71 @@
+"""CPU: the seeded synthetic S4 adjacencies (tmgcn_amd/synth.py) — the balanced one of SURVEY §8d and the skewed one the
+roofline_skewed bench leg runs on."""
+import numpy as np
+import torch
+
+from tmgcn_amd import synth
+
+
+def _rows(A):
+    return (A.rowptr[1:] - A.rowptr[:-1]).reshape(A.T, A.N)
+
+
+def test_powerlaw_degrees_shape():
+    d = synth.powerlaw_degrees(2_000_000, 32)
+    assert d[0] == 100_000 and 5 <= (d == 100_000).sum() <= 30            # a handful of hubs at the cap
+    assert abs(d.sum() / 2e6 - 32) < 1.0 and d[-1] >= 1 and np.all(np.diff(d) <= 0)
+    share = np.cumsum(d) / d.sum()
+    assert 0.55 < share[200_000] < 0.70                                   # a tenth of the rows holds ~60 % of the entries
+    assert synth.powerlaw_degrees(500, 32)[0] == 500                      # cap = N on small graphs
+
+
+def test_powerlaw_csr_is_seeded_per_slice_sorted_and_row_normalised():
+    T, N = 3, 4000
+    for sym in (False, True):
+        A = synth.device_powerlaw_csr(T, N, 32, "cpu", first_slice=5, symmetric=sym)
+        cnt = _rows(A)
+        assert int(cnt.min()) >= 1 and int(cnt.max()) > 1000 and abs(float(cnt.float().mean()) - 33) < 2.5
+        rid = A.row_ids()
+        col = A.col.long()
+        # columns ascending inside every row; the self loop is there; values = 1 / row length
+        same = rid[1:] == rid[:-1]
+        assert bool((col[1:][same] >= col[:-1][same]).all())
+        assert bool(torch.zeros(T * N, dtype=torch.bool).index_put_((rid[col == rid % N],), torch.tensor(True)).all())
+        assert torch.allclose(torch.zeros(T * N, dtype=torch.float64).index_add_(0, rid, A.val.double()), torch.ones(T * N, dtype=torch.float64), atol=1e-5)
+        # slice k depends on first_slice + k only: any rank can regenerate any slice
+        one = synth.device_powerlaw_csr(1, N, 32, "cpu", first_slice=6, symmetric=sym)
+        a, b = int(A.rowptr[N]), int(A.rowptr[2 * N])
+        assert torch.equal(one.col, A.col[a:b]) and torch.equal(one.val, A.val[a:b])
+        assert torch.equal(one.rowptr, A.rowptr[N:2 * N + 1] - a)
+        if sym:                                                         # pattern symmetric: the transpose has the same row lengths
+            assert torch.equal(_rows(A.transpose()), cnt)
+        else:                                                           # skewed out-degree only: in-degrees are Poisson-like
+            assert int(_rows(A.transpose()).max()) < 120
+    assert synth.device_csr("er", 1, 50, 4, "cpu").nnz == 50 * 5
+
+
+def test_row_blocks_partition_by_entries():
+    """csr.BatchedCSR.row_blocks (the partition the entry-major layer kernels take): ascending from 0 to R, at most 256 rows
+    and at most max_entries + the longest row of entries per block, cut at row boundaries; None when nothing needs cutting."""
+    from tmgcn_amd.csr import BatchedCSR
+    assert synth.device_er_csr(2, 1000, 3, "cpu").row_blocks() is None          # 4 per row: 1 024 entries per 256 rows
+    g = torch.Generator().manual_seed(0)
+    T, N = 3, 1300
+    cnt = torch.randint(0, 4, (T * N,), generator=g)
+    cnt[:250] = 13                                                            # dense rows at the start of slice 0
+    cnt[N + 100] = 5000                                                       # one row longer than max_entries
+    cnt[2 * N - 1] = 0
+    rowptr = torch.zeros(T * N + 1, dtype=torch.int64)
+    torch.cumsum(cnt, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    A = BatchedCSR(rowptr, torch.randint(0, N, (nnz,), generator=g, dtype=torch.int32), torch.rand(nnz, generator=g), T, N)
+    blk = A.row_blocks()
+    assert blk is A.row_blocks() and blk.dtype == torch.int64
+    assert int(blk[0]) == 0 and int(blk[-1]) == T * N and bool((blk[1:] > blk[:-1]).all())
+    rows = blk[1:] - blk[:-1]
+    ent = rowptr[blk[1:]] - rowptr[blk[:-1]]
+    assert int(rows.max()) <= 256 and int(ent.max()) <= 2048 + int(cnt.max())
+    assert int((ent > 2048).sum()) == 1                                       # only the block of the 5 000-entry row
+    assert blk.numel() - 1 > (T * N + 255) // 256                             # the dense region was cut further
+    # every multiple of 256 rows is still a boundary (blocks are only ever cut, never merged)
+    assert set(range(0, T * N, 256)) <= set(blk.tolist())

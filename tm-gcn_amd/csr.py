@@ -34,6 +34,7 @@ class BatchedCSR:
         self.N = int(N)
         self.nnz = int(col.numel())
         self._t: Optional["BatchedCSR"] = None
+        self._blocks = {}
 
     # ------------------------------------------------------------------ properties
     @property
@@ -173,6 +174,33 @@ class BatchedCSR:
             self._t = t
         return self._t
 
+    def row_blocks(self, max_rows: int = 256, max_entries: int = 2048) -> Optional[torch.Tensor]:
+        """Partition of the rows for the entry-major layer kernels (tmgcn_layer12_fwd/bwd_f32's `row_blocks`), cached:
+        blocks of `max_rows` consecutive rows, and every such block that holds more than `max_entries` stored entries
+        cut further — at row boundaries, into ceil(entries / max_entries) parts of about equal entry counts — so that
+        no block holds more than max_entries + its longest row.  int64 [n_blocks + 1] first-row indices on the
+        adjacency's device; None when no block needs cutting (balanced data: the kernels' own 256-row blocks)."""
+        key = (int(max_rows), int(max_entries))
+        if key not in self._blocks:
+            R, dev = self.n_rows, self.device
+            starts = torch.arange(0, R, max_rows, device=dev, dtype=torch.int64)
+            ends = torch.clamp(starts + max_rows, max=R)
+            lo, hi = self.rowptr[starts], self.rowptr[ends]
+            parts = torch.clamp((hi - lo + max_entries - 1) // max_entries, min=1)
+            if R == 0 or int(parts.max()) <= 1:
+                self._blocks[key] = None
+            else:
+                owner = torch.repeat_interleave(torch.arange(starts.numel(), device=dev), parts)
+                first_part = torch.cumsum(parts, 0) - parts
+                i = torch.arange(owner.numel(), device=dev) - first_part[owner]              # part index inside its block
+                target = lo[owner] + (hi[owner] - lo[owner]) * i // parts[owner]             # entry position the part starts at
+                cut = torch.searchsorted(self.rowptr, target.contiguous(), right=False)      # first row starting at or after it
+                cut = torch.minimum(torch.maximum(cut, starts[owner]), ends[owner])
+                cut = torch.where(i == 0, starts[owner], cut)
+                blk = torch.unique(torch.cat([cut, torch.tensor([R], device=dev, dtype=torch.int64)]))   # sorted; empty parts vanish
+                self._blocks[key] = blk.contiguous()
+        return self._blocks[key]
+
     def slices(self, k0: int, k1: int) -> "BatchedCSR":
         """Slices [k0, k1) as their own batched CSR (the shard one rank owns)."""
         assert 0 <= k0 <= k1 <= self.T
@@ -195,6 +223,7 @@ class BatchedCSR:
             v.T, v.N = 1, self.N
             v.nnz = bounds[k + 1] - bounds[k]
             v._t = None
+            v._blocks = {}
             out.append(v)
         return out
 

@@ -561,7 +561,7 @@ static bool small_head(int F, int C, const void* Z, const void* io) {
   }
 
 #ifndef TMGCN_DZ_CHAIN
-#define TMGCN_DZ_CHAIN 2   // entries per lane aimed at (A/B: tools/ab_edge_head.py, profiles/r02x_ab_edge_head.txt)
+#define TMGCN_DZ_CHAIN 2   // entries per lane aimed at (A/B: tools/ab_edge_head.py, profiles/archive/r02x_ab_edge_head.txt)
 #endif
 #ifndef TMGCN_DZ_MAXG
 #define TMGCN_DZ_MAXG 32

@@ -837,7 +837,7 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& h, unsigned& 
 #define X3_SCHED 1
 #endif
 // (The same products on v_mfma_f32_16x16x32_bf16 — 16 tiles of 16x16 per wave and step — were measured in round 3: the same
-// time within 2 %, a higher clock at twice the MFMA count; profiles/r3c_ab_dw_m16.txt.  Not kept.)
+// time within 2 %, a higher clock at twice the MFMA count; profiles/archive/r3c_ab_dw_m16.txt.  Not kept.)
 constexpr int X3_ROWS = 32;
 constexpr int X3_PITCH = 272;             // bytes per feature quad (4 x 64 + 16)
 constexpr int X3_PLANE = 32 * X3_PITCH;   // 128 features
@@ -1034,8 +1034,8 @@ __global__ __launch_bounds__(256, X3_OCC) void gemm_dw_bf16x3_kernel(DwArgs a) {
 // block per CU, double-buffered plane images (one barrier per step), waves 0-3 splitting while waves
 // 4-7 multiply (stagger), and a two-deep load ring in reserved registers (async_stage.h).  It ran
 // 2.17 ms against 1.89 ms for the kernel above at R = 8 M rows (2.20 ms without the stagger,
-// 2.02 ms without the RNE flush; profiles/r02k_ab_dw_forms.txt).  The PMC pass of
-// profiles/r02l_pmc_sq_gemm_dw.json says why more prefetch does not help either form: the matrix
+// 2.02 ms without the RNE flush; profiles/archive/r02k_ab_dw_forms.txt).  The PMC pass of
+// profiles/archive/r02l_pmc_sq_gemm_dw.json says why more prefetch does not help either form: the matrix
 // pipes are busy 47-48 % of the cycles and the waves wait on instruction ISSUE (MFMA pipe / VALU)
 // for 48 % of their life, on memory or barriers for only 26 %, at a shader clock of ~1.6 GHz — the
 // six plane products plus ~200 VALU instructions of splitting per step are co-limiting with the

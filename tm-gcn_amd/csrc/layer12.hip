@@ -49,6 +49,8 @@ struct L12Args {
   int32_t N;
   int32_t act1, act2;
   int32_t chunks, chunk_rows;   // staged variants: blocks per slice and rows per block
+  const int64_t* blk;           // entry-major variants, optional: first row of every row block (n_blk + 1 values, <= 256 rows each)
+  int32_t n_blk;
 };
 
 template <int N, typename T>
@@ -267,9 +269,11 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
     for (int n = 0; n < NT; ++n) W2[f][n] = a.W2[f * NT + n];
   const ActApply act1(a.act1), act2(a.act2);
   const int t = threadIdx.x;
-  const int64_t first = (int64_t)blockIdx.x * 256;
+  // the block's rows: 256 consecutive ones, or — with a partition (tmgcn_layer12_fwd_f32's row_blocks: row blocks cut so
+  // that none holds more than about two tiles of entries) — rows [blk[b], blk[b+1])
+  const int64_t first = a.blk ? a.blk[blockIdx.x] : (int64_t)blockIdx.x * 256;
   const int64_t r = first + t;
-  const int rows = a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256;
+  const int rows = a.blk ? (int)(a.blk[blockIdx.x + 1] - first) : (a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256);
   {
     const int64_t q = first + (t < rows ? t : rows);
     rp[t] = a.rowptr[q];
@@ -537,11 +541,11 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
 #pragma unroll
   for (int j = 0; j < NO; ++j) acc[j] = 0.0;
   constexpr int PER = kEmTile / 256;
-  const int64_t n_row_blocks = (a.n_rows + 255) / 256;
+  const int64_t n_row_blocks = a.blk ? a.n_blk : (a.n_rows + 255) / 256;
   for (int64_t rb = blockIdx.x; rb < n_row_blocks; rb += gridDim.x) {
-    const int64_t first = rb * 256;
+    const int64_t first = a.blk ? a.blk[rb] : rb * 256;
     const int64_t r = first + t;
-    const int rows = a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256;
+    const int rows = a.blk ? (int)(a.blk[rb + 1] - first) : (a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256);
     __syncthreads();                                  // the previous row block's readers of rp are done
     rp[t] = a.rowptr[first + (t < rows ? t : rows)];
     if (t == 0) rp[256] = a.rowptr[first + rows];
@@ -751,7 +755,7 @@ extern "C" int tmgcn_layer12_supported(int32_t K0, int32_t F, int32_t Nf) {
 extern "C" int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* H,
                                       const float* W1, int32_t act1, const float* W2, int32_t act2, int64_t n_rows,
                                       int32_t N, int32_t K0, int32_t F, int32_t Nf, float* Z, float* AX, float* pre2,
-                                      float avg_nnz_per_row, void* stream) {
+                                      float avg_nnz_per_row, const int64_t* row_blocks, int32_t n_row_blocks, void* stream) {
   TMGCN_REQUIRE(tmgcn_layer12_supported(K0, F, Nf), "layer12: unsupported widths %d -> %d -> %d (2 -> even <= 8 -> even <= 8)", K0, F, Nf);
   TMGCN_REQUIRE(n_rows >= 0 && N > 0 && n_rows % N == 0, "layer12: bad shape n_rows=%lld N=%d", (long long)n_rows, N);
   TMGCN_REQUIRE(act1 >= TMGCN_ACT_NONE && act1 <= TMGCN_ACT_SELU && act2 >= TMGCN_ACT_NONE && act2 <= TMGCN_ACT_SELU,
@@ -759,7 +763,8 @@ extern "C" int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, 
   if (n_rows == 0) return TMGCN_OK;
   TMGCN_REQUIRE(rowptr && H && W1 && W2 && Z, "layer12: null pointer");
   TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(H) % 8 == 0, "layer12: H must be 8-byte aligned");
-  L12Args a{rowptr, col, val, H, W1, W2, nullptr, nullptr, Z, AX, pre2, nullptr, nullptr, nullptr, n_rows, N, act1, act2, 0, 0};
+  TMGCN_REQUIRE((row_blocks == nullptr) == (n_row_blocks == 0) && n_row_blocks >= 0, "layer12: row_blocks and n_row_blocks go together");
+  L12Args a{rowptr, col, val, H, W1, W2, nullptr, nullptr, Z, AX, pre2, nullptr, nullptr, nullptr, n_rows, N, act1, act2, 0, 0, nullptr, 0};
   const bool staged = l12_staged(n_rows, N, F, avg_nnz_per_row);
   const int G = l12_lanes(avg_nnz_per_row, staged);
   if (staged) {
@@ -767,7 +772,9 @@ extern "C" int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, 
     a.chunk_rows = (N + a.chunks - 1) / a.chunks;
     l12_launch<false, true>(a, F, Nf, G, (unsigned)(n_rows / N * a.chunks), (size_t)N * F * 4 + (a.chunk_rows + 1) * 8, (hipStream_t)stream);
   } else if (N >= 256) {
-    l12_em_launch(a, F, Nf, (unsigned)((n_rows + 255) / 256), (hipStream_t)stream);       // entry-major: see l12_fwd_em_kernel
+    a.blk = row_blocks;                                                                  // entry-major: see l12_fwd_em_kernel
+    a.n_blk = n_row_blocks;
+    l12_em_launch(a, F, Nf, row_blocks ? (unsigned)n_row_blocks : (unsigned)((n_rows + 255) / 256), (hipStream_t)stream);
   } else {
     l12_launch<false, false>(a, F, Nf, G, (unsigned)((n_rows * G + 255) / 256), 0, (hipStream_t)stream);
   }
@@ -791,8 +798,8 @@ extern "C" int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F) {
 extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const float* dZ,
                                       const float* pre2, const float* H, const float* W1, int32_t act1, const float* W2,
                                       int32_t act2, int64_t n_rows, int32_t N, int32_t K0, int32_t F, int32_t Nf,
-                                      float* dW1, float avg_nnz_per_row, void* workspace, int64_t workspace_bytes,
-                                      void* stream) {
+                                      float* dW1, float avg_nnz_per_row, const int64_t* row_blocks, int32_t n_row_blocks,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
   TMGCN_REQUIRE(tmgcn_layer12_supported(K0, F, Nf), "layer12_bwd: unsupported widths %d -> %d -> %d", K0, F, Nf);
   TMGCN_REQUIRE(n_rows > 0 && N > 0 && n_rows % N == 0, "layer12_bwd: bad shape n_rows=%lld N=%d", (long long)n_rows, N);
   TMGCN_REQUIRE(act1 >= TMGCN_ACT_NONE && act1 <= TMGCN_ACT_SELU && act2 >= TMGCN_ACT_NONE && act2 <= TMGCN_ACT_SELU,
@@ -807,8 +814,9 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
     return TMGCN_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
+  TMGCN_REQUIRE((row_blocks == nullptr) == (n_row_blocks == 0) && n_row_blocks >= 0, "layer12_bwd: row_blocks and n_row_blocks go together");
   L12Args a{t_rowptr, t_col, t_val, H, W1, W2, dZ, pre2, nullptr, nullptr, nullptr, dW1, (float*)workspace,
-            acquire_sync_word(st), n_rows, N, act1, act2, 0, 0};
+            acquire_sync_word(st), n_rows, N, act1, act2, 0, 0, nullptr, 0};
   TMGCN_REQUIRE(a.sync, "layer12_bwd: no hand-off block: %s", pool_error());
   const bool staged = l12_staged(n_rows, N, Nf, avg_nnz_per_row);
   const int G = l12_lanes(avg_nnz_per_row, staged);
@@ -823,7 +831,9 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
     // a tile of entries; one block per row block when row blocks hold a tile or more on average — with real skew some hold
     // several, and chaining those behind each other costs more than the extra slabs (chess, 1 016 entries per row block:
     // 50.8 us against 61.7; the synthetic shape, 784: 30.0 against 26.6)
-    int64_t blocks = (n_rows + 255) / 256;
+    a.blk = row_blocks;
+    a.n_blk = n_row_blocks;
+    int64_t blocks = row_blocks ? n_row_blocks : (n_rows + 255) / 256;
     const int64_t cap = avg_nnz_per_row * 256.f > 0.9f * kEmTile ? kL12MaxBlocks : kL12ResidentBlocks;
     if (blocks > cap) blocks = cap;
     l12_bwd_em_launch(a, F, Nf, (unsigned)blocks, st);

@@ -819,9 +819,14 @@ struct HeadLossFn : public torch::autograd::Function<HeadLossFn> {
 struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& H, const Tensor& W1, const Tensor& W2, const Tensor& rowptr,
                         const Tensor& col, const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col,
-                        const OptTensor& t_val, int64_t N, double avg, int64_t act1, int64_t act2, bool need1, bool need2) {
+                        const OptTensor& t_val, int64_t N, double avg, int64_t act1, int64_t act2, const OptTensor& blk,
+                        const OptTensor& t_blk, bool need1, bool need2) {
     at::AutoDispatchBelowADInplaceOrView guard;
     want(H, "layer12 H");
+    for (const OptTensor* b : {&blk, &t_blk})
+      TORCH_CHECK(!b->has_value() || ((*b)->is_cuda() && (*b)->scalar_type() == at::kLong && (*b)->is_contiguous() && (*b)->dim() == 1 &&
+                                      (*b)->numel() >= 2),
+                  "layer12: a row-block partition is a contiguous int64 vector of at least two first-row indices on the device");
     want(W1, "layer12 W1");
     want(W2, "layer12 W2");
     check_csr(rowptr, col, val, H, N, "layer12");
@@ -843,6 +848,7 @@ struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
       ok(tmgcn_layer12_fwd_f32((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val), (const float*)ptr(H),
                                (const float*)ptr(W1), (int32_t)act1, (const float*)ptr(W2), (int32_t)act2, R, (int32_t)N,
                                (int32_t)K0, (int32_t)F, (int32_t)Nf, (float*)ptr(Z), (float*)ptr(AX), (float*)ptr(pre2), (float)avg,
+                               blk.has_value() ? (const int64_t*)ptr(*blk) : nullptr, blk.has_value() ? (int32_t)(blk->numel() - 1) : 0,
                                stream_of(H)),
          "tmgcn_layer12_fwd_f32");
     } else {
@@ -856,7 +862,8 @@ struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
       TORCH_CHECK(!need1 || (t_rowptr.has_value() && t_col.has_value() && t_val.has_value()),
                   "layer12: the gradient of W1 needs the transposed adjacency");
       ctx->save_for_backward({H, W1, W2, AX.defined() ? AX : none_like(H), pre2.defined() ? pre2 : none_like(H),
-                              need1 ? *t_rowptr : none_like(H), need1 ? *t_col : none_like(H), need1 ? *t_val : none_like(H)});
+                              need1 ? *t_rowptr : none_like(H), need1 ? *t_col : none_like(H), need1 ? *t_val : none_like(H),
+                              (need1 && t_blk.has_value()) ? *t_blk : none_like(H)});
     }
     ctx->saved_data["N"] = N;
     ctx->saved_data["avg"] = avg;
@@ -867,7 +874,7 @@ struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     at::AutoDispatchBelowADInplaceOrView guard;
     auto sv = ctx->get_saved_variables();
-    TORCH_CHECK(sv.size() == 8, "layer12: backward through a call made without gradients");
+    TORCH_CHECK(sv.size() == 9, "layer12: backward through a call made without gradients");
     const Tensor &H = sv[0], &W1 = sv[1], &W2 = sv[2], &AX = sv[3], &pre2 = sv[4];
     const int64_t N = ctx->saved_data["N"].toInt(), act1 = ctx->saved_data["act1"].toInt(), act2 = ctx->saved_data["act2"].toInt();
     const double avg = ctx->saved_data["avg"].toDouble();
@@ -883,14 +890,15 @@ struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
       ok(tmgcn_layer12_bwd_f32((const int64_t*)ptr(sv[5]), (const int32_t*)ptr(sv[6]), (const float*)ptr(sv[7]), (const float*)ptr(dZ),
                                act2 != TMGCN_ACT_NONE ? (const float*)ptr(pre2) : nullptr, (const float*)ptr(H), (const float*)ptr(W1),
                                (int32_t)act1, (const float*)ptr(W2), (int32_t)act2, R, (int32_t)N, (int32_t)K0, (int32_t)F,
-                               (int32_t)Nf, (float*)ptr(dW1), (float)avg, ptr(ws), ws.numel(), stream_of(H)),
+                               (int32_t)Nf, (float*)ptr(dW1), (float)avg, sv[8].numel() >= 2 ? (const int64_t*)ptr(sv[8]) : nullptr,
+                               sv[8].numel() >= 2 ? (int32_t)(sv[8].numel() - 1) : 0, ptr(ws), ws.numel(), stream_of(H)),
          "tmgcn_layer12_bwd_f32");
     }
     if (ctx->needs_input_grad(2)) {
       if (act2 != TMGCN_ACT_NONE) dW2 = bgemm_dW_act(AX, dZ, pre2, act2, false);
       else dW2 = bgemm_dW(AX, dZ, false, TMGCN_DW_AUTO);
     }
-    variable_list out(15);
+    variable_list out(17);
     out[1] = dW1;
     out[2] = dW2;
     return out;
@@ -960,11 +968,11 @@ std::tuple<Tensor, Tensor> head_loss_ad(const Tensor& Z, const OptTensor& W_fold
 }
 Tensor layer12_ad(const Tensor& H, const Tensor& W1, const Tensor& W2, const Tensor& rowptr, const Tensor& col, const Tensor& val,
                   const OptTensor& t_rowptr, const OptTensor& t_col, const OptTensor& t_val, int64_t N, double avg,
-                  int64_t act1, int64_t act2) {
+                  int64_t act1, int64_t act2, const OptTensor& blk, const OptTensor& t_blk) {
   TORCH_CHECK(!(at::GradMode::is_enabled() && H.requires_grad()), "layer12: H is the model's constant input (no gradient is formed for it)");
   const bool grad = at::GradMode::is_enabled();
-  return Layer12Fn::apply(H, W1, W2, rowptr, col, val, t_rowptr, t_col, t_val, N, avg, act1, act2, grad && W1.requires_grad(),
-                          grad && W2.requires_grad());
+  return Layer12Fn::apply(H, W1, W2, rowptr, col, val, t_rowptr, t_col, t_val, N, avg, act1, act2, blk, t_blk,
+                          grad && W1.requires_grad(), grad && W2.requires_grad());
 }
 Tensor activation_ad(const Tensor& x, int64_t act) { return ActivationFn::apply(x, act); }
 Tensor weighted_ce_ad(const Tensor& logits, const Tensor& target, const Tensor& weight, int64_t ignore_index) {
@@ -1015,7 +1023,7 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("edge_head(Tensor Z, Tensor U, Tensor src, Tensor dst, Tensor? eptr, Tensor? eidx) -> Tensor");
   m.def("activation(Tensor x, int act) -> Tensor");
   m.def("layer12(Tensor H, Tensor W1, Tensor W2, Tensor rowptr, Tensor col, Tensor val, Tensor? t_rowptr, Tensor? t_col, "
-        "Tensor? t_val, int N, float avg_nnz_per_row, int act1, int act2) -> Tensor");
+        "Tensor? t_val, int N, float avg_nnz_per_row, int act1, int act2, Tensor? row_blocks=None, Tensor? t_row_blocks=None) -> Tensor");
   m.def("layer12_supported(int K0, int F, int Nf) -> bool", &layer12_supported);
   m.def("weighted_ce(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> Tensor");
   m.def("head_loss(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor arow, Tensor ent, Tensor other, Tensor meta, "

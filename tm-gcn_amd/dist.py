@@ -493,7 +493,7 @@ class ShardedTMGCNLayer:
         #                 (256 threads, 132 VGPRs, 20 KB LDS: rocprofv3) does not fit beside three
         #                 128-VGPR blocks of the fused kernel on a CU (3 x 128 + 136 > 512), so the
         #                 free slot could not host it, and it cost 8 % at world size 1
-        #                 (profiles/r3i_cu_mask_rccl_world1.txt).
+        #                 (profiles/archive/r3i_cu_mask_rccl_world1.txt).
         real_exchange = self.G > 1 and pipeline and exchange == "a2a"
         if grid_reserve is None:
             grid_reserve = 0

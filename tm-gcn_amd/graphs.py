@@ -64,13 +64,50 @@ class GraphedTrainStep:
             out = model()
             return criterion(out, target), out
 
+        params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
+        # where the model keeps each of them: (module, attribute name), so that a step can run on fresh leaf aliases
+        slots = {}
+        for mod in model.modules():
+            for name, q in mod._parameters.items():
+                if q is not None:
+                    slots.setdefault(id(q), []).append((mod, name))
+
+        class _FreshLeaves:
+            """The optimizer's parameters replaced, inside the model, by fresh leaf ALIASES (`p.detach().requires_grad_()`:
+            same storage, no launch) for the duration of a forward.  Why: autograd binds a leaf's AccumulateGrad node to
+            the stream it was created on and keeps it alive as long as ANY graph references it — e.g. the `loss` of an
+            eager epoch the caller still holds.  A backward on another stream then synchronises with that stream, and
+            inside a capture this cross-stream dependency invalidates the capture (hipStreamEndCapture crashes:
+            tools/debug_capture.py; neither loss.backward() nor autograd.grad avoids the node's input buffer).  The
+            aliases' nodes are created by the very forward that uses them, on its stream."""
+
+            def __enter__(self):
+                self.alias = [p.detach().requires_grad_(True) for p in params]
+                for p, a in zip(params, self.alias):
+                    for mod, name in slots.get(id(p), ()):
+                        mod._parameters[name] = a
+                return self.alias
+
+            def __exit__(self, *exc):
+                for p in params:
+                    for mod, name in slots.get(id(p), ()):
+                        mod._parameters[name] = p
+                return False
+
+        def forward_backward():
+            with _FreshLeaves() as alias:
+                loss, out = forward_loss()
+                grads = torch.autograd.grad(loss, alias, grad_outputs=ops.unit_gradient(dev), allow_unused=True)
+            for p, g in zip(params, grads):          # what a backward into an empty .grad leaves behind
+                p.grad = g
+            return loss, out
+
         def one_step():
             if self.folded:
                 from .layers import fused_train_step
                 return fused_train_step(model, criterion, target, optimizer), None
             optimizer.zero_grad(set_to_none=True)
-            loss, out = forward_loss()
-            loss.backward(gradient=ops.unit_gradient(dev))
+            loss, out = forward_backward()
             optimizer.step()
             return loss, out
 
@@ -95,8 +132,7 @@ class GraphedTrainStep:
                 else:
                     if i:
                         optimizer.zero_grad(set_to_none=True)      # host side only: the next backward writes fresh gradients
-                    self.loss, self._output = forward_loss()
-                    self.loss.backward(gradient=self._one)
+                    self.loss, self._output = forward_backward()
                     optimizer.step()
                 self.losses.append(self.loss)
 

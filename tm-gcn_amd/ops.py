@@ -15,6 +15,7 @@ product never does).
 from __future__ import annotations
 
 import functools
+import os
 
 import ctypes as C
 from typing import Optional
@@ -513,6 +514,11 @@ def layer12_supported(K0: int, F: int, Nf: int) -> bool:
     return kernels.name == "hip" and _layer12_widths_ok(int(K0), int(F), int(Nf))
 
 
+# A/B switch of the entry-balanced row blocks of the entry-major layer kernels (tools/: TMGCN_L12_ROW_BLOCKS=0 gives the
+# kernels' own 256-row blocks; the forward's results do not depend on it, the backward's dW1 to fp32 summation order)
+L12_ROW_BLOCKS = os.environ.get("TMGCN_L12_ROW_BLOCKS", "1") != "0"
+
+
 def layer12(H: torch.Tensor, W1: torch.Tensor, act1, A: BatchedCSR, W2: torch.Tensor, act2=None, fuse: Optional[bool] = None):
     """act2((Â ⋆ act1(H·W1))·W2): layers 1 and 2 of the narrow 2-layer models (ehf:330-335 + 348-349; 486-487) with H the
     model's cached constant (AtXt / AX).  One forward and one backward launch (csrc/layer12.hip) when H carries no
@@ -528,8 +534,11 @@ def layer12(H: torch.Tensor, W1: torch.Tensor, act1, A: BatchedCSR, W2: torch.Te
     if not fuse:
         return spmm_feature_gemm(A, feature_gemm(H, W1, act=act1), W2, act=act2)
     need = torch.is_grad_enabled() and W1.requires_grad
+    # row blocks cut by entries where 256-row blocks would hold several tiles (real, skewed data): csr.BatchedCSR.row_blocks
+    blk = A.row_blocks() if (A.N >= 256 and L12_ROW_BLOCKS) else None
+    t_blk = A.transpose().row_blocks() if (need and A.N >= 256 and L12_ROW_BLOCKS) else None
     return kernels.ops.layer12(H, W1.contiguous(), W2.contiguous(), A.rowptr, A.col, A.val, *_csr_t(A, need), A.N, A.avg_nnz_per_row,
-                               _lib.ACT_IDS[act1], _lib.ACT_IDS[act2])
+                               _lib.ACT_IDS[act1], _lib.ACT_IDS[act2], blk, t_blk)
 
 
 def head_loss_sgd(AtXt: torch.Tensor, edges: EdgeIndex, W: torch.Tensor, U: torch.Tensor, target: torch.Tensor, weight: torch.Tensor,
