@@ -89,13 +89,18 @@ def test_link_prediction_script_flow(no_layers):
             assert abs(float(MAP) - ref[0]) <= 5e-4 and abs(float(MRR) - ref[1]) <= 5e-4, (name, float(MAP), float(MRR), ref)
 
 
-def _small_model(cls_module, **attrs):
+def _inputs():
     g9 = golden("g9_data")
     S = [int(s) for s in g9["S"]]
     A, A_labels, Ct_train, _, _, N, M = ehf.load_data(GOLDEN + "/", "g9_saved_content.mat", *S, transformed=True)
     X_train, _, _ = ehf.create_node_features(A, *S, same_block_size=True)
     e = A_labels._indices()
     e = e[:, e[0] < S[0]]
+    return Ct_train, X_train, e, M
+
+
+def _small_model(cls_module, **attrs):
+    Ct_train, X_train, e, M = _inputs()
     torch.manual_seed(0)
     m = cls_module.EmbeddingGCN(Ct_train, X_train, e, M, hidden_feat=[6, 2], condensed_W=True, use_Minv=False)
     for k, v in attrs.items():
@@ -143,6 +148,8 @@ def test_device_result_takes_host_operands_the_way_the_scripts_use_them():
     from tmgcn_amd import hosted as hosted_mod
     hosted_mod.FUSE_HEAD_LOSS = False
     try:
+        out = m()                                             # with the switch off gcn() hands back formed logits, never a placeholder
+        assert type(out) is DeviceResult
         loss2 = nn.CrossEntropyLoss(weight=class_weights)(out, target)
         assert abs(float(loss2) - float(loss)) <= 1e-6 * abs(float(loss))
         (g_out,) = torch.autograd.grad(loss2, out, retain_graph=True)
@@ -200,3 +207,65 @@ def test_host_operands_cross_pcie_once():
     assert big._tmgcn_uploads == 1 and small._tmgcn_uploads == 1
     big[0, 0] = 5.0                                                  # written to: the stale copy is not served
     assert float((out + big).sum()) == 600_004.0 and big._tmgcn_uploads == 2
+
+
+def test_lazy_logits_are_the_values_before_the_step_and_form_on_demand():
+    """Script mode, training epoch: gcn() returns a placeholder (hosted.LazyLogits); the criterion's one launch forms loss,
+    gradients AND the logits — the values before optimizer.step(), which is what the scripts' accuracy lines read afterwards
+    (experiment_reddit_our_link_prediction.py:76-87); anything else that touches the output first forms it from the
+    embedding; reading it for the first time after a step, without the criterion in between, is refused."""
+    import tmgcn_amd.layers as layers
+    from tmgcn_amd import hosted as hosted_mod
+    from tmgcn_amd.hosted import DeviceResult, LazyLogits
+    g = torch.Generator().manual_seed(5)
+    crit_w = torch.tensor([0.8, 0.2])
+    for no_layers in (1, 2):
+        def make(mod):
+            torch.manual_seed(11)
+            Ct_train, X_train, e, M = _inputs()
+            if no_layers == 1:
+                return mod.EmbeddingGCN(Ct_train, X_train, e, M, hidden_feat=[6, 2], condensed_W=True, use_Minv=False), e
+            return mod.EmbeddingGCN2(Ct_train, X_train, e, M, hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False, nonlin2="selu"), e
+        m, e = make(ehf)
+        ref, _ = make(layers)                                   # plain device tensors, logits always formed
+        target = torch.randint(0, 2, (e.shape[1],), generator=g)
+        crit = nn.CrossEntropyLoss(weight=crit_w)
+        crit_dev = nn.CrossEntropyLoss(weight=crit_w.cuda())
+        o1 = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+        o2 = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9)
+        for step in range(4):
+            o1.zero_grad(); o2.zero_grad()
+            out = m()
+            assert type(out) is LazyLogits and out._tmgcn_value is None
+            assert out.shape == (e.shape[1], 2) and out.is_cuda and len(out) == e.shape[1] and out._tmgcn_value is None
+            if step == 2:                                       # something reads the output BEFORE the criterion: formed from the embedding
+                guess_before = torch.argmax(out, dim=1)
+                assert out._tmgcn_value is not None
+            loss = crit(out, target)
+            assert isinstance(loss, DeviceResult) and out._tmgcn_value is not None
+            want = ref()
+            loss_ref = crit_dev(want, target.cuda())
+            loss.backward(); loss_ref.backward()
+            o1.step(); o2.step()
+            # read AFTER the step, as the scripts do: the logits of the parameters before it
+            got = out.detach().as_subclass(torch.Tensor)
+            assert_close(got, want.detach(), 1e-6, f"{no_layers}-layer logits read after step {step}")
+            assert abs(float(loss) - float(loss_ref)) <= 3e-6 * abs(float(loss_ref))      # (the partner is torch-ROCm's fp32 NLL mean)
+            if step == 2:
+                assert torch.equal(guess_before, want.detach().argmax(1))
+            for (n, p), q in zip(m.named_parameters(), ref.parameters()):
+                assert_close(p.detach(), q.detach(), 2e-6, f"{no_layers}-layer {n} after step {step}")
+        # never through the criterion, first read after a parameter changed: refused, with a message that says why
+        out = m()
+        with torch.no_grad():
+            m.U.add_(1.0)
+        with pytest.raises(RuntimeError, match="modified"):
+            out.sum()
+        # evaluation calls and the opt-out form the logits at once
+        with torch.no_grad():
+            assert type(m()) is DeviceResult
+        hosted_mod.FUSE_HEAD_LOSS = False
+        try:
+            assert type(m()) is DeviceResult
+        finally:
+            hosted_mod.FUSE_HEAD_LOSS = True

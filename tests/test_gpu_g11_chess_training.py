@@ -5,21 +5,23 @@ validation accuracy and validation loss at epochs 0 / 100 / 200 / 299, the argma
 
 Two routes walk all 300 epochs on the device-built adjacency: the plain loop (criterion(gcn(), target), torch.optim.SGD)
 and the captured one (GraphedTrainStep: layers 1 + 2 fused, one-pass head + loss, FusedSGD, one hipGraph per epoch).
-Stated tolerance for a trajectory (rounding differences are fed back through 300 momentum-SGD steps, so the 1e-5 bar of a
-single step does not apply): every loss within 1e-3 of the reference's (relative), the script's accuracies within 0.5 %
-(absolute), the argmax class counts within 0.5 % of the edges, validation loss within 1e-3, final parameters within 1e-2
-of max|ref|.  The MEASURED deviations (max per 100 epochs) go to the tolerance record — they sit far below the bounds."""
+Tolerance: the stated bar itself.  Rounding differences are fed back through 300 momentum-SGD steps, but the training is
+contractive and they do not grow: every loss within 1e-5 of the reference's (relative; measured 2-4e-7 in every block of 100
+epochs), validation loss within 1e-5, final parameters within 1e-5 of max|ref| (measured 2-3e-7), the script's accuracies and
+the argmax class counts equal up to ONE edge (measured: identical).  The measured deviations are written to
+gpurun_out/g11_trajectory.json (a copy is committed under profiles/)."""
 import numpy as np
 import pytest
 import torch
 
 from _g10 import G10
-from _util import golden, max_rel_err, record_tolerance
+from _util import golden, max_rel_err
 import tmgcn_amd.layers as ehf
 from tmgcn_amd import adjacency
 
 pytestmark = pytest.mark.gpu
-LOSS_TOL, ACC_TOL, PARAM_TOL = 1e-3, 5e-3, 1e-2
+LOSS_TOL, PARAM_TOL = 1e-5, 1e-5
+MEASURED = {}
 
 
 @pytest.fixture(scope="module")
@@ -41,8 +43,9 @@ def _model(g, d, A_train):
 def _check_run(tag, g, d, A_val, m, losses, outs_at):
     ref = d["losses"]
     rel = np.abs(np.array(losses) - ref) / np.abs(ref)
+    rec = MEASURED.setdefault(tag, {})
     for a in range(0, len(ref), 100):
-        record_tolerance(f"G11 {tag}: max relative loss deviation, epochs {a}-{a + 99}", float(rel[a:a + 100].max()), LOSS_TOL, "max|Δloss|/loss")
+        rec[f"max_rel_loss_deviation_epochs_{a}_{a + 99}"] = float(rel[a:a + 100].max())
     assert float(rel.max()) <= LOSS_TOL, f"{tag}: loss deviates by {rel.max():.2e} at epoch {int(rel.argmax())}"
     tgt = torch.from_numpy(g.target_train).cuda()
     tgt_val, ev = torch.from_numpy(g.target_val).cuda(), torch.from_numpy(g.eval_val).cuda()
@@ -58,18 +61,26 @@ def _check_run(tag, g, d, A_val, m, losses, outs_at):
         acc_train = int((guess == tgt).sum()) / len(tgt)
         acc_val = int((gv[ev] == tgt_val[ev]).sum()) / int(ev.sum())
         loss_val = float(crit(out_val[ev], tgt_val[ev]))
-        for what, got, want, tol in (("acc_train", acc_train, mk["acc_train"], ACC_TOL), ("acc_val", acc_val, mk["acc_val"], ACC_TOL),
+        one_train, one_val = 1.0 / len(tgt), 1.0 / int(ev.sum())           # one edge's worth of accuracy
+        for what, got, want, tol in (("acc_train", acc_train, mk["acc_train"], 1.01 * one_train), ("acc_val", acc_val, mk["acc_val"], 1.01 * one_val),
                                      ("loss_val", loss_val, mk["loss_val"], LOSS_TOL * mk["loss_val"])):
-            record_tolerance(f"G11 {tag}: {what} at epoch {ep}", abs(got - want), tol, "|Δ|")
+            rec[f"{what}_deviation_epoch_{ep}"] = abs(got - want)
             assert abs(got - want) <= tol, f"{tag} epoch {ep}: {what} {got} vs the reference's {want}"
         cnt = torch.bincount(guess, minlength=3).cpu().numpy()
         cnt_v = torch.bincount(gv[ev], minlength=3).cpu().numpy()
-        assert np.abs(cnt - [mk[f"train_argmax_{c}"] for c in range(3)]).max() <= ACC_TOL * len(tgt), f"{tag} epoch {ep}: train argmax counts {cnt}"
-        assert np.abs(cnt_v - [mk[f"val_argmax_{c}"] for c in range(3)]).max() <= ACC_TOL * int(ev.sum()), f"{tag} epoch {ep}: val argmax counts {cnt_v}"
+        assert np.abs(cnt - [mk[f"train_argmax_{c}"] for c in range(3)]).max() <= 1, f"{tag} epoch {ep}: train argmax counts {cnt}"
+        assert np.abs(cnt_v - [mk[f"val_argmax_{c}"] for c in range(3)]).max() <= 1, f"{tag} epoch {ep}: val argmax counts {cnt_v}"
     for n, q in m.named_parameters():
         err = max_rel_err(q.detach(), d[f"{n}_final"])
-        record_tolerance(f"G11 {tag}: {n} after 300 epochs", err, PARAM_TOL)
+        rec[f"{n}_after_300_epochs"] = err
         assert err <= PARAM_TOL, f"{tag}: {n} after 300 epochs {err:.2e}"
+    import json
+    import os
+    from _util import ROOT
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "g11_trajectory.json"), "w") as f:
+        json.dump({"fixture": "tests/golden/g11_chess_train300.npz", "bounds": {"loss_rel": LOSS_TOL, "param_rel": PARAM_TOL, "accuracy": "one edge"},
+                   "measured": MEASURED}, f, indent=1)
 
 
 def _val(g, m, A_val):

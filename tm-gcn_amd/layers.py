@@ -224,9 +224,23 @@ class _Head:
     def forward(self, At=None, X=None, edges=None):
         Z, eidx, U, fold = self._embed(At, X, edges)
         head = (Z, eidx, U, fold) if (self._shard is None and self.host_operands) else None
-        if fold is not None:
-            Z = ops.feature_gemm(Z, fold)                                    # ehf:222
-        return self._deliver(self._head(Z, eidx, U), head)
+
+        def form():
+            Zf = ops.feature_gemm(Z, fold) if fold is not None else Z        # ehf:222
+            return self._head(Zf, eidx, U)
+
+        if head is not None and self.output_device is None and torch.is_grad_enabled() and U.requires_grad:
+            # script mode, training epoch: the criterion will take the one-pass head + loss kernel from `head` and never read
+            # the logits; they are formed by that launch as a by-product, or on first use by anything else (hosted.LazyLogits)
+            from . import hosted
+            if hosted.FUSE_HEAD_LOSS and hosted.LAZY_LOGITS and eidx.index_dtype == torch.int32:
+                key = ((fold if fold is not None else Z).shape[-1], U.shape[-1], Z.shape[-1] if fold is not None else 0)
+                ok = self.__dict__.setdefault("_lazy_ok", {})
+                if key not in ok:
+                    ok[key] = ops.head_loss_supported(*key)
+                if ok[key]:
+                    return hosted.LazyLogits.make(head, eidx.E, U.shape[-1], Z.device, form)
+        return self._deliver(form(), head)
 
     def loss(self, criterion, target: torch.Tensor, At=None, X=None, edges=None, want_logits: bool = False,
              unit_grad: bool = False):

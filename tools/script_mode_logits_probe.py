@@ -5,9 +5,10 @@ An untouched reference script calls `output = gcn(); loss = criterion(output, ta
 76-77).  With hosted.FUSE_HEAD_LOSS the criterion takes the one-pass head + loss kernel from what `output` was formed from,
 so the logits launch(es) inside gcn() — the edge head, and for the 1-layer model the AtXt·W GEMM in front of it — produce a
 tensor nobody reads in an ordinary epoch.  Forming them lazily would need a snapshot of U (and W) at call time (the scripts
-read `output_train` AFTER optimizer.step(), :81/:87) — one small launch instead of one or two.  This probe measures the UPPER
-BOUND of what laziness could buy: gcn() returns an UNINITIALISED [E, C] tensor that carries the head (no logits launch, no
-snapshot launch at all), everything else as in script mode.
+read `output_train` AFTER optimizer.step(), :81/:87) — one small launch instead of one or two.  hosted.LazyLogits (round 5) avoids the snapshot: the
+criterion's own launch writes the logits as a by-product.  This probe times, interleaved in one process: script mode with the
+placeholder (hosted.LAZY_LOGITS = True, the default), with the logits formed by gcn() (False: round 4), and the UPPER BOUND —
+gcn() returns an UNINITIALISED [E, C] tensor that carries the head (no logits launch, no by-product store).
     python tools/script_mode_logits_probe.py [S1 S2 S3]"""
 import json
 import os
@@ -35,12 +36,17 @@ def main():
         spec = bench.EPOCH_MODELS[name]
         orig = layers._Head.forward
         r = {}
-        for tag, fwd in (("script", orig), ("script_without_logits_upper_bound", no_logits_forward), ("script_again", orig)):
+        from tmgcn_amd import hosted
+        for tag, fwd, lazy in (("script_lazy", orig, True), ("script_logits_formed_by_gcn", orig, False),
+                               ("script_without_logits_upper_bound", no_logits_forward, False),
+                               ("script_lazy_again", orig, True), ("script_logits_formed_by_gcn_again", orig, False)):
             layers._Head.forward = fwd
+            hosted.LAZY_LOGITS = lazy
             try:
                 _, med, best = bench.gpu_epochs(g, spec, 50, "script")
             finally:
                 layers._Head.forward = orig
+                hosted.LAZY_LOGITS = True
             r[tag + "_ms"] = round(med * 1e3, 4)
             r[tag + "_ms_min_pass"] = round(best * 1e3, 4)
         rec[name] = r
