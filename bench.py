@@ -1026,6 +1026,8 @@ def worker(args):
     stage("done")
     bad = [v for v in (res.get("verify"), ((compare or {}).get("full_n") or {}).get(
         ("allgather" if args.exchange == "a2a" else "a2a") + "_verify")) if v is not None and not v["ok"]]
+    if skewed is not None and "error" not in skewed and skewed.get("verify_ok") is False:
+        bad.append({"roofline_skewed": skewed.get("verify")})
     if bad:
         sys.stderr.write(f"[bench r{rank}] VERIFY FAILED: {json.dumps(bad)}\n")
         sys.exit(3)

@@ -36,7 +36,7 @@ def ref_spmm(csr, X):
 
 
 # ------------------------------------------------------------------------------------- P2
-@pytest.mark.parametrize("F", [1, 2, 3, 4, 6, 8, 5, 12, 16, 20, 32, 64, 100, 128, 256, 260])
+@pytest.mark.parametrize("F", [1, 2, 3, 4, 6, 8, 5, 12, 16, 20, 32, 64, 100, 128, 256, 260, 512, 1000])
 @pytest.mark.parametrize("T,N,deg", [(3, 50, 4.0), (2, 301, 40.0), (1, 7, 1.5)])
 def test_spmm_vs_oracle(F, T, N, deg):
     csr = rand_csr(T, N, deg, seed=F * 7 + N)
@@ -88,14 +88,14 @@ LONG_ROW_CASES = {
 
 
 @pytest.mark.parametrize("case", list(LONG_ROW_CASES))
-@pytest.mark.parametrize("F", [64, 128, 256])
+@pytest.mark.parametrize("F", [64, 128, 256, 520])
 def test_spmm_long_rows_split_across_waves(case, F):
     """Rows longer than 256 entries are gathered by the four waves of their block (quarters of the row, partial sums added
     in wave order) and tiles of more than 8192 entries are processed before the counter-driven loop starts
     (csrc/spmm_row.h): against the C oracle's row-by-row sum, and reproducible to the bit."""
     T, N, lengths = LONG_ROW_CASES[case]
-    if F == 256 and N > 10_000:
-        pytest.skip("the wide case is covered on the small shapes")
+    if F >= 256 and N > 10_000:
+        pytest.skip("the wide cases are covered on the small shapes")
     csr = _csr_with_row_lengths(T, N, lengths, seed=F + N)
     X = torch.randn(T, N, F, generator=torch.Generator().manual_seed(2))
     A = csr.to(DEV)

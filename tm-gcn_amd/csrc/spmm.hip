@@ -8,7 +8,7 @@
 // HBM-bound gather: per stored non-zero the kernel moves 8 B of (col,val) and one
 // F*4-byte row of X; per row 8 B of rowptr and one F*4-byte output row.  Three
 // kernels cover the F regimes of the reference's configs:
-//   spmm_vec4   F % 4 == 0, F >= 16   lanes across F (float4 per lane), S = 64/LPR
+//   spmm_vec4   F % 4 == 0, F >= 16   lanes across F (float4 per lane; F > 256 as column chunks of 256), S = 64/LPR
 //                                      non-zero streams per wave, DPP/shuffle combine
 //   spmm_small  F in {1,2,3,4,6,8}     lanes across non-zeros (G lanes per row),
 //                                      wavefront-shuffle segmented sum
@@ -66,21 +66,26 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
     TileRows rows;
     rows.load(rowptr, r_begin, r_end, lane);
     if (TMGCN_HEAVY_FIRST && !scanning && rows.entries > heavy.thr) continue;   // done in somebody's pass 1
-    for (int rr = wave; rr < (int)(r_end - r_begin); rr += 4) {
-      if ((rows.long_mask >> rr) & 1) continue;
-      const int64_t r = r_begin + rr;
-      const int64_t slice = r / N;
-      const float4 acc = gather_row<LPR, U>(col, val, X + slice * (int64_t)N * F4, readlane64(rows.beg, rr),
-                                            readlane64(rows.end, rr), F4, lane);
-      if (lane < LPR && lane < F4) store_f4(&Y[r * F4 + lane], acc);
-    }
-    for (uint64_t m = rows.long_mask; m; m &= m - 1) {          // long rows: all four waves on each
-      const int rr = __builtin_ctzll(m);
-      const int64_t r = r_begin + rr;
-      const int64_t slice = r / N;
-      const float4 acc = gather_long_row<LPR, U>(col, val, X + slice * (int64_t)N * F4, readlane64(rows.beg, rr),
-                                                 readlane64(rows.end, rr), F4, lane, wave, s_part);
-      if (wave == (rr & 3) && lane < LPR && lane < F4) store_f4(&Y[r * F4 + lane], acc);
+    // a row wider than 64 float4 (F > 256; LPR = 64 then) is gathered as column chunks of 256 floats: the row's entries are
+    // walked once per chunk (col / val come from L1 the second time), every gather is still a contiguous 1 KB piece
+    for (int c0 = 0; c0 < F4; c0 += kWave) {
+      const int w4 = F4 - c0 < kWave ? F4 - c0 : kWave;     // == F4 whenever F <= 256
+      for (int rr = wave; rr < (int)(r_end - r_begin); rr += 4) {
+        if ((rows.long_mask >> rr) & 1) continue;
+        const int64_t r = r_begin + rr;
+        const int64_t slice = r / N;
+        const float4 acc = gather_row<LPR, U>(col, val, X + slice * (int64_t)N * F4 + c0, readlane64(rows.beg, rr),
+                                              readlane64(rows.end, rr), w4, lane, F4);
+        if (lane < LPR && lane < w4) store_f4(&Y[r * F4 + c0 + lane], acc);
+      }
+      for (uint64_t m = rows.long_mask; m; m &= m - 1) {          // long rows: all four waves on each
+        const int rr = __builtin_ctzll(m);
+        const int64_t r = r_begin + rr;
+        const int64_t slice = r / N;
+        const float4 acc = gather_long_row<LPR, U>(col, val, X + slice * (int64_t)N * F4 + c0, readlane64(rows.beg, rr),
+                                                   readlane64(rows.end, rr), w4, lane, wave, s_part, F4);
+        if (wave == (rr & 3) && lane < LPR && lane < w4) store_f4(&Y[r * F4 + c0 + lane], acc);
+      }
     }
   }
 }
@@ -233,11 +238,11 @@ extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int3
     default: break;
   }
 
-  if (F % 4 == 0 && F >= 16 && F <= 256 &&
+  if (F % 4 == 0 && F >= 16 && F <= 4096 &&
       (reinterpret_cast<uintptr_t>(X) % 16 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0)) {
     const int F4 = F / 4;
     int lpr = 4;
-    while (lpr < F4) lpr <<= 1;
+    while (lpr < F4 && lpr < 64) lpr <<= 1;                 // F > 256: 64 lanes, column chunks of 256 floats
     const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
     TMGCN_REQUIRE(n_tiles < (int64_t)0x7fffffff, "spmm: too many row tiles");
     unsigned int* counter = acquire_tile_counter(st);

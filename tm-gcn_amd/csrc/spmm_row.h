@@ -20,11 +20,13 @@ __device__ __forceinline__ void store_f1(float* p, float v) { __builtin_nontempo
 // non-zeros; the row's (col,val) pairs are fetched 64 at a time with one coalesced load per
 // array and handed to the streams with ds_bpermute (__shfl); U 16-B gathers in flight per lane.
 // On return every lane of stream 0 (sub == 0) holds the full sum (fixed butterfly order).
+// `stride4` = row pitch of Xs in float4 (default: F4, a dense [N][F] matrix); a wider matrix is gathered as column chunks.
 template <int LPR, int U>
 __device__ __forceinline__ float4 gather_row(const int32_t* __restrict__ col,
                                              const float* __restrict__ val,
                                              const float4* __restrict__ Xs, int64_t beg,
-                                             int64_t end, int F4, int lane) {
+                                             int64_t end, int F4, int lane, int stride4 = 0) {
+  if (stride4 == 0) stride4 = F4;
   constexpr int S = kWave / LPR;
   const int sub = lane / LPR;
   const int fl = lane % LPR;
@@ -47,7 +49,7 @@ __device__ __forceinline__ float4 gather_row(const int32_t* __restrict__ col,
         const int cc = __shfl(c, idx & 63);
         vv[u] = __shfl(v, idx & 63);
         x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < n && f_ok) x[u] = Xs[(int64_t)cc * F4 + fl];
+        if (idx < n && f_ok) x[u] = Xs[(int64_t)cc * stride4 + fl];
         if (idx >= n) vv[u] = 0.f;
       }
 #pragma unroll
@@ -166,12 +168,12 @@ struct TileRows {
 template <int LPR, int U>
 __device__ __forceinline__ float4 gather_long_row(const int32_t* __restrict__ col, const float* __restrict__ val,
                                                   const float4* __restrict__ Xs, int64_t beg, int64_t end, int F4, int lane,
-                                                  int wave, float4* part) {
+                                                  int wave, float4* part, int stride4 = 0) {
   const int64_t q = (((end - beg + 3) >> 2) + (kWave - 1)) & ~(int64_t)(kWave - 1);
   int64_t b = beg + wave * q, e = b + q;
   if (b > end) b = end;
   if (e > end) e = end;
-  const float4 p = gather_row<LPR, U>(col, val, Xs, b, e, F4, lane);
+  const float4 p = gather_row<LPR, U>(col, val, Xs, b, e, F4, lane, stride4);
   if (lane < LPR) part[wave * LPR + lane] = p;
   __syncthreads();
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -48,7 +48,8 @@ def run(lib, which):
 
 
 res = {}
-for which in ("spmm", "fused", "fused+ax"):
+KINDS = ("spmm", "fused", "fused+ax") if F <= 128 else ("spmm",)          # the fused kernel takes K <= 128
+for which in KINDS:
     for name, lib in libs.items():
         assert run(lib, which) == 0
     torch.cuda.synchronize()
@@ -64,7 +65,7 @@ for which in ("spmm", "fused", "fused+ax"):
 ref = None
 for name, lib in libs.items():
     Y.zero_(); AX.zero_()
-    assert run(lib, "fused+ax") == 0
+    assert run(lib, KINDS[-1]) == 0
     torch.cuda.synchronize()
     if ref is None:
         ref = (Y.clone(), AX.clone())

@@ -63,6 +63,25 @@ def spmm(T=4, N=2_000_000, F=128, deg=32):
     print(f"spmm_gemm (+AX store): {ms:.2f} ms  {by / ms / 1e6:.0f} GB/s (P2 bytes only)")
 
 
+def wide(T=4, N=1_000_000, deg=32):
+    """Feature widths beyond the fused kernel's K <= 128: the plain SpMM (vec4 up to F = 256, the generic kernel above) and
+    the standalone GEMM (bf16-split, k-chunks above 128) — what a layer of that width runs as two launches."""
+    A = synth.device_er_csr(T, N, deg, dev)
+    for F in (64, 128, 256, 512):
+        X = torch.rand(T, N, F, device=dev)
+        by = A.nnz * (8 + F * 4 + (4 + F * 4) / (A.nnz / A.n_rows))
+        ms = timeit(lambda: K.spmm(A, X))
+        line = f"wide F={F}: spmm {ms:.2f} ms {by / ms / 1e6:.0f} GB/s"
+        W = torch.randn(F, F, device=dev) * 0.1
+        msg = timeit(lambda: K.gemm(X, W))
+        line += f" | gemm {F}x{F} {msg:.2f} ms {2 * X.numel() * 4 / msg / 1e6:.0f} GB/s {2.0 * T * N * F * F / msg / 1e9:.1f} TFLOP/s"
+        if K.spmm_gemm_supported(F, F):
+            msf = timeit(lambda: K.spmm_gemm(A, X, W))
+            line += f" | fused {msf:.2f} ms"
+        print(line, flush=True)
+        del X
+
+
 def mtransform_dense(T=128, N=250_000, F=128):
     import numpy as np
     X = torch.rand(T, N, F, device=dev)
@@ -85,6 +104,8 @@ if __name__ == "__main__":
             gemm()
         elif w == "spmm":
             spmm()
+        elif w == "wide":
+            wide()
         elif w == "dense":
             mtransform_dense()
             mtransform_dense(T=64, N=20000, F=6)
