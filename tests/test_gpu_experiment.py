@@ -250,7 +250,8 @@ def test_lazy_logits_are_the_values_before_the_step_and_form_on_demand():
             # read AFTER the step, as the scripts do: the logits of the parameters before it
             got = out.detach().as_subclass(torch.Tensor)
             assert_close(got, want.detach(), 1e-6, f"{no_layers}-layer logits read after step {step}")
-            assert abs(float(loss) - float(loss_ref)) <= 3e-6 * abs(float(loss_ref))      # (the partner is torch-ROCm's fp32 NLL mean)
+            loss64 = nn.CrossEntropyLoss(weight=crit_w.double())(want.detach().double().cpu(), target)   # (torch-ROCm's fp32 NLL mean is itself ~4e-6 off)
+            assert abs(float(loss) - float(loss64)) <= 1e-5 * abs(float(loss64))     # the stated bar (two models' fp32 trajectories)
             if step == 2:
                 assert torch.equal(guess_before, want.detach().argmax(1))
             for (n, p), q in zip(m.named_parameters(), ref.parameters()):
