@@ -44,7 +44,8 @@ typedef enum {
 /* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
 enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
 
-/* ABI version 5 = version 4 + tmgcn_pool_stats + the row_blocks partition argument of tmgcn_layer12_fwd/bwd_f32; the launchers' scratch words (tile counters, hand-off blocks) are kept apart
+/* ABI version 5 = version 4 + tmgcn_pool_stats + the row_blocks partition argument of tmgcn_layer12_fwd/bwd_f32 + the giant-row
+ *   plan entry points tmgcn_spmm_csr_batched_f32_plan / tmgcn_spmm_gemm_f32_plan / tmgcn_spmm_giant_workspace_bytes; the launchers' scratch words (tile counters, hand-off blocks) are kept apart
  *   per stream (eager launches) and per recorded launch (hipGraph capture), and a launcher that cannot keep two launches
  *   apart returns TMGCN_ERR_INVALID with the reason instead of re-using a word that may be in flight (csrc/pools.hip).
  * ABI version 4 = version 3 + tmgcn_head_loss_f32 / tmgcn_scale2_f32 (one-pass edge head + loss + gradients).
@@ -122,6 +123,19 @@ int tmgcn_mtransform_ld_f32(const float* M, int32_t Tm, int32_t ldm, int32_t tra
  *
  * Row sums are formed in a fixed order (no atomics): bitwise reproducible.
  */
+/* Giant rows (optional plan of the two SpMM launchers below; csr.BatchedCSR.giant_plan builds it): a row of more than
+ * TMGCN_GIANT_ROW stored entries is cut into chunks of TMGCN_GIANT_CHUNK entries (the last one shorter), each summed by one
+ * block of a small launch in front of the main kernel, which then adds the partial sums in chunk order instead of gathering the
+ * row on the four waves of ONE block (41 M entries/s: a 10^6-entry row would cost 23 ms whatever else the launch holds).
+ *   giant_rows    int64 [n_giant]      ascending global row indices (k*N + i) of EVERY row with more than TMGCN_GIANT_ROW entries
+ *   giant_chunks  int32 [n_giant + 1 + n_giant_chunks]  first chunk of each giant row (n_giant + 1 values, 0 … n_giant_chunks),
+ *                                      then for every chunk the index of its giant row
+ *   giant_ws      float [n_giant_chunks][F]   workspace (tmgcn_spmm_giant_workspace_bytes)
+ * All NULL / 0 = no plan.  Results are bit-reproducible for a given plan; with and without a plan they differ by fp32
+ * summation order on the giant rows only. */
+#define TMGCN_GIANT_ROW 32768
+#define TMGCN_GIANT_CHUNK 4096
+int64_t tmgcn_spmm_giant_workspace_bytes(int32_t n_giant_chunks, int32_t F);
 int tmgcn_spmm_csr_batched_f32(const int64_t* rowptr, const int32_t* col, const float* val,
                                const float* X, float* Y, int64_t n_rows, int32_t N, int32_t F,
                                void* stream);
@@ -131,6 +145,12 @@ int tmgcn_spmm_csr_batched_f32(const int64_t* rowptr, const int32_t* col, const 
 int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int32_t* col, const float* val,
                                     const float* X, float* Y, int64_t n_rows, int32_t N,
                                     int32_t F, float avg_nnz_per_row, void* stream);
+/* … with a giant-row plan (above; used by the F % 4 == 0, F >= 16 kernel, ignored by the narrow ones) */
+int tmgcn_spmm_csr_batched_f32_plan(const int64_t* rowptr, const int32_t* col, const float* val,
+                                    const float* X, float* Y, int64_t n_rows, int32_t N,
+                                    int32_t F, float avg_nnz_per_row, const int64_t* giant_rows,
+                                    const int32_t* giant_chunks, int32_t n_giant, int32_t n_giant_chunks,
+                                    float* giant_ws, int64_t giant_ws_bytes, void* stream);
 
 /* ---- P2+P3 fused: Y = act((Â ⋆ X) · Wop) in one launch ------------------------------
  * Replaces the pair  sparse.mm loop + t.matmul(AtXt, W)  (ehf:206-207 + 222, 303-304 + 349,
@@ -160,6 +180,15 @@ int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* col, const fl
                              int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
                              float* Y, float* AX, float* pre_act, int32_t grid_reserve,
                              float avg_nnz_per_row, void* stream);
+/* … with a giant-row plan (the MFMA-epilogue kernel, K a multiple of 8 in [16, 128]; ignored by the narrow one) */
+int tmgcn_spmm_gemm_f32_plan(const int64_t* rowptr, const int32_t* col, const float* val,
+                             const float* X, int64_t n_rows, int32_t N, int32_t K,
+                             const float* W, int32_t Nf, int32_t trans_w,
+                             int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
+                             float* Y, float* AX, float* pre_act, int32_t grid_reserve,
+                             float avg_nnz_per_row, const int64_t* giant_rows, const int32_t* giant_chunks,
+                             int32_t n_giant, int32_t n_giant_chunks, float* giant_ws, int64_t giant_ws_bytes,
+                             void* stream);
 
 /* ---- P3: feature·weight contraction ----------------------------------------------
  * Replaces  t.matmul(AtXt, Wt)  ehf:222, 330, 340, 344, 349, 415, 486-489.

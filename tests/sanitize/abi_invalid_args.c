@@ -44,6 +44,9 @@ int main(void) {
   BAD(tmgcn_mtransform_f32(0, -1, 4, 0, 0, 0, 4, 4, 3, 0, 0, 0, 16, 0, 0, 0));           /* negative T */
   BAD(tmgcn_mtransform_ld_f32(0, 4, 4, 0, 0, 0, 4, 4, 3, 0, 0, 2, 0, 2, 16, 0, 0, 0));   /* ld < C, nulls */
   /* P2 */
+  BAD(tmgcn_spmm_csr_batched_f32_plan(0, 0, 0, 0, 0, 9, 3, 128, -1.f, 0, 0, -1, 0, 0, 0, 0));              /* negative giant count */
+  BAD(tmgcn_spmm_gemm_f32_plan(0, 0, 0, 0, 9, 3, 128, 0, 128, 0, 0, 0, 0, 0, 0, 0, 0, -1.f, 0, 0, 2, 1, 0, 0, 0));  /* nulls */
+  if (tmgcn_spmm_giant_workspace_bytes(3, 128) != 3 * 128 * 4 || tmgcn_spmm_giant_workspace_bytes(0, 128) != 0) { ++failures; printf("FAIL giant workspace bytes\n"); }
   BAD(tmgcn_spmm_csr_batched_f32(0, 0, 0, 0, 0, 10, 3, 4, 0));                            /* rows not a multiple of N */
   BAD(tmgcn_spmm_csr_batched_f32(0, 0, 0, 0, 0, 9, 3, 4, 0));                             /* null pointers */
   BAD(tmgcn_spmm_csr_batched_f32_hint(0, 0, 0, 0, 0, 9, 3, 0, 1.0f, 0));                  /* F = 0 */

@@ -127,6 +127,65 @@ def test_spmm_gemm_long_rows_split_across_waves(case, K, Nf, per_slice):
     assert torch.equal(Y, Y2)
 
 
+GIANT_ROWS = {(0, 17): 1_000_000, (0, 18): 40_000, (0, 90_000): 32_769, (1, 50_000): 32_768, (1, 50_001): 65_536,
+              (1, 100_002): 200_001, (1, 0): 20_000}
+
+
+@pytest.mark.parametrize("F", [16, 128, 320])
+def test_spmm_giant_rows_are_summed_chunk_by_chunk(F):
+    """Rows of more than 32 768 entries take the giant-row plan (csr.BatchedCSR.giant_plan -> tmgcn_spmm_csr_batched_f32_plan):
+    4 096-entry chunks summed by a launch in front of the main kernel, partial sums added in chunk order.  Against the C oracle,
+    bit-reproducible, and within fp32 summation order of the plan-less route (four waves of one block per row)."""
+    T, N = 2, 100_003
+    csr = _csr_with_row_lengths(T, N, GIANT_ROWS, seed=F)
+    A = csr.to(DEV)
+    rows, chunks = A.giant_plan()
+    want_rows = sorted(k * N + i for (k, i), n in GIANT_ROWS.items() if n > 32_768)
+    assert rows.tolist() == want_rows and chunks.numel() == len(want_rows) + 1 + int(chunks[len(want_rows)])
+    assert int(chunks[len(want_rows)]) == sum((n + 4_095) // 4_096 for n in GIANT_ROWS.values() if n > 32_768)
+    X = torch.randn(T, N, F, generator=torch.Generator().manual_seed(2))
+    Xd = X.to(DEV)
+    Y = ops.kernels.spmm(A, Xd)
+    ref = ref_spmm(csr, X)
+    assert_close(Y, ref, REL_TOL, f"giant rows F={F}")
+    special = torch.tensor([k * N + i for (k, i) in GIANT_ROWS])
+    assert_close(Y.reshape(T * N, F)[special.to(DEV)], ref.reshape(T * N, F)[special], REL_TOL, f"giant rows F={F}: the special rows")
+    assert torch.equal(Y, ops.kernels.spmm(A, Xd))
+    Y0 = ops.kernels.ops.spmm_csr_batched(A.rowptr, A.col, A.val, Xd, N, A.avg_nnz_per_row, None, None)     # no plan
+    assert_close(Y0, ref, REL_TOL, "plan-less route")
+    other = torch.ones(T * N, dtype=torch.bool)
+    other[torch.tensor(want_rows)] = False
+    assert torch.equal(Y.reshape(T * N, F)[other.to(DEV)], Y0.reshape(T * N, F)[other.to(DEV)])          # only the giant rows differ
+
+
+@pytest.mark.parametrize("K,Nf,per_slice", [(128, 128, False), (64, 32, True)])
+def test_spmm_gemm_giant_rows(K, Nf, per_slice):
+    """The same plan through the fused kernel (forward operand) and, by autograd, through its transposed operand."""
+    T, N = 2, 100_003
+    csr = _csr_with_row_lengths(T, N, GIANT_ROWS, seed=K)
+    g = torch.Generator().manual_seed(K * 3 + Nf)
+    X = torch.randn(T, N, K, generator=g)
+    W = torch.randn(*((T, K, Nf) if per_slice else (K, Nf)), generator=g) * 0.2
+    A = csr.to(DEV)
+    Y, AX, _ = ops.kernels.spmm_gemm(A, X.to(DEV), W.to(DEV), want_ax=True)
+    ref_ax = ref_spmm(csr, X)
+    assert_close(AX, ref_ax, REL_TOL, "giant rows: SpMM intermediate")
+    assert_close(Y, ref_gemm(ref_ax, W, False, per_slice), REL_TOL, f"giant rows: fused K={K} Nf={Nf}")
+    assert torch.equal(AX, ops.kernels.spmm(A, X.to(DEV))), "fused and plain kernels sum a giant row in different orders"
+    assert torch.equal(Y, ops.kernels.spmm_gemm(A, X.to(DEV), W.to(DEV))[0])
+    if not per_slice:        # autograd: the TRANSPOSED operand has its own plan (giant COLUMNS of Â: here none — hubs gather, they are not gathered)
+        Xg, Wg = X.to(DEV).requires_grad_(True), W.to(DEV).requires_grad_(True)
+        dY = torch.randn(T, N, Nf, generator=g)
+        ops.spmm_feature_gemm(A, Xg, Wg).backward(dY.to(DEV))
+        assert_close(Xg.grad, ref_spmm(csr.transpose(), ref_gemm(dY, W, trans_w=True)), REL_TOL, "dX")
+        # and with the roles swapped — the transpose as the forward operand: its transpose (= csr) brings the giant plan to the backward
+        At = csr.transpose().to(DEV)
+        assert At.giant_plan()[0] is None and At.transpose().giant_plan()[0] is not None
+        Xg2 = X.to(DEV).requires_grad_(True)
+        ops.spmm_feature_gemm(At, Xg2, Wg.detach()).backward(dY.to(DEV))
+        assert_close(Xg2.grad, ref_spmm(csr, ref_gemm(dY, W, trans_w=True)), REL_TOL, "dX through the giant plan of the transpose")
+
+
 @pytest.mark.parametrize("symmetric", [False, True])
 def test_layer_on_powerlaw_graph_vs_oracle(symmetric):
     """The S4-shaped layer (F 128 -> 128) on synth.device_powerlaw_csr (capped-Zipf row lengths; the cap reaches N here):

@@ -35,6 +35,10 @@ SIGNATURES = {
     "tmgcn_mtransform_ld_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
     "tmgcn_spmm_csr_batched_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_spmm_csr_batched_f32_hint": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, C.c_float, _p]),
+    "tmgcn_spmm_giant_workspace_bytes": (_i64, [_i32, _i32]),
+    "tmgcn_spmm_csr_batched_f32_plan": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, C.c_float, _p, _p, _i32, _i32, _p, _i64, _p]),
+    "tmgcn_spmm_gemm_f32_plan": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _i32, _i64, _i64, _i32, _p, _p, _p, _i32, C.c_float,
+                                           _p, _p, _i32, _i32, _p, _i64, _p]),
     "tmgcn_spmm_gemm_supported": (C.c_int, [_i32, _i32]),
     "tmgcn_spmm_gemm_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _i32, _i64, _i64, _i32, _p, _p, _p, _i32, _p]),
     "tmgcn_spmm_gemm_f32_hint": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p, _i32, _i32, _i64, _i64, _i32, _p, _p, _p, _i32, C.c_float, _p]),

@@ -17,9 +17,13 @@ ordered by column, so every row sum has a fixed order.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
+
+
+_GIANT_PLAN = os.environ.get("TMGCN_GIANT_PLAN", "1") != "0"      # A/B switch (tools/): 0 = never build a giant-row plan
 
 
 class BatchedCSR:
@@ -200,6 +204,27 @@ class BatchedCSR:
                 blk = torch.unique(torch.cat([cut, torch.tensor([R], device=dev, dtype=torch.int64)]))   # sorted; empty parts vanish
                 self._blocks[key] = blk.contiguous()
         return self._blocks[key]
+
+    GIANT_ROW, GIANT_CHUNK = 32768, 4096          # include/tmgcn.h: TMGCN_GIANT_ROW, TMGCN_GIANT_CHUNK
+
+    def giant_plan(self):
+        """The giant-row plan of the SpMM launchers (include/tmgcn.h "Giant rows"), cached: rows of more than GIANT_ROW
+        stored entries are summed chunk by chunk (GIANT_CHUNK entries, one block each) by a small launch in front of the main
+        kernel instead of on the four waves of one block.  Returns (rows int64 [n], chunks int32 [n + 1 + m]) on the
+        adjacency's device — ascending row indices; first chunk of every giant row, then every chunk's giant row — or
+        (None, None) when no row is that long (every adjacency in the reference's scope: one host sync per CSR to find out)."""
+        if "giant" not in self._blocks:
+            cnt = self.rowptr[1:] - self.rowptr[:-1]
+            plan = (None, None)
+            if self.n_rows and self.device.type == "cuda" and _GIANT_PLAN and int(cnt.max()) > self.GIANT_ROW:
+                rows = torch.nonzero(cnt > self.GIANT_ROW).reshape(-1)
+                n_chunks = (cnt[rows] + self.GIANT_CHUNK - 1) // self.GIANT_CHUNK
+                chunk_ptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=self.device)
+                torch.cumsum(n_chunks, 0, out=chunk_ptr[1:])
+                chunk_giant = torch.repeat_interleave(torch.arange(rows.numel(), device=self.device), n_chunks)
+                plan = (rows.contiguous(), torch.cat([chunk_ptr, chunk_giant]).to(torch.int32).contiguous())
+            self._blocks["giant"] = plan
+        return self._blocks["giant"]
 
     def slices(self, k0: int, k1: int) -> "BatchedCSR":
         """Slices [k0, k1) as their own batched CSR (the shard one rank owns)."""

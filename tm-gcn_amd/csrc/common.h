@@ -67,6 +67,12 @@ __device__ __forceinline__ bool last_block_ticket(int32_t* sync, int n_blocks, i
   return *lds_flag != 0;
 }
 
+// Giant-row pre-pass (spmm.hip; used by the plain and the fused SpMM launchers): validates the plan, launches one block per
+// chunk that writes the chunk's partial sum of Â·X to `ws`.  Returns TMGCN_OK without a launch when n_giant == 0.
+int launch_giant_partial(const char* who, const int64_t* rowptr, const int32_t* col, const float* val, const float* X, int32_t N,
+                         int32_t F, const int64_t* giant_rows, const int32_t* giant_chunks, int32_t n_giant, int32_t n_giant_chunks,
+                         float* ws, int64_t ws_bytes, hipStream_t st);
+
 #define TMGCN_REQUIRE(cond, ...)            \
   do {                                      \
     if (!(cond)) {                          \

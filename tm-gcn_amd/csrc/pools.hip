@@ -79,6 +79,7 @@ int eager_slot(DevicePools* p, hipStream_t stream) {
     return p->n_streams++;
   }
   for (int i = 0; i < kStreamSlots; ++i) {
+    if (capturing(p->stream[i])) continue;                 // (querying a capturing stream would invalidate its capture)
     const hipError_t q = hipStreamQuery(p->stream[i]);     // drained, or destroyed (an error other than NotReady): reusable
     if (q != hipSuccess) (void)hipGetLastError();
     if (q != hipErrorNotReady) {

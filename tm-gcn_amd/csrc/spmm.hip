@@ -35,7 +35,7 @@ template <int LPR, int U>
 __global__ __launch_bounds__(256) void spmm_vec4_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float4* __restrict__ X, float4* __restrict__ Y,
-    int64_t n_rows, int32_t N, int32_t F4, unsigned int* tile_counter) {
+    int64_t n_rows, int32_t N, int32_t F4, unsigned int* tile_counter, GiantPlan giant) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   __shared__ unsigned int s_tile;
@@ -82,12 +82,77 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
         const int rr = __builtin_ctzll(m);
         const int64_t r = r_begin + rr;
         const int64_t slice = r / N;
-        const float4 acc = gather_long_row<LPR, U>(col, val, X + slice * (int64_t)N * F4 + c0, readlane64(rows.beg, rr),
-                                                   readlane64(rows.end, rr), w4, lane, wave, s_part, F4);
+        const int64_t beg = readlane64(rows.beg, rr), end = readlane64(rows.end, rr);
+        float4 acc;
+        if (giant.rows && end - beg > kGiantRow) {               // summed chunk by chunk in front of this launch
+          if (wave != (rr & 3)) continue;
+          acc = giant_row_sum(giant, r, F4, lane, c0, w4);
+        } else {
+          acc = gather_long_row<LPR, U>(col, val, X + slice * (int64_t)N * F4 + c0, beg, end, w4, lane, wave, s_part, F4);
+        }
         if (wave == (rr & 3) && lane < LPR && lane < w4) store_f4(&Y[r * F4 + c0 + lane], acc);
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------
+// Giant-row pre-pass (spmm_row.h "Giant rows"): block c sums chunk c — kGiantChunk consecutive entries of one giant row —
+// with the four-wave gather and stores the partial sum to ws[c][F].
+// ---------------------------------------------------------------------------------
+template <int LPR, int U>
+__global__ __launch_bounds__(256) void spmm_giant_partial_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const float4* __restrict__ X, int32_t N, int32_t F4, const int64_t* __restrict__ g_rows,
+    const int32_t* __restrict__ g_chunk_ptr, const int32_t* __restrict__ g_chunk_giant, float4* __restrict__ ws) {
+  __shared__ float4 s_part[4 * LPR];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = blockIdx.x;
+  const int g = g_chunk_giant[c];
+  const int64_t r = g_rows[g];
+  int64_t beg = rowptr[r] + (int64_t)(c - g_chunk_ptr[g]) * kGiantChunk;
+  int64_t end = rowptr[r + 1];
+  if (beg > end) beg = end;
+  if (end - beg > kGiantChunk) end = beg + kGiantChunk;
+  const int64_t slice = r / N;
+  for (int c0 = 0; c0 < F4; c0 += kWave) {
+    const int w4 = F4 - c0 < kWave ? F4 - c0 : kWave;
+    const float4 acc = gather_long_row<LPR, U>(col, val, X + slice * (int64_t)N * F4 + c0, beg, end, w4, lane, wave, s_part, F4);
+    if (wave == 0 && lane < LPR && lane < w4) ws[(int64_t)c * F4 + c0 + lane] = acc;
+  }
+}
+
+int launch_giant_partial(const char* who, const int64_t* rowptr, const int32_t* col, const float* val, const float* X, int32_t N,
+                         int32_t F, const int64_t* giant_rows, const int32_t* giant_chunks, int32_t n_giant, int32_t n_giant_chunks,
+                         float* ws, int64_t ws_bytes, hipStream_t st) {
+  TMGCN_REQUIRE(n_giant >= 0 && n_giant_chunks >= 0, "%s: negative giant-row counts", who);
+  if (n_giant == 0) return TMGCN_OK;
+  TMGCN_REQUIRE(giant_rows && giant_chunks && ws && n_giant_chunks >= n_giant, "%s: giant-row plan: null pointer or fewer chunks than rows", who);
+  TMGCN_REQUIRE(ws_bytes >= tmgcn_spmm_giant_workspace_bytes(n_giant_chunks, F), "%s: giant-row workspace too small", who);
+  TMGCN_REQUIRE(F % 4 == 0 && F >= 16 && reinterpret_cast<uintptr_t>(ws) % 16 == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0,
+                "%s: the giant-row plan needs F %% 4 == 0, F >= 16 and 16-byte aligned X / workspace", who);
+  const int F4 = F / 4;
+  int lpr = 4;
+  while (lpr < F4 && lpr < 64) lpr <<= 1;
+  const int32_t* chunk_ptr = giant_chunks;
+  const int32_t* chunk_giant = giant_chunks + n_giant + 1;
+  const float4* X4 = reinterpret_cast<const float4*>(X);
+  float4* ws4 = reinterpret_cast<float4*>(ws);
+#define TMGCN_GIANT_CASE(L, UU)                                                                                          \
+  case L:                                                                                                                \
+    hipLaunchKernelGGL((spmm_giant_partial_kernel<L, UU>), dim3((unsigned)n_giant_chunks), dim3(256), 0, st, rowptr, col, \
+                       val, X4, N, F4, giant_rows, chunk_ptr, chunk_giant, ws4);                                         \
+    break;
+  switch (lpr) {     // the (LPR, U) pairs of spmm_vec4_kernel and of spmm_gemm_kernel: one row-sum order everywhere
+    TMGCN_GIANT_CASE(4, 2)
+    TMGCN_GIANT_CASE(8, 2)
+    TMGCN_GIANT_CASE(16, TMGCN_SPMM_U)
+    TMGCN_GIANT_CASE(32, TMGCN_SPMM_U)
+    TMGCN_GIANT_CASE(64, TMGCN_SPMM_U)
+  }
+#undef TMGCN_GIANT_CASE
+  return check_launch(who);
 }
 
 // ---------------------------------------------------------------------------------
@@ -209,10 +274,16 @@ using namespace tmgcn;
 
 // avg_nnz_per_row hint: < 0 means "unknown" (G defaults to 8).  Exposed through a
 // second entry point so the public signature stays the reference-shaped one.
-extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int32_t* col,
+extern "C" int64_t tmgcn_spmm_giant_workspace_bytes(int32_t n_giant_chunks, int32_t F) {
+  return n_giant_chunks > 0 && F > 0 ? (int64_t)n_giant_chunks * F * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int tmgcn_spmm_csr_batched_f32_plan(const int64_t* rowptr, const int32_t* col,
                                                 const float* val, const float* X, float* Y,
                                                 int64_t n_rows, int32_t N, int32_t F,
-                                                float avg_nnz_per_row, void* stream) {
+                                                float avg_nnz_per_row, const int64_t* giant_rows,
+                                                const int32_t* giant_chunks, int32_t n_giant, int32_t n_giant_chunks,
+                                                float* giant_ws, int64_t giant_ws_bytes, void* stream) {
   TMGCN_REQUIRE(n_rows >= 0 && N > 0 && F > 0, "spmm: bad shape n_rows=%lld N=%d F=%d",
                 (long long)n_rows, N, F);
   if (n_rows == 0) return TMGCN_OK;
@@ -245,6 +316,13 @@ extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int3
     while (lpr < F4 && lpr < 64) lpr <<= 1;                 // F > 256: 64 lanes, column chunks of 256 floats
     const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
     TMGCN_REQUIRE(n_tiles < (int64_t)0x7fffffff, "spmm: too many row tiles");
+    GiantPlan giant{nullptr, nullptr, nullptr, 0};
+    if (n_giant > 0) {
+      const int rc = launch_giant_partial("spmm (giant rows)", rowptr, col, val, X, N, F, giant_rows, giant_chunks, n_giant,
+                                          n_giant_chunks, giant_ws, giant_ws_bytes, st);
+      if (rc != TMGCN_OK) return rc;
+      giant = GiantPlan{giant_rows, giant_chunks, reinterpret_cast<const float4*>(giant_ws), n_giant};
+    }
     unsigned int* counter = acquire_tile_counter(st);
     TMGCN_REQUIRE(counter, "spmm: no tile counter: %s", pool_error());
     const float4* X4 = reinterpret_cast<const float4*>(X);
@@ -254,7 +332,7 @@ extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int3
     int64_t gx = 2 * (int64_t)persistent_grid(spmm_vec4_kernel<L, UU>, 256);                 \
     if (gx > n_tiles) gx = n_tiles;                                                          \
     hipLaunchKernelGGL((spmm_vec4_kernel<L, UU>), dim3((unsigned)gx), dim3(256), 0, st,      \
-                       rowptr, col, val, X4, Y4, n_rows, N, F4, counter);                    \
+                       rowptr, col, val, X4, Y4, n_rows, N, F4, counter, giant);             \
     break;                                                                                   \
   }
     switch (lpr) {
@@ -289,6 +367,14 @@ extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int3
 #undef TMGCN_GEN_CASE
     return check_launch("spmm_generic");
   }
+}
+
+extern "C" int tmgcn_spmm_csr_batched_f32_hint(const int64_t* rowptr, const int32_t* col,
+                                                const float* val, const float* X, float* Y,
+                                                int64_t n_rows, int32_t N, int32_t F,
+                                                float avg_nnz_per_row, void* stream) {
+  return tmgcn_spmm_csr_batched_f32_plan(rowptr, col, val, X, Y, n_rows, N, F, avg_nnz_per_row, nullptr, nullptr, 0, 0,
+                                         nullptr, 0, stream);
 }
 
 extern "C" int tmgcn_spmm_csr_batched_f32(const int64_t* rowptr, const int32_t* col,

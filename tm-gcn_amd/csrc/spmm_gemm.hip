@@ -53,6 +53,7 @@ struct FusedArgs {
   int64_t tiles_per_batch;
   int64_t n_tiles;
   unsigned int* tile_counter;  // dynamic tile scheduling (common.h)
+  GiantPlan giant;             // rows summed chunk by chunk in front of this launch (spmm_row.h), or rows == nullptr
 };
 
 template <int LPR, int U, int NJ>  // NJ = K / 8 (K is a multiple of 8 here)
@@ -133,8 +134,14 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
       const int rr = __builtin_ctzll(m);
       const int64_t r = row0 + rr;
       const int64_t slice = r / a.N;
-      const float4 acc = gather_long_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, readlane64(rows.beg, rr),
-                                                 readlane64(rows.end, rr), F4, lane, wave, s_part);
+      const int64_t beg = readlane64(rows.beg, rr), end = readlane64(rows.end, rr);
+      float4 acc;
+      if (a.giant.rows && end - beg > kGiantRow) {
+        if (wave != (rr & 3)) continue;
+        acc = giant_row_sum(a.giant, r, F4, lane, 0, F4);
+      } else {
+        acc = gather_long_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, beg, end, F4, lane, wave, s_part);
+      }
       if (wave == (rr & 3) && lane < LPR && lane < F4) {
         *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
         if (a.AX) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
@@ -257,12 +264,14 @@ extern "C" int tmgcn_spmm_gemm_supported(int32_t K, int32_t Nf) {
   return ((K % 8 == 0 && K >= 16 && K <= FKC && Nf >= 1 && Nf <= 128) || fused_small_ok(K, Nf)) ? 1 : 0;
 }
 
-extern "C" int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* col, const float* val,
+extern "C" int tmgcn_spmm_gemm_f32_plan(const int64_t* rowptr, const int32_t* col, const float* val,
                                          const float* X, int64_t n_rows, int32_t N, int32_t K,
                                          const float* W, int32_t Nf, int32_t trans_w,
                                          int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
                                          float* Y, float* AX, float* pre_act, int32_t grid_reserve,
-                                         float avg_nnz_per_row, void* stream) {
+                                         float avg_nnz_per_row, const int64_t* giant_rows, const int32_t* giant_chunks,
+                                         int32_t n_giant, int32_t n_giant_chunks, float* giant_ws, int64_t giant_ws_bytes,
+                                         void* stream) {
   TMGCN_REQUIRE(grid_reserve >= 0 && grid_reserve <= 4096, "spmm_gemm: grid_reserve %d out of range [0, 4096]", grid_reserve);
   TMGCN_REQUIRE(n_rows >= 0 && N > 0, "spmm_gemm: bad shape n_rows=%lld N=%d", (long long)n_rows, N);
   TMGCN_REQUIRE(tmgcn_spmm_gemm_supported(K, Nf),
@@ -275,7 +284,7 @@ extern "C" int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* co
   TMGCN_REQUIRE(n_rows % N == 0, "spmm_gemm: n_rows=%lld is not a multiple of N=%d", (long long)n_rows, N);
   if (fused_small_ok(K, Nf)) {
     FusedArgs s{rowptr, col, val, reinterpret_cast<const float4*>(X), n_rows, N, K, W, Nf, trans_w,
-                rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0, nullptr};
+                rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0, nullptr, GiantPlan{nullptr, nullptr, nullptr, 0}};
     // lanes per row: from the caller's average row length where it is known (as in
     // tmgcn_spmm_csr_batched_f32_hint), else 8 — the row lengths live on the device and the
     // reference's M-transformed adjacencies have tens of entries per row
@@ -297,7 +306,13 @@ extern "C" int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* co
   TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 && (!AX || reinterpret_cast<uintptr_t>(AX) % 16 == 0),
                 "spmm_gemm: X / AX must be 16-byte aligned");
   FusedArgs a{rowptr, col, val, reinterpret_cast<const float4*>(X), n_rows, N, K, W, Nf, trans_w,
-              rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0, nullptr};
+              rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0, nullptr, GiantPlan{nullptr, nullptr, nullptr, 0}};
+  if (n_giant > 0) {
+    const int rc = launch_giant_partial("spmm_gemm (giant rows)", rowptr, col, val, X, N, K, giant_rows, giant_chunks, n_giant,
+                                        n_giant_chunks, giant_ws, giant_ws_bytes, (hipStream_t)stream);
+    if (rc != TMGCN_OK) return rc;
+    a.giant = GiantPlan{giant_rows, giant_chunks, reinterpret_cast<const float4*>(giant_ws), n_giant};
+  }
   const int64_t br = rows_per_batch ? rows_per_batch : n_rows;
   const int64_t nb = (n_rows + br - 1) / br;
   a.tiles_per_batch = (br + FBM - 1) / FBM;
@@ -334,6 +349,16 @@ extern "C" int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* co
   }
 #undef TMGCN_FUSED_CASE
   return check_launch("spmm_gemm");
+}
+
+extern "C" int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* col, const float* val,
+                                         const float* X, int64_t n_rows, int32_t N, int32_t K,
+                                         const float* W, int32_t Nf, int32_t trans_w,
+                                         int64_t rows_per_batch, int64_t w_batch_stride, int32_t act,
+                                         float* Y, float* AX, float* pre_act, int32_t grid_reserve,
+                                         float avg_nnz_per_row, void* stream) {
+  return tmgcn_spmm_gemm_f32_plan(rowptr, col, val, X, n_rows, N, K, W, Nf, trans_w, rows_per_batch, w_batch_stride, act, Y, AX,
+                                  pre_act, grid_reserve, avg_nnz_per_row, nullptr, nullptr, 0, 0, nullptr, 0, stream);
 }
 
 extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* val,

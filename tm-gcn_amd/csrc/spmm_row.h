@@ -192,4 +192,46 @@ __device__ __forceinline__ float4 gather_long_row(const int32_t* __restrict__ co
   return s;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Giant rows.  Four waves of one block gather 41 M entries/s (tools/hub_tail_probe.py): a row of 10^6 entries is 23 ms
+// on its own, whatever else the launch holds.  With a PLAN from the caller (the rows of more than kGiantRow entries and a
+// chunk count for each: csr.BatchedCSR.giant_plan) such rows are cut into chunks of kGiantChunk entries that a small
+// launch in front of the main kernel sums one block per chunk (spmm_giant_partial_kernel, spmm.hip: the same four-wave
+// gather, partial sums to a workspace), and the main kernels ADD UP a giant row's partial sums, in chunk order, instead of
+// gathering it.  Stream order is the only synchronisation; sums stay in a fixed order.  Without a plan (NULL) a giant
+// row takes the four-wave path like any other long row.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kGiantRow = TMGCN_GIANT_ROW;        // include/tmgcn.h
+constexpr int kGiantChunk = TMGCN_GIANT_CHUNK;
+
+struct GiantPlan {
+  const int64_t* rows;        // [n] ascending global row indices (k*N + i) of the rows with more than kGiantRow entries
+  const int32_t* chunk_ptr;   // [n + 1] first chunk of each of them
+  const float4* partial;      // [n_chunks][F4] partial sums
+  int32_t n;
+};
+
+// Σ of the partial sums of giant row r (the caller saw more than kGiantRow entries, so r is in the plan); lanes < w4 of
+// the calling wave return their float4 of columns [4·(c0 + lane), …); wave-uniform control flow.
+__device__ __forceinline__ float4 giant_row_sum(const GiantPlan& g, int64_t r, int F4, int lane, int c0, int w4) {
+  int lo = 0, hi = g.n - 1;
+  while (lo < hi) {                                  // bisection: a few L2 hits, once per giant row
+    const int mid = (lo + hi) >> 1;
+    if (g.rows[mid] < r) lo = mid + 1;
+    else hi = mid;
+  }
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (lane < w4) {
+    const int c_end = g.chunk_ptr[lo + 1];
+    for (int c = g.chunk_ptr[lo]; c < c_end; ++c) {
+      const float4 t = g.partial[(int64_t)c * F4 + c0 + lane];
+      s.x += t.x;
+      s.y += t.y;
+      s.z += t.z;
+      s.w += t.w;
+    }
+  }
+  return s;
+}
+
 }  // namespace tmgcn

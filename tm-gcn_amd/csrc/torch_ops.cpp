@@ -127,16 +127,41 @@ void check_csr(const Tensor& rowptr, const Tensor& col, const Tensor& val, const
   TORCH_CHECK(val.device() == X.device(), who, ": adjacency and X live on different devices");
 }
 
+// A CSR's giant-row plan (include/tmgcn.h "Giant rows"; csr.BatchedCSR.giant_plan): the rows (int64 [n]) and the chunk
+// arrays (int32 [n + 1 + m]) on the device, plus the workspace this call allocates for the partial sums.
+struct Giant {
+  const int64_t* rows = nullptr;
+  const int32_t* chunks = nullptr;
+  int32_t n = 0, m = 0;
+  Tensor ws;
+  float* ws_ptr() const { return ws.defined() ? (float*)ws.data_ptr() : nullptr; }
+  int64_t ws_bytes() const { return ws.defined() ? ws.numel() * 4 : 0; }
+};
+Giant giant_of(const OptTensor& g_rows, const OptTensor& g_chunks, const Tensor& X, const char* who) {
+  Giant g;
+  if (!g_rows.has_value() || !g_chunks.has_value() || g_rows->numel() == 0) return g;
+  TORCH_CHECK(g_rows->is_cuda() && g_chunks->is_cuda() && g_rows->scalar_type() == at::kLong && g_chunks->scalar_type() == at::kInt &&
+                  g_rows->is_contiguous() && g_chunks->is_contiguous() && g_chunks->numel() > 2 * g_rows->numel(),
+              who, ": a giant-row plan is (int64 rows [n], int32 chunks [n + 1 + m]) on the device");
+  g.rows = (const int64_t*)g_rows->const_data_ptr();
+  g.chunks = (const int32_t*)g_chunks->const_data_ptr();
+  g.n = (int32_t)g_rows->numel();
+  g.m = (int32_t)(g_chunks->numel() - g_rows->numel() - 1);
+  g.ws = at::empty({(int64_t)g.m, X.size(2)}, X.options());
+  return g;
+}
+
 Tensor spmm_csr_batched(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& X,
-                        int64_t N, double avg_nnz_per_row) {
+                        int64_t N, double avg_nnz_per_row, const OptTensor& giant_rows, const OptTensor& giant_chunks) {
   want(X, "spmm X");
   check_csr(rowptr, col, val, X, N, "spmm");
   c10::DeviceGuard g(X.device());
   Tensor Y = at::empty_like(X);
-  ok(tmgcn_spmm_csr_batched_f32_hint((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col),
+  const Giant gi = giant_of(giant_rows, giant_chunks, X, "spmm");
+  ok(tmgcn_spmm_csr_batched_f32_plan((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col),
                                      (const float*)ptr(val), (const float*)ptr(X), (float*)ptr(Y),
                                      X.size(0) * N, (int32_t)N, (int32_t)X.size(2), (float)avg_nnz_per_row,
-                                     stream_of(X)),
+                                     gi.rows, gi.chunks, gi.n, gi.m, gi.ws_ptr(), gi.ws_bytes(), stream_of(X)),
      "tmgcn_spmm_csr_batched_f32");
   return Y;
 }
@@ -160,26 +185,29 @@ WShape w_shape(const Tensor& W, bool trans_w, int64_t T, int64_t K, const char* 
 
 void spmm_gemm_launch(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& X, int64_t N,
                       const Tensor& W, bool trans_w, int64_t act, const Tensor& Y, const Tensor& AX,
-                      const Tensor& pre, int64_t grid_reserve, double avg_nnz_per_row) {
+                      const Tensor& pre, int64_t grid_reserve, double avg_nnz_per_row, const OptTensor& giant_rows,
+                      const OptTensor& giant_chunks) {
   const WShape s = w_shape(W, trans_w, X.size(0), X.size(2), "spmm_gemm");
+  const Giant gi = giant_of(giant_rows, giant_chunks, X, "spmm_gemm");
   // average row length (steers the lanes per row of the narrow kernel, hence its summation order):
   // the CALLER's figure for the rows it launches over.  A one-slice view of a larger CSR shares
   // the whole col/val arrays, so col.numel() / n_rows would be T times too large there; a
   // negative value means "unknown" and takes the kernel's default.
   const int64_t n_rows = X.size(0) * N;
   const float avg = (float)avg_nnz_per_row;
-  ok(tmgcn_spmm_gemm_f32_hint((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val),
+  ok(tmgcn_spmm_gemm_f32_plan((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val),
                               (const float*)ptr(X), n_rows, (int32_t)N, (int32_t)X.size(2),
                               (const float*)ptr(W), (int32_t)s.wn, trans_w ? 1 : 0, s.per_slice ? N : 0, s.stride,
                               (int32_t)act, (float*)ptr(Y), (float*)ptr(AX), (float*)ptr(pre), (int32_t)grid_reserve,
-                              avg, stream_of(X)),
+                              avg, gi.rows, gi.chunks, gi.n, gi.m, gi.ws_ptr(), gi.ws_bytes(), stream_of(X)),
      "tmgcn_spmm_gemm_f32");
 }
 
 std::tuple<Tensor, Tensor, Tensor> spmm_gemm(const Tensor& rowptr, const Tensor& col, const Tensor& val,
                                              const Tensor& X, int64_t N, const Tensor& W, bool trans_w,
                                              int64_t act, bool want_ax, bool want_pre, int64_t grid_reserve,
-                                             double avg_nnz_per_row) {
+                                             double avg_nnz_per_row, const OptTensor& giant_rows,
+                                             const OptTensor& giant_chunks) {
   want(X, "spmm_gemm X");
   want(W, "spmm_gemm W");
   check_csr(rowptr, col, val, X, N, "spmm_gemm");
@@ -188,14 +216,16 @@ std::tuple<Tensor, Tensor, Tensor> spmm_gemm(const Tensor& rowptr, const Tensor&
   Tensor Y = at::empty({X.size(0), N, s.wn}, X.options());
   Tensor AX = want_ax ? at::empty(X.sizes(), X.options()) : Tensor();
   Tensor pre = (want_pre && act != TMGCN_ACT_NONE) ? at::empty_like(Y) : Tensor();
-  spmm_gemm_launch(rowptr, col, val, aligned16(X), N, W, trans_w, act, Y, AX, pre, grid_reserve, avg_nnz_per_row);
+  spmm_gemm_launch(rowptr, col, val, aligned16(X), N, W, trans_w, act, Y, AX, pre, grid_reserve, avg_nnz_per_row, giant_rows,
+                   giant_chunks);
   return {Y, AX.defined() ? AX : none_like(X), pre.defined() ? pre : none_like(X)};
 }
 
 // writes into caller-provided (views of) tensors: the slice-by-slice pipelined multi-GPU path
 void spmm_gemm_out(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& X, int64_t N,
                    const Tensor& W, bool trans_w, int64_t act, Tensor Y, const OptTensor& AX,
-                   const OptTensor& pre, int64_t grid_reserve, double avg_nnz_per_row) {
+                   const OptTensor& pre, int64_t grid_reserve, double avg_nnz_per_row, const OptTensor& giant_rows,
+                   const OptTensor& giant_chunks) {
   want(X, "spmm_gemm X");
   want(W, "spmm_gemm W");
   want(Y, "spmm_gemm out Y");
@@ -209,7 +239,8 @@ void spmm_gemm_out(const Tensor& rowptr, const Tensor& col, const Tensor& val, c
   if (pr.defined()) want(pr, "spmm_gemm out pre");
   TORCH_CHECK(!ax.defined() || reinterpret_cast<uintptr_t>(ax.const_data_ptr()) % 16 == 0,
               "spmm_gemm: the AX output view must start 16-byte aligned");
-  spmm_gemm_launch(rowptr, col, val, aligned16(X), N, W, trans_w, act, Y, ax, pr, grid_reserve, avg_nnz_per_row);
+  spmm_gemm_launch(rowptr, col, val, aligned16(X), N, W, trans_w, act, Y, ax, pr, grid_reserve, avg_nnz_per_row, giant_rows,
+                   giant_chunks);
 }
 
 std::tuple<Tensor, Tensor> bgemm(const Tensor& A, const Tensor& W, bool trans_w, int64_t act, bool want_pre,
@@ -612,24 +643,29 @@ struct SpmmFn : public torch::autograd::Function<SpmmFn> {
   // sparse.mm backward: dX_k = Â_kᵀ dY_k (Â is a constant: no gradient, as in the reference)
   static Tensor forward(AutogradContext* ctx, const Tensor& X, const Tensor& rowptr, const Tensor& col,
                         const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col, const OptTensor& t_val,
-                        int64_t N, double avg, bool need) {
+                        int64_t N, double avg, const OptTensor& g_rows, const OptTensor& g_chunks, const OptTensor& t_g_rows,
+                        const OptTensor& t_g_chunks, bool need) {
     // `need` is decided by the caller: inside forward() autograd has already switched grad mode off
     at::AutoDispatchBelowADInplaceOrView guard;
     if (need) {
       TORCH_CHECK(t_rowptr.has_value() && t_col.has_value() && t_val.has_value(),
                   "spmm: X requires grad but no transposed adjacency was passed");
-      ctx->save_for_backward({*t_rowptr, *t_col, *t_val});
+      const bool tg = t_g_rows.has_value() && t_g_chunks.has_value();
+      ctx->save_for_backward({*t_rowptr, *t_col, *t_val, tg ? *t_g_rows : none_like(X), tg ? *t_g_chunks : none_like(X)});
     }
     ctx->saved_data["N"] = N;
     ctx->saved_data["avg"] = avg;
-    return spmm_csr_batched(rowptr, col, val, X, N, avg);
+    return spmm_csr_batched(rowptr, col, val, X, N, avg, g_rows, g_chunks);
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     at::AutoDispatchBelowADInplaceOrView guard;
     auto sv = ctx->get_saved_variables();
+    const bool tg = sv[3].numel() > 0;
     Tensor dX = spmm_csr_batched(sv[0], sv[1], sv[2], grads[0].contiguous(), ctx->saved_data["N"].toInt(),
-                                 ctx->saved_data["avg"].toDouble());
-    return {dX, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+                                 ctx->saved_data["avg"].toDouble(), tg ? OptTensor(sv[3]) : OptTensor(), tg ? OptTensor(sv[4]) : OptTensor());
+    variable_list out(14);
+    out[0] = dX;
+    return out;
   }
 };
 
@@ -675,14 +711,16 @@ struct SpmmFeatureGemmFn : public torch::autograd::Function<SpmmFeatureGemmFn> {
   static Tensor forward(AutogradContext* ctx, const Tensor& X, const Tensor& W, const Tensor& rowptr,
                         const Tensor& col, const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col,
                         const OptTensor& t_val, int64_t N, double avg, int64_t act, int64_t grid_reserve,
-                        bool need_x, bool need_w) {
+                        const OptTensor& g_rows, const OptTensor& g_chunks, const OptTensor& t_g_rows,
+                        const OptTensor& t_g_chunks, bool need_x, bool need_w) {
     at::AutoDispatchBelowADInplaceOrView guard;
-    auto [Y, AX, pre] = spmm_gemm(rowptr, col, val, X, N, W, false, act, need_w, need_x || need_w, grid_reserve, avg);
+    auto [Y, AX, pre] = spmm_gemm(rowptr, col, val, X, N, W, false, act, need_w, need_x || need_w, grid_reserve, avg, g_rows, g_chunks);
     if (need_x)
       TORCH_CHECK(t_rowptr.has_value() && t_col.has_value() && t_val.has_value(),
                   "spmm_feature_gemm: X requires grad but no transposed adjacency was passed");
+    const bool tg = need_x && t_g_rows.has_value() && t_g_chunks.has_value();
     ctx->save_for_backward({W, AX, pre, need_x ? *t_rowptr : Tensor(), need_x ? *t_col : Tensor(),
-                            need_x ? *t_val : Tensor()});
+                            need_x ? *t_val : Tensor(), tg ? *t_g_rows : none_like(X), tg ? *t_g_chunks : none_like(X)});
     ctx->saved_data["N"] = N;
     ctx->saved_data["avg"] = avg;
     ctx->saved_data["act"] = act;
@@ -698,16 +736,20 @@ struct SpmmFeatureGemmFn : public torch::autograd::Function<SpmmFeatureGemmFn> {
     if (act != TMGCN_ACT_NONE) dY = act_bwd(pre, dY, act);
     Tensor dX, dW;
     if (ctx->needs_input_grad(0)) {
+      const bool tg = sv[6].numel() > 0;
+      const OptTensor gr = tg ? OptTensor(sv[6]) : OptTensor(), gc = tg ? OptTensor(sv[7]) : OptTensor();
       if (spmm_gemm_supported(dY.size(-1), W.size(-2)))
         dX = std::get<0>(spmm_gemm(sv[3], sv[4], sv[5], dY, N, W, true, TMGCN_ACT_NONE, false, false,
-                                   ctx->saved_data["reserve"].toInt(), ctx->saved_data["avg"].toDouble()));
+                                   ctx->saved_data["reserve"].toInt(), ctx->saved_data["avg"].toDouble(), gr, gc));
       else  // the transposed widths have no fused kernel: dA = dY·Wᵀ, then Âᵀ·dA
         dX = spmm_csr_batched(sv[3], sv[4], sv[5], std::get<0>(bgemm(dY, W, true, TMGCN_ACT_NONE, false, TMGCN_GEMM_AUTO)), N,
-                              ctx->saved_data["avg"].toDouble());
+                              ctx->saved_data["avg"].toDouble(), gr, gc);
     }
     if (ctx->needs_input_grad(1)) dW = bgemm_dW(AX, dY, W.dim() == 3, TMGCN_DW_AUTO);
-    return {dX,       dW,       Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
-            Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    variable_list out(18);
+    out[0] = dX;
+    out[1] = dW;
+    return out;
   }
 };
 
@@ -940,17 +982,20 @@ Tensor m_transform_ad(const Tensor& X, const Tensor& M, int64_t band_lo, int64_t
   return MTransformFn::apply(X, M, band_lo, band_hi, row_off, col_off, T_out, xg, yg);
 }
 Tensor spmm_ad(const Tensor& X, const Tensor& rowptr, const Tensor& col, const Tensor& val, const OptTensor& t_rowptr,
-               const OptTensor& t_col, const OptTensor& t_val, int64_t N, double avg) {
-  return SpmmFn::apply(X, rowptr, col, val, t_rowptr, t_col, t_val, N, avg,
+               const OptTensor& t_col, const OptTensor& t_val, int64_t N, double avg, const OptTensor& g_rows,
+               const OptTensor& g_chunks, const OptTensor& t_g_rows, const OptTensor& t_g_chunks) {
+  return SpmmFn::apply(X, rowptr, col, val, t_rowptr, t_col, t_val, N, avg, g_rows, g_chunks, t_g_rows, t_g_chunks,
                        at::GradMode::is_enabled() && X.requires_grad());
 }
 Tensor feature_gemm_ad(const Tensor& A, const Tensor& W, int64_t act) { return FeatureGemmFn::apply(A, W, act); }
 Tensor spmm_feature_gemm_ad(const Tensor& X, const Tensor& W, const Tensor& rowptr, const Tensor& col,
                             const Tensor& val, const OptTensor& t_rowptr, const OptTensor& t_col,
-                            const OptTensor& t_val, int64_t N, double avg, int64_t act, int64_t grid_reserve) {
+                            const OptTensor& t_val, int64_t N, double avg, int64_t act, int64_t grid_reserve,
+                            const OptTensor& g_rows, const OptTensor& g_chunks, const OptTensor& t_g_rows,
+                            const OptTensor& t_g_chunks) {
   const bool grad = at::GradMode::is_enabled();
-  return SpmmFeatureGemmFn::apply(X, W, rowptr, col, val, t_rowptr, t_col, t_val, N, avg, act, grid_reserve,
-                                  grad && X.requires_grad(), grad && W.requires_grad());
+  return SpmmFeatureGemmFn::apply(X, W, rowptr, col, val, t_rowptr, t_col, t_val, N, avg, act, grid_reserve, g_rows, g_chunks,
+                                  t_g_rows, t_g_chunks, grad && X.requires_grad(), grad && W.requires_grad());
 }
 Tensor edge_head_ad(const Tensor& Z, const Tensor& U, const Tensor& src, const Tensor& dst, const OptTensor& eptr,
                     const OptTensor& eidx) {
@@ -987,11 +1032,14 @@ TORCH_LIBRARY(tmgcn, m) {
         "int x_group_rows, int y_group_rows) -> Tensor");
   m.def("mtransform_out(Tensor M, Tensor X, Tensor(a!) Y, bool transpose, int row_off, int col_off, int band_lo, "
         "int band_hi, int x_group_rows, int y_group_rows) -> ()");
-  m.def("spmm_csr_batched(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, float avg_nnz_per_row) -> Tensor");
+  m.def("spmm_csr_batched(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, float avg_nnz_per_row, "
+        "Tensor? giant_rows=None, Tensor? giant_chunks=None) -> Tensor");
   m.def("spmm_gemm(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, Tensor W, bool trans_w, int act, "
-        "bool want_ax, bool want_pre, int grid_reserve, float avg_nnz_per_row=-1.0) -> (Tensor, Tensor, Tensor)");
+        "bool want_ax, bool want_pre, int grid_reserve, float avg_nnz_per_row=-1.0, Tensor? giant_rows=None, "
+        "Tensor? giant_chunks=None) -> (Tensor, Tensor, Tensor)");
   m.def("spmm_gemm_out(Tensor rowptr, Tensor col, Tensor val, Tensor X, int N, Tensor W, bool trans_w, int act, "
-        "Tensor(a!) Y, Tensor(b!)? AX, Tensor(c!)? pre, int grid_reserve, float avg_nnz_per_row=-1.0) -> ()");
+        "Tensor(a!) Y, Tensor(b!)? AX, Tensor(c!)? pre, int grid_reserve, float avg_nnz_per_row=-1.0, Tensor? giant_rows=None, "
+        "Tensor? giant_chunks=None) -> ()");
   m.def("bgemm(Tensor A, Tensor W, bool trans_w, int act, bool want_pre, int algo) -> (Tensor, Tensor)");
   m.def("bgemm_dW(Tensor A, Tensor dY, bool per_slice, int algo) -> Tensor");
   m.def("bgemm_dW_act(Tensor A, Tensor dY, Tensor pre, int act, bool per_slice) -> Tensor");
@@ -1016,10 +1064,12 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("m_transform(Tensor X, Tensor M, int band_lo, int band_hi, int row_off, int col_off, int T_out, "
         "int x_group_rows, int y_group_rows) -> Tensor");
   m.def("spmm(Tensor X, Tensor rowptr, Tensor col, Tensor val, Tensor? t_rowptr, Tensor? t_col, Tensor? t_val, "
-        "int N, float avg_nnz_per_row) -> Tensor");
+        "int N, float avg_nnz_per_row, Tensor? giant_rows=None, Tensor? giant_chunks=None, Tensor? t_giant_rows=None, "
+        "Tensor? t_giant_chunks=None) -> Tensor");
   m.def("feature_gemm(Tensor A, Tensor W, int act) -> Tensor");
   m.def("spmm_feature_gemm(Tensor X, Tensor W, Tensor rowptr, Tensor col, Tensor val, Tensor? t_rowptr, "
-        "Tensor? t_col, Tensor? t_val, int N, float avg_nnz_per_row, int act, int grid_reserve) -> Tensor");
+        "Tensor? t_col, Tensor? t_val, int N, float avg_nnz_per_row, int act, int grid_reserve, Tensor? giant_rows=None, "
+        "Tensor? giant_chunks=None, Tensor? t_giant_rows=None, Tensor? t_giant_chunks=None) -> Tensor");
   m.def("edge_head(Tensor Z, Tensor U, Tensor src, Tensor dst, Tensor? eptr, Tensor? eidx) -> Tensor");
   m.def("activation(Tensor x, int act) -> Tensor");
   m.def("layer12(Tensor H, Tensor W1, Tensor W2, Tensor rowptr, Tensor col, Tensor val, Tensor? t_rowptr, Tensor? t_col, "

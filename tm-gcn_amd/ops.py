@@ -263,7 +263,8 @@ class HipKernels:
 
     # P2 ---------------------------------------------------------------------------------
     def spmm(self, A: BatchedCSR, X: torch.Tensor, tag="spmm") -> torch.Tensor:
-        return self._run(tag, X.device, lambda: self.ops.spmm_csr_batched(A.rowptr, A.col, A.val, X, A.N, A.avg_nnz_per_row))
+        return self._run(tag, X.device, lambda: self.ops.spmm_csr_batched(A.rowptr, A.col, A.val, X, A.N, A.avg_nnz_per_row,
+                                                                          *A.giant_plan()))
 
     # P2+P3 fused ----------------------------------------------------------------------
     def spmm_gemm_supported(self, K: int, Nf: int) -> bool:
@@ -280,11 +281,11 @@ class HipKernels:
             Y, AX, pre = out
             self._run(tag, X.device, lambda: self.ops.spmm_gemm_out(
                 A.rowptr, A.col, A.val, X, A.N, W, bool(trans_w), act_id, Y, AX, pre, int(grid_reserve),
-                float(A.avg_nnz_per_row)))
+                float(A.avg_nnz_per_row), *A.giant_plan()))
             return Y, AX, pre
         Y, AX, pre = self._run(tag, X.device, lambda: self.ops.spmm_gemm(
             A.rowptr, A.col, A.val, X, A.N, W, bool(trans_w), act_id, bool(want_ax), bool(want_pre), int(grid_reserve),
-            float(A.avg_nnz_per_row)))
+            float(A.avg_nnz_per_row), *A.giant_plan()))
         return Y, (AX if AX.numel() else None), (pre if pre.numel() else None)
 
     # P3 ---------------------------------------------------------------------------------
@@ -461,6 +462,11 @@ def _csr_t(A: BatchedCSR, needed: bool):
     return At.rowptr, At.col, At.val
 
 
+def _giant(A: BatchedCSR, needed: bool):
+    """(rows, chunks) of A's giant-row plan and of its transpose's (the backward operand; None, None when not needed)."""
+    return (*A.giant_plan(), *(A.transpose().giant_plan() if needed else (None, None)))
+
+
 def m_transform(X: torch.Tensor, op: MOperator, row_off=0, col_off=0, T_out=None, x_group_rows=0,
                 y_group_rows=0) -> torch.Tensor:
     """P1: Y[k] = Σ_j M[row_off+k][col_off+j] · X[j]  along the first (time) mode.
@@ -475,7 +481,7 @@ def spmm(A: BatchedCSR, X: torch.Tensor) -> torch.Tensor:
     """P2: Y[k] = Â_k · X[k] for all frontal slices in one launch."""
     if _registered():
         need = X.requires_grad and torch.is_grad_enabled()
-        return kernels.ops.spmm(X, A.rowptr, A.col, A.val, *_csr_t(A, need), A.N, A.avg_nnz_per_row)
+        return kernels.ops.spmm(X, A.rowptr, A.col, A.val, *_csr_t(A, need), A.N, A.avg_nnz_per_row, *_giant(A, need))
     return _Spmm.apply(X, A)
 
 
@@ -500,7 +506,7 @@ def spmm_feature_gemm(A: BatchedCSR, X: torch.Tensor, W: torch.Tensor, act=None,
         if _registered():
             need = X.requires_grad and torch.is_grad_enabled()
             return kernels.ops.spmm_feature_gemm(X, W, A.rowptr, A.col, A.val, *_csr_t(A, need), A.N,
-                                                 A.avg_nnz_per_row, _lib.ACT_IDS[act], 0)
+                                                 A.avg_nnz_per_row, _lib.ACT_IDS[act], 0, *_giant(A, need))
         return _SpmmGemm.apply(X, W, A, act)
     return feature_gemm(spmm(A, X), W, act=act)
 

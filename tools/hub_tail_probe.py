@@ -2,7 +2,8 @@
 """What ONE very long row costs a launch: a one-slice S4 launch (N = 2 M, 33 entries per row, F = 128: 66 M entries) with one
 row replaced by a hub of H entries, H = 0 / 1e4 / 1e5 / 1e6.  A long row runs on the four waves of ONE block (csrc/spmm_row.h);
 heavy tiles are taken first, so inside a big launch the hub hides under everything else — but a launch cannot be shorter than
-its longest row.  Prints the fused kernel's time per H.    python tools/hub_tail_probe.py"""
+its longest row, unless the giant-row plan (csr.BatchedCSR.giant_plan) has it summed chunk by chunk by many blocks in front of
+the launch.  Prints the fused kernel's time per H, with and without the plan.    python tools/hub_tail_probe.py"""
 import os
 import sys
 
@@ -31,16 +32,21 @@ for H in (0, 10_000, 100_000, 1_000_000, 4_000_000):
         A = BatchedCSR(rowptr, col, val, 1, N)
     else:
         A = base
-    for _ in range(2):
-        ops.kernels.spmm_gemm(A, X, W)
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        ops.kernels.spmm_gemm(A, X, W)
-        e.record()
+    line = f"hub of {H:>9,d} entries in a {A.nnz / 1e6:.0f} M-entry launch:"
+    for plan in (True, False):        # with the giant-row plan (rows > 32 768 entries summed chunk by chunk in front of the launch) / without
+        if not plan:
+            A._blocks["giant"] = (None, None)
+        for _ in range(2):
+            ops.kernels.spmm_gemm(A, X, W)
         torch.cuda.synchronize()
-        ts.append(s.elapsed_time(e))
-    ts.sort()
-    print(f"hub of {H:>9,d} entries in a {A.nnz / 1e6:.0f} M-entry launch: {ts[2]:7.3f} ms (min {ts[0]:.3f})", flush=True)
+        ts = []
+        for _ in range(5):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            ops.kernels.spmm_gemm(A, X, W)
+            e.record()
+            torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e))
+        ts.sort()
+        line += f"  {'with' if plan else 'without'} plan {ts[2]:7.3f} ms"
+    print(line, flush=True)
