@@ -44,15 +44,12 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
   const TileMap tm{n_rows, n_rows, n_tiles, n_tiles};
   HeavyScan heavy;
   heavy.init(rowptr, tm);
-  bool scanning = true;
   for (;;) {
-    // this block's share of the heavy tiles first (spmm_row.h); then persistent blocks draw 64-row tiles from a
-    // device counter (ascending: resident blocks stay inside one slice of X); see common.h
+    // the heavy tiles first (spmm_row.h: windows drawn from counter[1]); then persistent blocks draw 64-row tiles from
+    // counter[0] (ascending: resident blocks stay inside one slice of X); see common.h
     int64_t tile = -1;
-    if (scanning) {
-      tile = heavy.next(rowptr, tm, lane);
-      scanning = tile >= 0;
-    }
+    if (heavy.scanning) tile = heavy.next(rowptr, tm, tile_counter + 1, &s_tile, lane);
+    const bool scanning = heavy.scanning;
     if (!scanning) {
       __syncthreads();
       if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);
@@ -323,7 +320,7 @@ extern "C" int tmgcn_spmm_csr_batched_f32_plan(const int64_t* rowptr, const int3
       if (rc != TMGCN_OK) return rc;
       giant = GiantPlan{giant_rows, giant_chunks, reinterpret_cast<const float4*>(giant_ws), n_giant};
     }
-    unsigned int* counter = acquire_tile_counter(st);
+    unsigned int* counter = acquire_tile_counters(st, 2);       // [0] tiles, [1] heavy-tile scan windows
     TMGCN_REQUIRE(counter, "spmm: no tile counter: %s", pool_error());
     const float4* X4 = reinterpret_cast<const float4*>(X);
     float4* Y4 = reinterpret_cast<float4*>(Y);

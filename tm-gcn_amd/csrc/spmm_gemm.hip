@@ -52,7 +52,7 @@ struct FusedArgs {
   int32_t act;
   int64_t tiles_per_batch;
   int64_t n_tiles;
-  unsigned int* tile_counter;  // dynamic tile scheduling (common.h)
+  unsigned int* tile_counter;  // dynamic tile scheduling (common.h): two counters, [0] tiles, [1] scan windows (spmm_row.h)
   GiantPlan giant;             // rows summed chunk by chunk in front of this launch (spmm_row.h), or rows == nullptr
 };
 
@@ -74,16 +74,13 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
   __shared__ unsigned int s_tile;
   HeavyScan heavy;
   heavy.init(a.rowptr, tm);
-  bool scanning = true;
 
   for (;;) {
-    // next tile: first this block's share of the heavy tiles (spmm_row.h), then from the device counter
-    // (ascending, so resident blocks stay inside one slice)
+    // next tile: first the heavy tiles (spmm_row.h: windows drawn from counter[1]), then from the device counter
+    // (counter[0]; ascending, so resident blocks stay inside one slice)
     int64_t tile = -1;
-    if (scanning) {
-      tile = heavy.next(a.rowptr, tm, lane);
-      scanning = tile >= 0;
-    }
+    if (heavy.scanning) tile = heavy.next(a.rowptr, tm, a.tile_counter + 1, &s_tile, lane);
+    const bool scanning = heavy.scanning;
     if (!scanning) {
       if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter, 1u);
       __syncthreads();
@@ -318,7 +315,7 @@ extern "C" int tmgcn_spmm_gemm_f32_plan(const int64_t* rowptr, const int32_t* co
   a.tiles_per_batch = (br + FBM - 1) / FBM;
   a.n_tiles = nb * a.tiles_per_batch;
   TMGCN_REQUIRE(a.n_tiles < (int64_t)0x7fffffff, "spmm_gemm: too many row tiles");
-  a.tile_counter = acquire_tile_counter((hipStream_t)stream);
+  a.tile_counter = acquire_tile_counters((hipStream_t)stream, 2);      // [0] the main loop's tiles, [1] the heavy-tile scan windows
   TMGCN_REQUIRE(a.tile_counter, "spmm_gemm: no tile counter: %s", pool_error());
   // persistent blocks: up to 4 per CU (LDS 33.8 KB each); tiles are dealt round-robin so the
   // blocks resident at any moment work on neighbouring rows of the same slice

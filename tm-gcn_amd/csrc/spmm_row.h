@@ -79,9 +79,9 @@ __device__ __forceinline__ float4 gather_row(const int32_t* __restrict__ col,
 //     entry range (a multiple of 64 each), the four partial sums added in wave order through LDS — instead of
 //     keeping one wave busy while the tile's other rows and the block's MFMA phase wait for it;
 //   * tiles with more than max(kHeavyMin, 8x the launch's mean) entries are taken FIRST: before a block starts
-//     drawing tiles from the launch's counter it scans the extents of tiles blockIdx.x, blockIdx.x + grid, ... (64 per
-//     coalesced load) and processes the heavy ones it finds; the counter-driven loop then skips them (same predicate,
-//     recomputed from the row extents it loads anyway).  A 100 000-entry hub — milliseconds even on four waves —
+//     drawing tiles from the launch's counter it draws windows of 64 consecutive tiles from a second counter, reads
+//     their extents (one coalesced load pair) and processes the heavy ones it finds; the counter-driven loop then skips
+//     them (same predicate, recomputed from the row extents it loads anyway).  A 100 000-entry hub — milliseconds even on four waves —
 //     therefore runs at the start of the launch, under everything else, never as its tail.
 // ------------------------------------------------------------------------------------------------------------
 #ifndef TMGCN_LONG_ROW
@@ -111,22 +111,35 @@ __device__ __forceinline__ void tile_extent(const TileMap& m, int64_t tile, int6
   if (row_end > m.n_rows) row_end = m.n_rows;
 }
 
-// Pass 1 of a block: its share of the heavy tiles, found 64 extents at a time.  All state is block-uniform (every wave
-// computes the same ballots from the same loads).
+// Pass 1: the heavy tiles, found 64 extents at a time.  Blocks draw WINDOWS of 64 consecutive tiles from a second device
+// counter (counter[1]; counter[0] feeds the main loop) until the windows run out, and process the heavy tiles of the windows
+// they drew: whichever blocks are resident first share ALL the heavy tiles — a block that becomes resident late (CU-masked
+// streams, RCCL kernels holding CUs) finds nothing left to scan instead of owning a share that would run as the launch's
+// tail.  All state is block-uniform (every wave computes the same ballot from the same loads).
 struct HeavyScan {
-  int64_t thr, base, win;
+  int64_t thr, win;
   uint64_t pending;
+  bool scanning;
   __device__ __forceinline__ void init(const int64_t* __restrict__ rowptr, const TileMap& m) {
     const int64_t mean = (rowptr[m.n_rows] - rowptr[0]) / m.n_tiles;
     thr = 8 * mean > kHeavyMin ? 8 * mean : kHeavyMin;
-    base = TMGCN_HEAVY_FIRST ? (int64_t)blockIdx.x : m.n_tiles;
     win = 0;
     pending = 0;
+    scanning = TMGCN_HEAVY_FIRST != 0;
   }
-  __device__ __forceinline__ int64_t next(const int64_t* __restrict__ rowptr, const TileMap& m, int lane) {   // -1: done
+  // next heavy tile of this block, or -1 when the scan is over (then `scanning` is false); s_slot: one LDS word of the block
+  __device__ __forceinline__ int64_t next(const int64_t* __restrict__ rowptr, const TileMap& m, unsigned int* scan_counter,
+                                          unsigned int* s_slot, int lane) {
     while (pending == 0) {
-      if (base >= m.n_tiles) return -1;
-      const int64_t t = base + (int64_t)lane * gridDim.x;
+      if (threadIdx.x == 0) *s_slot = atomicAdd(scan_counter, 1u);
+      __syncthreads();
+      win = (int64_t)*s_slot * kWave;
+      __syncthreads();                                 // everybody has read the slot before it is written again
+      if (win >= m.n_tiles) {
+        scanning = false;
+        return -1;
+      }
+      const int64_t t = win + lane;
       int64_t ent = 0;
       if (t < m.n_tiles) {
         int64_t b, r0, r1;
@@ -135,12 +148,10 @@ struct HeavyScan {
         ent = rowptr[r1] - rowptr[r0];
       }
       pending = __ballot(ent > thr);
-      win = base;
-      base += (int64_t)kWave * gridDim.x;
     }
     const int l = __builtin_ctzll(pending);
     pending &= pending - 1;
-    return win + (int64_t)l * gridDim.x;
+    return win + l;
   }
 };
 
