@@ -626,10 +626,10 @@ def measure_skewed(args):
     """The headline's graph gives every row exactly deg+1 entries.  The reference's real operand does not (read_data.py:116-127,
     204-223: the M-product of symmetrised real graphs; its chess data has 13 % of the rows holding 59 % of the entries).  The same
     layer, N, mean row length and uniform columns with capped-Zipf row lengths (synth.device_powerlaw_csr: a dozen rows of 100 000
-    entries per slice, a tenth of the rows holding 60 % of the entries) as a CHILD run of this script — 3 steps, its own verify
+    entries per slice, a tenth of the rows holding 60 % of the entries) as a CHILD run of this script — 5 steps, its own verify
     leg against the CPU oracle, no other legs — so that a profiler around this process sees the headline's launches only."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--nodes", str(args.nodes),
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "5", "--warmup", "2", "--nodes", str(args.nodes),
            "--slices-per-gpu", str(args.slices_per_gpu), "--deg", str(args.deg), "--feat", str(args.feat), "--band", str(args.band),
            "--graph", "powerlaw", "--no-epochs", "--no-cpu-baseline", "--no-measure-traffic", "--no-hbm-only", "--no-skewed",
            "--verify-rows", str(args.verify_rows), "--deadline", "400"]
