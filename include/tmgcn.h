@@ -44,7 +44,7 @@ typedef enum {
 /* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
 enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
 
-/* ABI version 5 = version 4 + tmgcn_pool_stats + the row_blocks partition argument of tmgcn_layer12_fwd/bwd_f32 + the giant-row
+/* ABI version 5 = version 4 + tmgcn_pool_stats + the row_blocks partition argument of tmgcn_layer12_fwd/bwd_f32 + tmgcn_head_loss_combine_f32 (split rows of the one-pass head + loss plan) + the giant-row
  *   plan entry points tmgcn_spmm_csr_batched_f32_plan / tmgcn_spmm_gemm_f32_plan / tmgcn_spmm_giant_workspace_bytes; the launchers' scratch words (tile counters, hand-off blocks) are kept apart
  *   per stream (eager launches) and per recorded launch (hipGraph capture), and a launcher that cannot keep two launches
  *   apart returns TMGCN_ERR_INVALID with the reason instead of re-using a word that may be in flight (csrc/pools.hip).
@@ -338,6 +338,12 @@ int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* w
  *                        ent is read only when the logits are stored
  *   arow[n_active][4]    the rows with at least one entry, ascending: (row, eptr[row], eptr[row+1], 0), 16-byte aligned
  *   other[2E]            row index of the OTHER endpoint of each entry's edge
+ *   arow[n_active][4]    (row, first entry, end entry, part) of every row with entries.  part = 0: the whole row.  A caller may
+ *                        SPLIT a long row (a hub of the labelled edges: a group of at most 16 lanes walks a row's entries) into
+ *                        several consecutive ranges, part = 1, 2, … numbered over ALL split rows of the plan: every sum this
+ *                        kernel forms is linear in the entries, so parts are independent — except that a part's share of dZ[row]
+ *                        goes to row R + part - 1 of dZ (dZ then has R + n_parts rows) and tmgcn_head_loss_combine_f32 adds the
+ *                        parts into dZ[row] afterwards, in order.  (K = 2 stores no dZ: nothing to combine.)
  *   meta[2E]             role << 7 | target class of each entry's edge (0..C-1; 127 = ignored: no weight, no gradient)
  *   class_count[C]       number of labelled edges per class: Σ_e w[t_e] = Σ_c class_count[c]·w[c]
  *   grad_scale           NULL, or one float on the device: the gradients are multiplied by it (the upstream
@@ -354,6 +360,8 @@ int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* w
  */
 #define TMGCN_SYNC_INTS 272
 int tmgcn_head_loss_supported(int32_t F, int32_t C, int32_t K);
+/* srow [n_split][4] = (row, first part - 1, number of parts, 0) of every split row: dZ[row] = Σ_k dZ[R + first + k], k ascending */
+int tmgcn_head_loss_combine_f32(const int32_t* srow, int32_t n_split, float* dZ, int64_t R, int32_t F, void* stream);
 int64_t tmgcn_head_loss_workspace_bytes(int32_t F, int32_t C, int32_t K);
 int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t K, const float* U,
                         const int32_t* eptr, const int32_t* arow, int64_t n_active, const int32_t* ent,

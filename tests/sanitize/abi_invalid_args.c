@@ -43,6 +43,8 @@ int main(void) {
   BAD(tmgcn_mtransform_f32(0, 4, 4, 0, 0, 0, 4, 4, 3, 0, 0, 0, 16, 0, 0, 0));            /* null M / X / Y */
   BAD(tmgcn_mtransform_f32(0, -1, 4, 0, 0, 0, 4, 4, 3, 0, 0, 0, 16, 0, 0, 0));           /* negative T */
   BAD(tmgcn_mtransform_ld_f32(0, 4, 4, 0, 0, 0, 4, 4, 3, 0, 0, 2, 0, 2, 16, 0, 0, 0));   /* ld < C, nulls */
+  BAD(tmgcn_head_loss_combine_f32(0, 3, 0, 10, 6, 0));                                                     /* null pointers */
+  NOP(tmgcn_head_loss_combine_f32(0, 0, 0, 10, 6, 0));                                                     /* nothing split */
   /* P2 */
   BAD(tmgcn_spmm_csr_batched_f32_plan(0, 0, 0, 0, 0, 9, 3, 128, -1.f, 0, 0, -1, 0, 0, 0, 0));              /* negative giant count */
   BAD(tmgcn_spmm_gemm_f32_plan(0, 0, 0, 0, 9, 3, 128, 0, 128, 0, 0, 0, 0, 0, 0, 0, 0, -1.f, 0, 0, 2, 1, 0, 0, 0));  /* nulls */

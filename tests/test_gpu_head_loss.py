@@ -298,6 +298,50 @@ def test_hub_rows_and_skewed_degrees():
     assert_close(Ur.grad, ref_dU, 2e-6, "dU")
 
 
+@pytest.mark.parametrize("T,N,E", [(2, 300, 60_000), (50, 2000, 60_000)])       # gradients in the loss launch / in the backward's launch
+@pytest.mark.parametrize("K,C", [(0, 2), (0, 3), (2, 2)])
+def test_rows_of_hub_nodes_are_split_into_parts(T, N, E, K, C):
+    """Hubs of the LABELLED edges (one node incident to 40 % of a slice's edges: rows of ~12 000 entries next to rows of one):
+    the plan cuts rows of more than 256 entries into parts (ops.HeadLossPlan -> arow's 4th column, tmgcn_head_loss_combine_f32),
+    every sum of the kernel being linear in the entries.  Loss, logits, dZ (or the folded model's dW) and dU against the
+    scripts' statements in fp64; reproducible to the bit."""
+    F = 6
+    g = torch.Generator().manual_seed(T * 31 + K + C)
+    Z = torch.randn(T, N, K if K else F, generator=g).cuda()
+    W = (torch.randn(K, F, generator=g) * 0.7).cuda() if K else None
+    U = torch.randn(2 * F, C, generator=g).cuda()
+    t = torch.randint(0, T, (E,), generator=g)
+    src, dst = torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)
+    src[torch.rand(E, generator=g) < 0.4] = 11                     # node 11 of every slice: a hub on the src side …
+    dst[torch.rand(E, generator=g) < 0.05] = 11                    # … sometimes on the dst side, self-pairs included
+    dst[torch.rand(E, generator=g) < 0.02] = 5                     # a second, smaller hub (rows of 300-600 entries: two or three parts)
+    edges = torch.stack([t, src, dst])
+    target = torch.randint(0, C, (E,), generator=g)
+    target[torch.rand(E, generator=g) < 0.03] = -100
+    target = target.cuda()
+    weight = (torch.rand(C, generator=g) + 0.1).cuda()
+    idx = ops.EdgeIndex(edges, N, "cuda", T=T)
+    plan = ops.head_loss_plan(idx, T * N, target, C)
+    assert plan.srow is not None and plan.n_parts >= 2 * T and int(plan.arow[:, 3].max()) == plan.n_parts
+    assert int((plan.arow[:, 2] - plan.arow[:, 1]).max()) <= ops.HeadLossPlan.SPLIT
+
+    def run():
+        Zr, Ur = Z.clone().requires_grad_(True), U.clone().requires_grad_(True)
+        Wr = W.clone().requires_grad_(True) if K else None
+        loss, logits = ops.head_loss(Zr if not K else Z, idx, Ur, target, weight, want_logits=True, fold_W=Wr)
+        loss.backward()
+        return loss.detach(), logits, (Wr.grad if K else Zr.grad), Ur.grad
+
+    loss, logits, dA, dU = run()
+    ref_logits, ref_loss, ref_dZ, ref_dU, ref_dW = _fp64(Z, W, U, edges, target, weight, N)
+    assert_close(logits, ref_logits, 1e-6, "logits")
+    assert abs(float(loss) - float(ref_loss)) <= 1e-6 * max(1.0, abs(float(ref_loss)))
+    assert_close(dA, ref_dW if K else ref_dZ, 2e-6, "dW" if K else "dZ")
+    assert_close(dU, ref_dU, 2e-6, "dU")
+    again = run()
+    assert all(torch.equal(x, y) for x, y in zip((loss, logits, dA, dU), again))
+
+
 @pytest.mark.parametrize("kw", [dict(lr=0.01, momentum=0.9), dict(lr=0.05), dict(lr=0.02, momentum=0.8, dampening=0.1, weight_decay=0.01, nesterov=False),
                                 dict(lr=0.01, momentum=0.9, nesterov=True)])
 def test_whole_training_step_of_the_folded_model_in_one_launch(kw):

@@ -44,7 +44,9 @@ struct HeadLossArgs {
   const float* Wf;             // fold: [K][F]
   const float* U;              // [2F][C]
   const int32_t* eptr;         // [R+1]
-  const int4* arow;            // [n_active] (row, first entry, end entry, -)
+  const int4* arow;            // [n_active] (row, first entry, end entry, part): part = 0: all entries of the row; part = p > 0:
+                               //   one PART of a row the plan split (long rows: hubs of the labelled edges) — its dZ share goes
+                               //   to row R + p - 1 of dZ and tmgcn_head_loss_combine_f32 adds the parts up afterwards
   const int32_t* ent;          // [2E]  2*edge + role (read only when the logits are stored)
   const int32_t* other;        // [2E]  row of the other endpoint
   const uint8_t* meta;         // [2E]  role << 7 | target class (127 = ignored)
@@ -303,7 +305,8 @@ __global__ __launch_bounds__(256) void head_loss_small_kernel(HeadLossArgs a) {
         float sf[2 * CT];
 #pragma unroll
         for (int c = 0; c < 2 * CT; ++c) sf[c] = (float)(Sf[c] * invden_g);
-        float2* o = reinterpret_cast<float2*>(a.dZ + r * FT);
+        // (a part of a split row stores its share of dZ[r] — the expression is linear in S — to its own scratch row)
+        float2* o = reinterpret_cast<float2*>(a.dZ + (cur.w ? a.R + cur.w - 1 : r) * FT);
         for (int q = gl; q < FT / 2; q += G) {        // lane q of the group stores features 2q, 2q+1
           float v0 = 0.f, v1 = 0.f;
 #pragma unroll
@@ -460,6 +463,18 @@ static void head_loss_launch_c(const HeadLossArgs& a, int C, bool grad, int K, i
   }
 }
 
+// dZ of the rows the plan split: dZ[row] = Σ_parts dZ[R + first + k], k ascending (fixed order).  One thread per (row, feature).
+__global__ __launch_bounds__(256) void head_loss_combine_kernel(const int4* __restrict__ srow, int32_t n_split, float* __restrict__ dZ,
+                                                                 int64_t R, int32_t F) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)n_split * F) return;
+  const int4 s = srow[i / F];                         // (row, first part, number of parts, -)
+  const int f = (int)(i % F);
+  float v = 0.f;
+  for (int k = 0; k < s.z; ++k) v += dZ[(R + s.y + k) * F + f];
+  dZ[(int64_t)s.x * F + f] = v;
+}
+
 // dst_a = g·a, dst_b = g·b in one launch (g a device scalar: the upstream gradient of the loss)
 __global__ __launch_bounds__(256) void scale2_kernel(const float* __restrict__ g, const float* __restrict__ a,
                                                       float* __restrict__ oa, int64_t na, const float* __restrict__ b,
@@ -494,8 +509,8 @@ extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t 
                                     void* workspace, int64_t workspace_bytes, int32_t* sync, void* stream) {
   TMGCN_REQUIRE(tmgcn_head_loss_supported(F, C, K), "head_loss: unsupported widths F=%d C=%d K=%d (even F <= 8, 2 <= C <= 4, K in {0, 2})",
                 F, C, K);
-  TMGCN_REQUIRE(R > 0 && E > 0 && R < (int64_t)0x7fffffff && 2 * E < (int64_t)0x7fffffff && n_active > 0 && n_active <= R,
-                "head_loss: need 0 < R, 2E < 2^31 and 0 < n_active <= R (got R=%lld E=%lld n_active=%lld)", (long long)R,
+  TMGCN_REQUIRE(R > 0 && E > 0 && R < (int64_t)0x7fffffff && 2 * E < (int64_t)0x7fffffff && n_active > 0 && n_active <= R + 2 * E,
+                "head_loss: need 0 < R, 2E < 2^31 and 0 < n_active <= R + 2E (got R=%lld E=%lld n_active=%lld)", (long long)R,
                 (long long)E, (long long)n_active);
   TMGCN_REQUIRE(Z && U && eptr && arow && other && meta && class_count && weight && workspace, "head_loss: null pointer");
   if (!sync) sync = acquire_sync_word((hipStream_t)stream);
@@ -527,6 +542,16 @@ extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t 
     default: head_loss_launch_c<8>(a, C, grad, K, G, R, st);
   }
   return check_launch("head_loss");
+}
+
+extern "C" int tmgcn_head_loss_combine_f32(const int32_t* srow, int32_t n_split, float* dZ, int64_t R, int32_t F, void* stream) {
+  TMGCN_REQUIRE(n_split >= 0 && R > 0 && F > 0, "head_loss_combine: bad sizes n_split=%d R=%lld F=%d", n_split, (long long)R, F);
+  if (n_split == 0) return TMGCN_OK;
+  TMGCN_REQUIRE(srow && dZ && reinterpret_cast<uintptr_t>(srow) % 16 == 0, "head_loss_combine: null pointer or srow not 16-byte aligned");
+  const int64_t n = (int64_t)n_split * F;
+  hipLaunchKernelGGL(head_loss_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const int4*>(srow), n_split, dZ, R, F);
+  return check_launch("head_loss_combine");
 }
 
 extern "C" int tmgcn_head_loss_sgd_f32(const float* Z, float* W_fold, int32_t K, float* U, const int32_t* eptr, const int32_t* arow,

@@ -426,7 +426,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> head_loss_fwd(const Tensor& Z, const 
                                                          const Tensor& eptr, const Tensor& arow, const Tensor& ent,
                                                          const Tensor& other, const Tensor& meta, const Tensor& counts,
                                                          const Tensor& weight, Tensor sync, const OptTensor& gscale,
-                                                         bool grad, bool want_logits, bool want_loss) {
+                                                         bool grad, bool want_logits, bool want_loss, const OptTensor& srow,
+                                                         int64_t n_parts) {
   want(Z, "head_loss Z");
   want(U, "head_loss U");
   want(weight, "head_loss weight");
@@ -456,7 +457,15 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> head_loss_fwd(const Tensor& Z, const 
   c10::DeviceGuard g(Z.device());
   Tensor loss = want_loss ? at::empty({}, Z.options()) : none_like(Z);
   Tensor logits = want_logits ? at::empty({E, C}, Z.options()) : none_like(Z);
-  Tensor dZ = grad ? (fold ? at::empty({K, F}, Z.options()) : at::empty_like(Z)) : none_like(Z);
+  // rows the plan split (hubs of the labelled edges): their parts' shares of dZ go to n_parts scratch rows behind the R real
+  // ones and are added up by tmgcn_head_loss_combine_f32 right after the launch (include/tmgcn.h)
+  const bool split = srow.has_value() && srow->defined() && srow->numel() > 0 && n_parts > 0;
+  if (split) {
+    want(*srow, "head_loss srow", at::kInt);
+    TORCH_CHECK(srow->dim() == 2 && srow->size(1) == 4, "head_loss: srow must be [n_split, 4]");
+  }
+  Tensor dZfull = (grad && !fold) ? at::empty({R + (split ? n_parts : 0), F}, Z.options()) : Tensor();
+  Tensor dZ = grad ? (fold ? at::empty({K, F}, Z.options()) : dZfull.narrow(0, 0, R)) : none_like(Z);
   Tensor dU = grad ? at::empty_like(U) : none_like(Z);
   const int64_t need = tmgcn_head_loss_workspace_bytes((int32_t)F, (int32_t)C, (int32_t)K);
   Tensor ws = at::empty({need}, Z.options().dtype(at::kByte));
@@ -468,6 +477,9 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> head_loss_fwd(const Tensor& Z, const 
                          (grad && !fold) ? (float*)ptr(dZ) : nullptr, grad ? (float*)ptr(dU) : nullptr,
                          (grad && fold) ? (float*)ptr(dZ) : nullptr, ptr(ws), ws.numel(), (int32_t*)sync.data_ptr(), stream_of(Z)),
      "tmgcn_head_loss_f32");
+  if (split && grad && !fold)
+    ok(tmgcn_head_loss_combine_f32((const int32_t*)ptr(*srow), (int32_t)srow->size(0), (float*)ptr(dZfull), R, (int32_t)F, stream_of(Z)),
+       "tmgcn_head_loss_combine_f32");
   return {loss, logits, dZ, dU};
 }
 
@@ -809,7 +821,7 @@ struct HeadLossFn : public torch::autograd::Function<HeadLossFn> {
   static variable_list forward(AutogradContext* ctx, const Tensor& Z, const OptTensor& W_fold, const Tensor& U,
                                const Tensor& eptr, const Tensor& arow, const Tensor& ent, const Tensor& other,
                                const Tensor& meta, const Tensor& counts, const Tensor& weight, const Tensor& sync,
-                               bool want_logits, bool need, bool unit_grad) {
+                               bool want_logits, bool need, bool unit_grad, const OptTensor& srow, int64_t n_parts) {
     at::AutoDispatchBelowADInplaceOrView guard;
     const bool fold = W_fold.has_value() && W_fold->defined();
     Tensor Z2 = Z.contiguous().reshape({-1, Z.size(-1)});
@@ -818,11 +830,13 @@ struct HeadLossFn : public torch::autograd::Function<HeadLossFn> {
     // pass then, so one launch does everything whatever the shape
     const bool deferred = need && !fold && !unit_grad && R * F * 8 > E * 10;
     auto [loss, logits, dZ, dU] = head_loss_fwd(Z2, W_fold, U, eptr, arow, ent, other, meta, counts, weight, sync, OptTensor(),
-                                                need && !deferred, want_logits, true);
+                                                need && !deferred, want_logits, true, srow, n_parts);
     if (need && deferred)
-      ctx->save_for_backward({Z2, U, eptr, arow, ent, other, meta, counts, weight, sync});
+      ctx->save_for_backward({Z2, U, eptr, arow, ent, other, meta, counts, weight, sync,
+                              (srow.has_value() && srow->defined()) ? *srow : none_like(Z2)});
     else if (need)
       ctx->save_for_backward({dZ, dU});
+    ctx->saved_data["n_parts"] = n_parts;
     ctx->saved_data["zshape"] = Z.sizes().vec();
     ctx->saved_data["fold"] = fold;
     ctx->saved_data["deferred"] = deferred;
@@ -836,9 +850,9 @@ struct HeadLossFn : public torch::autograd::Function<HeadLossFn> {
     Tensor g = grads[0].contiguous().to(at::kFloat);
     Tensor gz, gu;
     if (deferred) {
-      TORCH_CHECK(sv.size() == 10, "head_loss: backward through a call made without gradients");
+      TORCH_CHECK(sv.size() == 11, "head_loss: backward through a call made without gradients");
       auto out = head_loss_fwd(sv[0], OptTensor(), sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7], sv[8], sv[9], g, true, false,
-                               false);
+                               false, sv[10].numel() ? OptTensor(sv[10]) : OptTensor(), ctx->saved_data["n_parts"].toInt());
       gz = std::get<2>(out);
       gu = std::get<3>(out);
     } else {
@@ -850,7 +864,7 @@ struct HeadLossFn : public torch::autograd::Function<HeadLossFn> {
         std::tie(gz, gu) = scale2(g, sv[0], sv[1]);
       }
     }
-    variable_list out(14);
+    variable_list out(16);
     if (fold) out[1] = gz; else out[0] = gz.reshape(ctx->saved_data["zshape"].toIntVector());
     out[2] = gu;
     return out;
@@ -1005,10 +1019,11 @@ Tensor edge_head_ad(const Tensor& Z, const Tensor& U, const Tensor& src, const T
 std::tuple<Tensor, Tensor> head_loss_ad(const Tensor& Z, const OptTensor& W_fold, const Tensor& U, const Tensor& eptr,
                                         const Tensor& arow, const Tensor& ent, const Tensor& other, const Tensor& meta,
                                         const Tensor& counts, const Tensor& weight, const Tensor& sync, bool want_logits,
-                                        bool unit_grad) {
+                                        bool unit_grad, const OptTensor& srow, int64_t n_parts) {
   const bool fold = W_fold.has_value() && W_fold->defined();
   const bool need = at::GradMode::is_enabled() && (U.requires_grad() || (fold ? W_fold->requires_grad() : Z.requires_grad()));
-  auto out = HeadLossFn::apply(Z, W_fold, U, eptr, arow, ent, other, meta, counts, weight, sync, want_logits, need, unit_grad);
+  auto out = HeadLossFn::apply(Z, W_fold, U, eptr, arow, ent, other, meta, counts, weight, sync, want_logits, need, unit_grad, srow,
+                               n_parts);
   return {out[0], out[1]};
 }
 Tensor layer12_ad(const Tensor& H, const Tensor& W1, const Tensor& W2, const Tensor& rowptr, const Tensor& col, const Tensor& val,
@@ -1051,8 +1066,8 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("wce_fwd(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> (Tensor, Tensor)");
   m.def("wce_bwd(Tensor logits, Tensor target, Tensor weight, Tensor stats, Tensor g, int ignore_index) -> Tensor");
   m.def("head_loss_fwd(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor arow, Tensor ent, Tensor other, Tensor meta, "
-        "Tensor counts, Tensor weight, Tensor(a!) sync, Tensor? gscale, bool grad, bool want_logits, bool want_loss) -> "
-        "(Tensor, Tensor, Tensor, Tensor)");
+        "Tensor counts, Tensor weight, Tensor(a!) sync, Tensor? gscale, bool grad, bool want_logits, bool want_loss, "
+        "Tensor? srow=None, int n_parts=0) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("scale2(Tensor g, Tensor a, Tensor b) -> (Tensor, Tensor)");
   m.def("sgd_step(Tensor(a!)[] params, Tensor[] grads, Tensor(b!)[] bufs, float lr, float momentum, float dampening, "
         "float weight_decay, bool nesterov, bool maximize, bool first_step) -> ()");
@@ -1077,7 +1092,8 @@ TORCH_LIBRARY(tmgcn, m) {
   m.def("layer12_supported(int K0, int F, int Nf) -> bool", &layer12_supported);
   m.def("weighted_ce(Tensor logits, Tensor target, Tensor weight, int ignore_index) -> Tensor");
   m.def("head_loss(Tensor Z, Tensor? W_fold, Tensor U, Tensor eptr, Tensor arow, Tensor ent, Tensor other, Tensor meta, "
-        "Tensor counts, Tensor weight, Tensor(a!) sync, bool want_logits, bool unit_grad) -> (Tensor, Tensor)");
+        "Tensor counts, Tensor weight, Tensor(a!) sync, bool want_logits, bool unit_grad, Tensor? srow=None, int n_parts=0) -> "
+        "(Tensor, Tensor)");
   m.def("head_loss_sgd(Tensor Z, Tensor(a!) W_fold, Tensor(b!) U, Tensor eptr, Tensor arow, Tensor other, Tensor meta, Tensor counts, "
         "Tensor weight, Tensor(c!) sync, Tensor(d!)? buf_W, Tensor(e!)? buf_U, float lr, float momentum, float dampening, "
         "float weight_decay, bool nesterov, bool maximize, bool first_step) -> (Tensor, Tensor, Tensor)");

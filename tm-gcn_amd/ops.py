@@ -115,6 +115,8 @@ class HeadLossPlan:
     tensor; nn.CrossEntropyLoss device-asserts on it).  `sync` is the launch's hand-off word: zero
     between launches, so launches that share a plan must not overlap (one training loop does not)."""
 
+    SPLIT = 256          # entries per part of a split row (see __init__)
+
     def __init__(self, edges: "EdgeIndex", R: int, target: torch.Tensor, C: int, ignore_index: int = -100):
         if edges.index_dtype != torch.int32 or R >= 2 ** 31 - 1:
             raise RuntimeError("head_loss: the edge set needs 64-bit indices; use edge_head + weighted_ce")
@@ -136,8 +138,27 @@ class HeadLossPlan:
         t8 = torch.where(ignored, torch.full_like(t, 127), t)                     # 7 bits of class, bit 7 = role
         self.meta = (t8[e] | (role.long() << 7)).to(torch.uint8).contiguous()
         active = torch.nonzero(self.eptr[1:] > self.eptr[:-1]).flatten()            # rows with at least one entry
-        self.arow = torch.stack((active.to(torch.int32), self.eptr[:-1][active], self.eptr[1:][active],
-                                 torch.zeros_like(active, dtype=torch.int32)), dim=1).contiguous()
+        beg, end = self.eptr[:-1][active].long(), self.eptr[1:][active].long()
+        # Hubs of the labelled edges: a group of at most 16 lanes walks a row's entries, so one node incident to 20 000 of them
+        # (real interaction graphs; the negatives of link prediction multiply them by 20) costs the launch 1.5 ms where the
+        # uniform case takes 0.1.  Rows of more than SPLIT entries are cut into parts of SPLIT (include/tmgcn.h: every sum
+        # of the kernel is linear in the entries; dZ shares are added up by tmgcn_head_loss_combine_f32).
+        n_part = torch.clamp((end - beg + self.SPLIT - 1) // self.SPLIT, min=1)
+        self.srow, self.n_parts = None, 0
+        if active.numel() and int(n_part.max()) > 1:
+            own = torch.repeat_interleave(torch.arange(active.numel(), device=dev), n_part)     # arow entry -> active row
+            k = torch.arange(own.numel(), device=dev) - (torch.cumsum(n_part, 0) - n_part)[own]    # part index inside its row
+            is_split = n_part[own] > 1
+            pid = torch.cumsum(is_split.long(), 0) * is_split                                    # 1, 2, … over all split rows' parts
+            pbeg = beg[own] + k * self.SPLIT
+            pend = torch.minimum(pbeg + self.SPLIT, end[own])
+            self.arow = torch.stack((active[own], pbeg, pend, pid), dim=1).to(torch.int32).contiguous()
+            sp = n_part > 1
+            first = (torch.cumsum(n_part * sp, 0) - n_part * sp)[sp]                             # first part - 1 of every split row
+            self.srow = torch.stack((active[sp], first, n_part[sp], torch.zeros_like(first)), dim=1).to(torch.int32).contiguous()
+            self.n_parts = int((n_part * sp).sum())
+        else:
+            self.arow = torch.stack((active, beg, end, torch.zeros_like(active)), dim=1).to(torch.int32).contiguous()
         self.counts = torch.bincount(t[~ignored], minlength=C)[:C].to(torch.int64).contiguous()
         self.sync = torch.zeros(_lib.SYNC_INTS, dtype=torch.int32, device=dev)   # include/tmgcn.h: TMGCN_SYNC_INTS
         self.R, self.C, self.ignore_index = R, C, ignore_index
@@ -633,7 +654,7 @@ def head_loss(Z: torch.Tensor, edges: EdgeIndex, U: torch.Tensor, target: torch.
     plan = head_loss_plan(edges, R, target, Cn, ignore_index)
     w = weight.detach().to(device=Z.device, dtype=torch.float32).contiguous()
     loss, logits = kernels.ops.head_loss(Z, fold_W, U.contiguous(), plan.eptr, plan.arow, plan.ent, plan.other, plan.meta,
-                                         plan.counts, w, plan.sync, bool(want_logits), bool(unit_grad))
+                                         plan.counts, w, plan.sync, bool(want_logits), bool(unit_grad), plan.srow, plan.n_parts)
     return (loss, logits) if want_logits else loss
 
 
