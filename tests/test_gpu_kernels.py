@@ -127,6 +127,28 @@ def test_spmm_gemm_long_rows_split_across_waves(case, K, Nf, per_slice):
     assert torch.equal(Y, Y2)
 
 
+@pytest.mark.parametrize("case", ["threshold", "one heavy tile of two"])
+@pytest.mark.parametrize("F,Nf", [(2, 6), (6, 6), (8, 4), (3, 16)])
+def test_narrow_kernels_leave_long_rows_to_the_whole_wave(case, F, Nf):
+    """The narrow kernels (F <= 8: G lanes per row) hand rows of more than 32 trips to all 64 lanes of the wave
+    (csrc/spmm_row.h: narrow_wave_row): plain SpMM and the fused narrow SpMM + GEMM against the C oracle, reproducible."""
+    T, N, lengths = LONG_ROW_CASES[case]
+    csr = _csr_with_row_lengths(T, N, lengths, seed=F * 13 + Nf)
+    g = torch.Generator().manual_seed(F)
+    X = torch.randn(T, N, F, generator=g)
+    W = torch.randn(F, Nf, generator=g) * 0.5
+    A = csr.to(DEV)
+    Y = ops.kernels.spmm(A, X.to(DEV))
+    ref = ref_spmm(csr, X)
+    assert_close(Y, ref, REL_TOL, f"narrow spmm F={F} {case}")
+    assert torch.equal(Y, ops.kernels.spmm(A, X.to(DEV)))
+    if ops.kernels.spmm_gemm_supported(F, Nf):
+        Z, AX, _ = ops.kernels.spmm_gemm(A, X.to(DEV), W.to(DEV), act="selu", want_ax=True)
+        assert_close(AX, ref, REL_TOL, f"narrow fused: SpMM intermediate F={F} {case}")
+        assert_close(Z, torch.nn.functional.selu(ref_gemm(ref, W)), REL_TOL, f"narrow fused F={F} Nf={Nf} {case}")
+        assert torch.equal(Z, ops.kernels.spmm_gemm(A, X.to(DEV), W.to(DEV), act="selu")[0])
+
+
 GIANT_ROWS = {(0, 17): 1_000_000, (0, 18): 40_000, (0, 90_000): 32_769, (1, 50_000): 32_768, (1, 50_001): 65_536,
               (1, 100_002): 200_001, (1, 0): 20_000}
 

@@ -168,43 +168,37 @@ __global__ __launch_bounds__(256) void spmm_small_kernel(
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
+  int64_t beg = 0, end = 0;
   if (live) {
-    const int64_t beg = rowptr[r];
-    const int64_t end = rowptr[r + 1];
+    beg = rowptr[r];
+    end = rowptr[r + 1];
+  }
+  // rows that would take this group more than kNarrowLong trips are left to the whole wave below (spmm_row.h)
+  const bool is_long = G < kWave && end - beg > (int64_t)kNarrowLong * G;
+  if (live && !is_long) {
     const int64_t xoff = (r / N) * (int64_t)N;
-    for (int64_t p = beg + gl; p < end; p += G) {
-      const int64_t src = (xoff + col[p]) * F;
-      const float v = val[p];
-      if constexpr (F % 4 == 0) {
-#pragma unroll
-        for (int q = 0; q < F / 4; ++q) {
-          const float4 x = *reinterpret_cast<const float4*>(X + src + 4 * q);
-          acc[4 * q + 0] = fmaf(v, x.x, acc[4 * q + 0]);
-          acc[4 * q + 1] = fmaf(v, x.y, acc[4 * q + 1]);
-          acc[4 * q + 2] = fmaf(v, x.z, acc[4 * q + 2]);
-          acc[4 * q + 3] = fmaf(v, x.w, acc[4 * q + 3]);
-        }
-      } else if constexpr (F % 2 == 0) {
-#pragma unroll
-        for (int q = 0; q < F / 2; ++q) {
-          const float2 x = *reinterpret_cast<const float2*>(X + src + 2 * q);
-          acc[2 * q + 0] = fmaf(v, x.x, acc[2 * q + 0]);
-          acc[2 * q + 1] = fmaf(v, x.y, acc[2 * q + 1]);
-        }
-      } else {
-#pragma unroll
-        for (int f = 0; f < F; ++f) acc[f] = fmaf(v, X[src + f], acc[f]);
-      }
-    }
+    for (int64_t p = beg + gl; p < end; p += G) narrow_fma<F>(acc, val[p], X + (xoff + col[p]) * F);
   }
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) {
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] += __shfl_xor(acc[f], o);
   }
-  if (live && gl == 0) {
+  if (live && !is_long && gl == 0) {
 #pragma unroll
     for (int f = 0; f < F; ++f) Y[r * F + f] = acc[f];
+  }
+  if constexpr (G < kWave) {
+    const int lane = threadIdx.x & 63;
+    for (uint64_t m = __ballot(is_long && gl == 0); m; m &= m - 1) {
+      const int src = __builtin_ctzll(m);
+      const int64_t r2 = readlane64(r, src), b2 = readlane64(beg, src), e2 = readlane64(end, src);
+      narrow_wave_row<F>(acc, col, val, X, (r2 / N) * (int64_t)N, b2, e2, lane);
+      if (lane == 0) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) Y[r2 * F + f] = acc[f];
+      }
+    }
   }
 }
 

@@ -205,8 +205,14 @@ __global__ __launch_bounds__(256) void spmm_gemm_small_kernel(FusedArgs a) {
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
+  int64_t beg = 0, end = 0;
   if (live) {
-    const int64_t beg = a.rowptr[r], end = a.rowptr[r + 1];
+    beg = a.rowptr[r];
+    end = a.rowptr[r + 1];
+  }
+  // rows that would take this group more than kNarrowLong trips are left to the whole wave below (spmm_row.h)
+  const bool is_long = G < kWave && end - beg > (int64_t)kNarrowLong * G;
+  if (live && !is_long) {
     const int64_t xoff = (r / a.N) * (int64_t)a.N;
     for (int64_t p = beg + gl; p < end; p += G) {
       const float* x = X + (xoff + a.col[p]) * F;
@@ -219,18 +225,30 @@ __global__ __launch_bounds__(256) void spmm_gemm_small_kernel(FusedArgs a) {
   for (int o = G >> 1; o > 0; o >>= 1)
 #pragma unroll
     for (int f = 0; f < F; ++f) acc[f] += __shfl_xor(acc[f], o);
-  if (!live) return;
-  if (a.AX && gl == 0) {
+  // the row sum is in every lane of the group (of the wave, for a long row): `lanes` of them form the output columns
+  auto epilogue = [&](int64_t row, int first, int lanes) {
+    if (a.AX && first == 0) {
 #pragma unroll
-    for (int f = 0; f < F; ++f) a.AX[r * F + f] = acc[f];
-  }
-  const float* Wb = a.W + (a.rows_per_batch ? (r / a.rows_per_batch) * a.w_batch_stride : 0);
-  for (int n = gl; n < a.Nf; n += G) {
-    float s = 0.f;
+      for (int f = 0; f < F; ++f) a.AX[row * F + f] = acc[f];
+    }
+    const float* Wb = a.W + (a.rows_per_batch ? (row / a.rows_per_batch) * a.w_batch_stride : 0);
+    for (int n = first; n < a.Nf; n += lanes) {
+      float s = 0.f;
 #pragma unroll
-    for (int f = 0; f < F; ++f) s = fmaf(acc[f], a.trans_w ? Wb[(int64_t)n * F + f] : Wb[(int64_t)f * a.Nf + n], s);
-    if (a.pre) a.pre[r * a.Nf + n] = s;
-    a.Y[r * a.Nf + n] = act(s);
+      for (int f = 0; f < F; ++f) s = fmaf(acc[f], a.trans_w ? Wb[(int64_t)n * F + f] : Wb[(int64_t)f * a.Nf + n], s);
+      if (a.pre) a.pre[row * a.Nf + n] = s;
+      a.Y[row * a.Nf + n] = act(s);
+    }
+  };
+  if (live && !is_long) epilogue(r, gl, G);
+  if constexpr (G < kWave) {
+    const int lane = threadIdx.x & 63;
+    for (uint64_t m = __ballot(is_long && gl == 0); m; m &= m - 1) {
+      const int src = __builtin_ctzll(m);
+      const int64_t r2 = readlane64(r, src), b2 = readlane64(beg, src), e2 = readlane64(end, src);
+      narrow_wave_row<F>(acc, a.col, a.val, X, (r2 / a.N) * (int64_t)a.N, b2, e2, lane);
+      epilogue(r2, lane, kWave);
+    }
   }
 }
 

@@ -204,6 +204,66 @@ __device__ __forceinline__ float4 gather_long_row(const int32_t* __restrict__ co
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Narrow kernels (F <= 8: spmm_small, spmm_gemm_small): G lanes share a row and stride over its entries.  A row that
+// would take a group more than kNarrowLong trips is left to the WHOLE WAVE afterwards: the groups flag their long rows
+// (ballot), and for each of them all 64 lanes stride over the entries, four (col, val) pairs and four gathers in flight per
+// lane, combined by the full butterfly — 8 to 64 times the lanes and a quarter of the dependent round trips for the rows
+// that would otherwise be the launch's tail (a 10 000-entry hub on 8 lanes: 1 250 trips).  Fixed order: reproducible.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kNarrowLong = 32;
+
+template <int F>
+__device__ __forceinline__ void narrow_fma(float (&acc)[F], float v, const float* __restrict__ x) {
+  if constexpr (F % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < F / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(x + 4 * q);
+      acc[4 * q + 0] = fmaf(v, t.x, acc[4 * q + 0]);
+      acc[4 * q + 1] = fmaf(v, t.y, acc[4 * q + 1]);
+      acc[4 * q + 2] = fmaf(v, t.z, acc[4 * q + 2]);
+      acc[4 * q + 3] = fmaf(v, t.w, acc[4 * q + 3]);
+    }
+  } else if constexpr (F % 2 == 0) {
+#pragma unroll
+    for (int q = 0; q < F / 2; ++q) {
+      const float2 t = *reinterpret_cast<const float2*>(x + 2 * q);
+      acc[2 * q + 0] = fmaf(v, t.x, acc[2 * q + 0]);
+      acc[2 * q + 1] = fmaf(v, t.y, acc[2 * q + 1]);
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = fmaf(v, x[f], acc[f]);
+  }
+}
+
+// Σ over [beg, end) of val[p]·X[xoff + col[p]] by the 64 lanes of the calling wave (beg, end wave-uniform, end > beg); on
+// return every lane holds the sum.
+template <int F>
+__device__ __forceinline__ void narrow_wave_row(float (&acc)[F], const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                const float* __restrict__ X, int64_t xoff, int64_t beg, int64_t end, int lane) {
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = 0.f;
+  constexpr int NB = 4;
+  for (int64_t p = beg + lane; p < end; p += NB * kWave) {
+    int c[NB];
+    float v[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {                      // unconditional loads on clamped positions, masked by a zero value
+      const int64_t q = p + u * kWave;
+      const int64_t qc = q < end ? q : end - 1;
+      c[u] = col[qc];
+      v[u] = q < end ? val[qc] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) narrow_fma<F>(acc, v[u], X + (xoff + c[u]) * F);
+  }
+#pragma unroll
+  for (int o = kWave >> 1; o > 0; o >>= 1)
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] += __shfl_xor(acc[f], o);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Giant rows.  Four waves of one block gather 41 M entries/s (tools/hub_tail_probe.py): a row of 10^6 entries is 23 ms
 // on its own, whatever else the launch holds.  With a PLAN from the caller (the rows of more than kGiantRow entries and a
 // chunk count for each: csr.BatchedCSR.giant_plan) such rows are cut into chunks of kGiantChunk entries that a small
