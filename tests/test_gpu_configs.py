@@ -65,9 +65,9 @@ def _check(got, ref32, truth, what):
         f"{what}: vs reference-fp32 {e_ref:.2e}, vs fp64 truth {e_truth:.2e} (reference itself {e_ref_truth:.2e})"
 
 
-def _run_model(name, kind, hidden, nonlin="selu", param_dtype=torch.float32, scale=1.0):
+def _run_model(name, kind, hidden, nonlin="selu", param_dtype=torch.float32, scale=1.0, **graph_kw):
     from oracle import tmgcn_oracle as orc
-    g = synth.dynamic_graph(**synth.CONFIGS[name], seed=0)
+    g = synth.dynamic_graph(**{**synth.CONFIGS[name], **graph_kw}, seed=0)
     At, X, M = g.At_list(), torch.from_numpy(g.X), torch.from_numpy(g.M)
     edges, labels = torch.from_numpy(g.edges), torch.from_numpy(g.labels)
     torch.manual_seed(1)
@@ -101,6 +101,19 @@ def test_S2_reddit_lp_shaped_1layer_fp32():
     _check(out, ref32, ref64, "S2 logits")
     for n, q in m.named_parameters():
         _check(q.grad, g32[n], g64[n], "S2 d" + n)
+
+
+@pytest.mark.parametrize("kind,hidden", [("gcn", [6, 2]), ("gcn2", [6, 6, 2])])
+def test_S2_shape_with_hub_nodes(kind, hidden):
+    """The Reddit-LP shape with HUB source nodes (Zipf 1.5: one node is the source of a third of every slice's edges): rows of
+    thousands of entries in the M-transformed adjacency and in the inverted index of the labelled edges — the narrow SpMM's
+    whole-wave rows, the entry-balanced row blocks of the fused layers, the split rows of the head + loss plan — for the
+    1-layer and the 2-layer model of the link-prediction scripts (experiment_reddit_our_link_prediction.py:61-64), against the
+    oracle run the reference's way."""
+    m, out, (ref32, g32), (ref64, g64) = _run_model("S2", kind, hidden, zipf=1.5, edges_per_slice=1500, neg_per_pos=4)
+    _check(out, ref32, ref64, f"S2-hubs {kind} logits")
+    for n, q in m.named_parameters():
+        _check(q.grad, g32[n], g64[n], f"S2-hubs {kind} d" + n)
 
 
 def test_S3_amlsim_shaped_bf16_weights():

@@ -37,11 +37,16 @@ def band_M(T: int, no_diag: int = 20, kind: str = "matlab") -> np.ndarray:
     return M
 
 
-def random_slices(T: int, N: int, edges_per_slice: int, rng: np.random.Generator) -> List[sp.csr_matrix]:
-    """T raw directed adjacency slices with unit weights (duplicates merged)."""
+def random_slices(T: int, N: int, edges_per_slice: int, rng: np.random.Generator, zipf: float = 0.0) -> List[sp.csr_matrix]:
+    """T raw directed adjacency slices with unit weights (duplicates merged).  zipf > 0: source nodes drawn with
+    probability ∝ rank^-zipf (the same hubs in every slice), as interaction graphs have them; 0: uniform."""
     out = []
+    p = None
+    if zipf > 0:
+        p = np.arange(1, N + 1, dtype=np.float64) ** (-zipf)
+        p /= p.sum()
     for _ in range(T):
-        r = rng.integers(0, N, edges_per_slice)
+        r = rng.choice(N, edges_per_slice, p=p) if p is not None else rng.integers(0, N, edges_per_slice)
         c = rng.integers(0, N, edges_per_slice)
         a = sp.coo_matrix((np.ones(edges_per_slice), (r, c)), shape=(N, N)).tocsr()
         a.data[:] = 1.0
@@ -133,15 +138,16 @@ class DynamicGraph:
 
 def dynamic_graph(T: int, N: int, edges_per_slice: int, seed: int = 0, window: int = 10,
                   no_diag: int = 20, m_kind: str = "matlab", F0: Optional[int] = None,
-                  neg_per_pos: int = 0) -> DynamicGraph:
+                  neg_per_pos: int = 0, zipf: float = 0.0) -> DynamicGraph:
     """Reference-shaped dynamic graph: raw random slices -> Ĉ -> Â = M ×₁ Ĉ, features, labelled edges.
 
     neg_per_pos = 0 : edge classification (labels random in {0,1}, the Bitcoin scripts' shape)
     neg_per_pos > 0 : link prediction (positives label 0, ``neg_per_pos`` sampled non-edges label 1;
                       ehf.augment_edges:500-526 with a seeded vectorised sampler)
+    zipf > 0        : hub source nodes (random_slices): skewed rows in Â and skewed endpoints of the labelled edges
     """
     rng = np.random.default_rng(seed)
-    A = random_slices(T, N, edges_per_slice, rng)
+    A = random_slices(T, N, edges_per_slice, rng, zipf)
     C = normalise(edge_life(symmetrise(A), window))
     M = band_M(T, no_diag, m_kind)
     Ct = m_product(C, M)
