@@ -264,6 +264,8 @@ EPOCH_MODELS = {  # the scripts' model per config
     "S2": dict(kind="gcn", hidden=[6, 2]),                      # experiment_reddit_our_link_prediction.py:65
     "S3": dict(kind="gcn2", hidden=[6, 6, 2], nonlin="selu", bf16=True),  # AMLSim, bf16 weights
     "P128": dict(kind="gcn2", hidden=[128, 128, 2], nonlin="relu", scale=0.05),  # BASELINE.md §2 probe, wide features
+    "S2z": dict(kind="gcn", hidden=[6, 2]),                     # hub source nodes (synth.CONFIGS): the 1-layer …
+    "S2z2": dict(kind="gcn2", hidden=[6, 6, 2], nonlin="selu"),  # … and the 2-layer link-prediction model
 }
 
 

@@ -44,7 +44,7 @@ typedef enum {
 /* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
 enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
 
-/* ABI version 5 = version 4 + tmgcn_pool_stats + the row_blocks partition argument of tmgcn_layer12_fwd/bwd_f32 + tmgcn_head_loss_combine_f32 (split rows of the one-pass head + loss plan) + the giant-row
+/* ABI version 5 = version 4 + tmgcn_pool_stats + the row_blocks partition argument of tmgcn_layer12_fwd/bwd_f32 + tmgcn_head_loss_combine_f32 / tmgcn_head_loss_lanes (split rows of the one-pass head + loss plan) + the giant-row
  *   plan entry points tmgcn_spmm_csr_batched_f32_plan / tmgcn_spmm_gemm_f32_plan / tmgcn_spmm_giant_workspace_bytes; the launchers' scratch words (tile counters, hand-off blocks) are kept apart
  *   per stream (eager launches) and per recorded launch (hipGraph capture), and a launcher that cannot keep two launches
  *   apart returns TMGCN_ERR_INVALID with the reason instead of re-using a word that may be in flight (csrc/pools.hip).
@@ -250,7 +250,9 @@ int tmgcn_gemm_dw_act_f32(const float* A, const float* dY, const float* pre_act,
  *   entry-major kernels — n_row_blocks + 1 ascending first-row indices from 0 to n_rows, at most 256 rows per block
  *   (N >= 256: a block then holds at most one slice boundary).  A caller that knows its row lengths cuts the blocks so
  *   that none holds more than about two 1 024-entry tiles (csr.BatchedCSR.row_blocks): with real, skewed data the
- *   longest block otherwise sets the launch time.  The forward's and the backward's partitions are independent (the
+ *   longest block otherwise sets the launch time.  The BACKWARD takes its entry-major kernel whenever a partition is given
+ *   (otherwise only for fewer than 4 entries per row): a caller passes one for skewed adjacencies — hub rows — and none for
+ *   evenly filled ones, where lanes-per-row is the faster walk above 4 entries per row.  The forward's and the backward's partitions are independent (the
  *   backward's is over the TRANSPOSED rows); results do not depend on the partition in the forward (whole rows) and
  *   are bit-reproducible for a given partition in the backward (dW1 is summed per block, blocks in order). */
 int tmgcn_layer12_supported(int32_t K0, int32_t F, int32_t Nf);
@@ -360,6 +362,9 @@ int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* w
  */
 #define TMGCN_SYNC_INTS 272
 int tmgcn_head_loss_supported(int32_t F, int32_t C, int32_t K);
+/* lanes that will share one arow entry (1, 4 or 16: chosen from the mean number of entries per arow entry; a lane takes its
+ * entries 2 (one lane) or 8 at a time): a plan that splits rows sizes its parts from this — about eight trips of the group */
+int tmgcn_head_loss_lanes(int64_t E, int64_t n_active);
 /* srow [n_split][4] = (row, first part - 1, number of parts, 0) of every split row: dZ[row] = Σ_k dZ[R + first + k], k ascending */
 int tmgcn_head_loss_combine_f32(const int32_t* srow, int32_t n_split, float* dZ, int64_t R, int32_t F, void* stream);
 int64_t tmgcn_head_loss_workspace_bytes(int32_t F, int32_t C, int32_t K);

@@ -884,6 +884,41 @@ def test_layer12_entry_major_kernels_on_skewed_rows(act2):
     _assert_layer12_vs_oracle(out[0], H, W1, "selu", A, W2, act2, dZ, "entry-major fused")
 
 
+@pytest.mark.parametrize("base_deg", [1, 12])            # the backward's two walks: entry-major (sparse rows) / lanes per row
+@pytest.mark.parametrize("act2", [None, "selu"])
+def test_layer12_hub_rows(base_deg, act2):
+    """Hub rows (3 000 and 700 entries next to rows of 1-12) through the fused layers 1 + 2: the entry-major kernels hand a long
+    segment of a tile to the owning wave, the lanes-per-row backward hands a long row to the whole wave (csrc/layer12.hip) —
+    forward and both weight gradients against the oracle, reproducible."""
+    T, N = 3, 1300
+    lengths = {(0, 5): 3000, (1, 700): 3000, (1, 701): 700, (2, 1299): 1500, (2, 0): 65}
+    g0 = torch.Generator().manual_seed(base_deg)
+    cnt = torch.full((T * N,), base_deg, dtype=torch.int64)
+    for (k, i), n in lengths.items():
+        cnt[k * N + i] = n
+    rowptr = torch.zeros(T * N + 1, dtype=torch.int64)
+    torch.cumsum(cnt, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    rows = torch.repeat_interleave(torch.arange(T * N), cnt)
+    cols = torch.randint(0, N, (nnz,), generator=g0)
+    from tmgcn_amd import adjacency
+    A = adjacency.DeviceCOO.from_edges((rows // N).numpy(), (rows % N).numpy(), cols.numpy(),
+                                       (torch.rand(nnz, generator=g0) * 0.5 + 0.1).numpy().astype(np.float32), T, N).sort_reduce().to_csr()
+    assert int((A.rowptr[1:] - A.rowptr[:-1]).max()) > 1000
+    g = torch.Generator().manual_seed(7)
+    H = torch.randn(T, N, 2, generator=g).to(DEV)
+    W1, W2 = (torch.randn(2, 6, generator=g) * 0.7).to(DEV), (torch.randn(6, 6, generator=g) * 0.7).to(DEV)
+    dZ = torch.randn(T, N, 6, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        a1, a2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+        Z = ops.layer12(H, a1, "selu", A, a2, act2, fuse=True)
+        Z.backward(dZ)
+        outs.append((Z.detach(), a1.grad, a2.grad))
+    assert all(torch.equal(x, y) for x, y in zip(*outs))
+    _assert_layer12_vs_oracle(outs[0], H, W1, "selu", A, W2, act2, dZ, f"hub rows, {base_deg} per row")
+
+
 @pytest.mark.parametrize("act1,act2", [("selu", None), ("relu", None), ("leaky", "relu"), (None, "selu")])
 @pytest.mark.parametrize("T,N,deg,F,Nf", [(5, 300, 3.0, 6, 6), (3, 77, 12.0, 6, 2), (4, 500, 0.4, 2, 6), (2, 64, 40.0, 8, 4),
                                           # staged variants (slice in LDS): several blocks per slice with a ragged last

@@ -64,6 +64,7 @@ SIGNATURES = {
     "tmgcn_wce_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i64, _p, _p]),
     "tmgcn_head_loss_supported": (C.c_int, [_i32, _i32, _i32]),
     "tmgcn_head_loss_combine_f32": (C.c_int, [_p, _i32, _p, _i64, _i32, _p]),
+    "tmgcn_head_loss_lanes": (C.c_int, [_i64, _i64]),
     "tmgcn_head_loss_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "tmgcn_head_loss_sgd_f32": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p, _p]),
     "tmgcn_head_loss_f32": (C.c_int, [_p, _p, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _i64, _p, _p]),

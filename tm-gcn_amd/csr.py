@@ -178,6 +178,17 @@ class BatchedCSR:
             self._t = t
         return self._t
 
+    def max_row_length(self) -> int:
+        """Stored entries of the longest row (cached; one host sync per CSR)."""
+        if "max_row" not in self._blocks:
+            self._blocks["max_row"] = int((self.rowptr[1:] - self.rowptr[:-1]).max()) if self.n_rows else 0
+        return self._blocks["max_row"]
+
+    def is_skewed(self) -> bool:
+        """Hub rows: the longest row holds more than 64 entries and more than 8 times the mean."""
+        m = self.max_row_length()
+        return m > 64 and m > 8 * self.avg_nnz_per_row
+
     def row_blocks(self, max_rows: int = 256, max_entries: int = 2048) -> Optional[torch.Tensor]:
         """Partition of the rows for the entry-major layer kernels (tmgcn_layer12_fwd/bwd_f32's `row_blocks`), cached:
         blocks of `max_rows` consecutive rows, and every such block that holds more than `max_entries` stored entries

@@ -544,6 +544,8 @@ extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t 
   return check_launch("head_loss");
 }
 
+extern "C" int tmgcn_head_loss_lanes(int64_t E, int64_t n_active) { return head_loss_lanes(E, n_active); }
+
 extern "C" int tmgcn_head_loss_combine_f32(const int32_t* srow, int32_t n_split, float* dZ, int64_t R, int32_t F, void* stream) {
   TMGCN_REQUIRE(n_split >= 0 && R > 0 && F > 0, "head_loss_combine: bad sizes n_split=%d R=%lld F=%d", n_split, (long long)R, F);
   if (n_split == 0) return TMGCN_OK;

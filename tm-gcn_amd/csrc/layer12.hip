@@ -53,6 +53,12 @@ struct L12Args {
   int32_t n_blk;
 };
 
+__device__ __forceinline__ int64_t l12_readlane64(int64_t v, int l) {   // l wave-uniform
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffff), l);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+  return ((int64_t)hi << 32) | lo;
+}
+
 template <int N, typename T>
 __device__ __forceinline__ T pick_at(const T (&v)[N], int i) {
   T r = v[0];
@@ -251,7 +257,48 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
 // under rocprofv3: chess 57 -> 37.6 us, the synthetic Bitcoin-OTC shape 21.7 -> 18.2.
 // Rows of two slices may share a block (N >= 256: at most one boundary): an entry's H row is found by comparing its
 // position with the first entry of the second slice.
+#ifndef TMGCN_L12_LONG_TRIPS
+#define TMGCN_L12_LONG_TRIPS 8     // trips of a row's G lanes beyond which the whole wave gathers it (l12_bwd_kernel; 16: S2z2 backward 90 us)
+#endif
 constexpr int kEmTile = 1024;      // 512: chess 56.6 us, 2 048: the synthetic shape 26.7 (two blocks per CU)
+constexpr int kEmLong = 64;        // entries of one row inside a tile beyond which the row's WAVE sums them (below)
+
+// Thread t adds the entries [lo, hi) of ITS row that lie in the tile parked in LDS (value in plane 0, the W planes behind
+// it), in entry order.  A segment of more than kEmLong entries — a hub row: one lane walking 1 024 entries is 50 us per tile
+// while 255 lanes wait (the Reddit-LP shape with Zipf sources: forward 329 us) — is summed by all 64 lanes of the wave that
+// owns the row instead (lanes stride over the entries, butterfly, the owner adds the sum): fixed order, reproducible.
+template <int W>
+__device__ __forceinline__ void em_row_sum(const float (&park)[1 + W][kEmTile], int tile, int lo, int hi, float (&acc)[W]) {
+  const bool seg_long = hi - lo > kEmLong;
+  if (!seg_long) {
+    for (int e = lo; e < hi; ++e) {
+      const float w = park[0][e - tile];
+#pragma unroll
+      for (int f = 0; f < W; ++f) acc[f] = fmaf(w, park[1 + f][e - tile], acc[f]);
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  for (uint64_t m = __ballot(seg_long); m; m &= m - 1) {
+    const int src = __builtin_ctzll(m);
+    const int slo = __builtin_amdgcn_readlane(lo, src), shi = __builtin_amdgcn_readlane(hi, src);
+    float part[W];
+#pragma unroll
+    for (int f = 0; f < W; ++f) part[f] = 0.f;
+    for (int e = slo + lane; e < shi; e += 64) {
+      const float w = park[0][e - tile];
+#pragma unroll
+      for (int f = 0; f < W; ++f) part[f] = fmaf(w, park[1 + f][e - tile], part[f]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int f = 0; f < W; ++f) part[f] += __shfl_xor(part[f], o);
+    if (lane == src) {
+#pragma unroll
+      for (int f = 0; f < W; ++f) acc[f] += part[f];
+    }
+  }
+}
 
 template <int KI, int F, int NT>
 __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
@@ -327,11 +374,7 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
     }
     __syncthreads();
     const int lo = my_lo > tile ? my_lo : tile, hi = my_hi < tile + kEmTile ? my_hi : tile + kEmTile;
-    for (int e = lo; e < hi; ++e) {
-      const float w = park[0][e - tile];
-#pragma unroll
-      for (int f = 0; f < F; ++f) acc[f] = fmaf(w, park[1 + f][e - tile], acc[f]);
-    }
+    em_row_sum<F>(park, tile, lo, hi, acc);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PER; ++u) c[u] = c_next[u], v[u] = v_next[u];
@@ -434,20 +477,31 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
     r_end = a.n_rows;
     r_step = (int64_t)gridDim.x * 256 / G;
   }
-  for (; r < r_end; r += r_step) {
-    int64_t beg, end;
+  constexpr int NB = STAGED ? 8 : 4;                         // NB consecutive non-zeros per lane and trip (see the forward kernel)
+  // unstaged: a row that would take its G lanes more than kL12LongTrips trips (a hub: 3 800 entries on two lanes are 470
+  // trips, 200 us of a launch that takes 30 without it) is gathered by all 64 lanes of the wave after the groups' own rows
+  constexpr bool WAVE_ROWS = !STAGED && G < 64;
+  constexpr int kL12LongTrips = TMGCN_L12_LONG_TRIPS;
+  for (;; r += r_step) {
+    const bool live = r < r_end;
+    if constexpr (WAVE_ROWS) {
+      if (__ballot(live) == 0) break;                      // (the wave leaves together: its long rows need all lanes)
+    } else {
+      if (!live) break;
+    }
+    int64_t beg = 0, end = 0;
     if constexpr (STAGED) {
       const int64_t* rps = reinterpret_cast<const int64_t*>(l12_stage + a.N * NT);
       beg = rps[r - r_base], end = rps[r - r_base + 1];
-    } else {
+    } else if (live) {
       beg = a.rowptr[r], end = a.rowptr[r + 1];
     }
     const int64_t xoff = STAGED ? 0 : (r / a.N) * (int64_t)a.N;   // staged: columns index the slice's LDS copy
     float t[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) t[n] = 0.f;
-    constexpr int NB = STAGED ? 8 : 4;                       // NB consecutive non-zeros per lane and trip (see the forward kernel)
-    for (int64_t t0 = beg; t0 < end; t0 += NB * G) {
+    const bool is_long = WAVE_ROWS && end - beg > (int64_t)kL12LongTrips * NB * G;
+    for (int64_t t0 = beg; t0 < (is_long ? beg : end); t0 += NB * G) {
       constexpr bool STRIDED = !STAGED && G > 1;
       constexpr int STEP = STRIDED ? G : 1;                   // entry of slot u: base + u·STEP
       const int64_t base = STRIDED ? t0 + gl : t0 + gl * NB;
@@ -490,6 +544,53 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
     for (int o = G >> 1; o > 0; o >>= 1)
 #pragma unroll
       for (int n = 0; n < NT; ++n) t[n] += __shfl_xor(t[n], o);
+    if constexpr (WAVE_ROWS) {
+      const int lane = threadIdx.x & 63;
+      for (uint64_t m = __ballot(is_long && gl == 0); m; m &= m - 1) {
+        const int src = __builtin_ctzll(m);
+        const int64_t r2 = l12_readlane64(r, src), b2 = l12_readlane64(beg, src), e2 = l12_readlane64(end, src);
+        const int64_t xoff2 = (r2 / a.N) * (int64_t)a.N;
+        float tw[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) tw[n] = 0.f;
+        for (int64_t p = b2 + lane; p < e2; p += NB * 64) {
+          int c[NB];
+          float v[NB];
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {                    // clamped, unconditional loads; masked by a zero value
+            const int64_t q = p + u * 64;
+            const int64_t qc = q < e2 ? q : e2 - 1;
+            c[u] = a.col[qc];
+            v[u] = q < e2 ? a.val[qc] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            const float2* gz = reinterpret_cast<const float2*>(a.dZ + (xoff2 + c[u]) * NT);
+            const float2* pz = reinterpret_cast<const float2*>((ACT2 ? a.pre2 : a.dZ) + (xoff2 + c[u]) * NT);
+#pragma unroll
+            for (int i = 0; i < NT / 2; ++i) {
+              float2 q = gz[i];
+              if constexpr (ACT2) {
+                const float2 w = pz[i];
+                q.x *= dact2(w.x);
+                q.y *= dact2(w.y);
+              }
+              tw[2 * i] = fmaf(v[u], q.x, tw[2 * i]);
+              tw[2 * i + 1] = fmaf(v[u], q.y, tw[2 * i + 1]);
+            }
+          }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) tw[n] += __shfl_xor(tw[n], o);
+        if (lane / G == src / G) {                          // the row's own group goes on with the sum
+#pragma unroll
+          for (int n = 0; n < NT; ++n) t[n] = tw[n];
+        }
+      }
+      if (!live) continue;
+    }
     // dY = t·W2ᵀ (input index ascending, as the transposed-weight form of spmm_gemm_small), P = H·W1, dP = dY ⊙ act1'(P)
     const float2 hv = *reinterpret_cast<const float2*>(a.H + r * KI);
     const float h[KI] = {hv.x, hv.y};
@@ -608,11 +709,7 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
       }
       __syncthreads();
       const int lo = my_lo > tile ? my_lo : tile, hi = my_hi < tile + kEmTile ? my_hi : tile + kEmTile;
-      for (int e = lo; e < hi; ++e) {
-        const float w = park[0][e - tile];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) ts[n] = fmaf(w, park[1 + n][e - tile], ts[n]);
-      }
+      em_row_sum<NT>(park, tile, lo, hi, ts);
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < PER; ++u) c[u] = c_next[u], v[u] = v_next[u];
@@ -824,8 +921,11 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
     a.chunks = l12_chunks(n_rows / N, N);
     a.chunk_rows = (N + a.chunks - 1) / a.chunks;
     l12_launch<true, true>(a, F, Nf, G, (unsigned)(n_rows / N * a.chunks), (size_t)N * Nf * 4 + (a.chunk_rows + 1) * 8, st);
-  } else if (G == 1 && N >= 256 && F <= 6 && Nf <= 6) {
-    // entry-major (l12_bwd_em_kernel).  Captured steps, kernel durations under rocprofv3: the synthetic Bitcoin-OTC shape
+  } else if ((G == 1 || row_blocks) && N >= 256 && F <= 6 && Nf <= 6) {
+    // entry-major (l12_bwd_em_kernel): sparse rows (one lane per row otherwise), and whenever the caller brings a partition of
+    // the rows — it does for SKEWED adjacencies (ops.layer12: hub rows; the Reddit-LP shape with Zipf sources, 11.8 entries per
+    // row and hubs of 3 800: 45.8 us against 80.1 for the lanes-per-row kernel; uniform rows of 8 / 16 / 40 entries: 38 / 53 /
+    // 132 against 30 / 62 / 106 — no partition is passed there).  Captured steps, kernel durations under rocprofv3: the synthetic Bitcoin-OTC shape
     // 31.1 -> 27.9 us; the chess data 60 -> 62 (no gain there: 512 / 1 024 / 1 536 / 4 096 blocks 79.8 / 65.7 / 58.8 / 59.5)
     // Grid: persistent blocks (all resident, each walking its row blocks one after the other) while a row block is less than
     // a tile of entries; one block per row block when row blocks hold a tile or more on average — with real skew some hold

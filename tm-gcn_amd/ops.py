@@ -115,7 +115,7 @@ class HeadLossPlan:
     tensor; nn.CrossEntropyLoss device-asserts on it).  `sync` is the launch's hand-off word: zero
     between launches, so launches that share a plan must not overlap (one training loop does not)."""
 
-    SPLIT = 256          # entries per part of a split row (see __init__)
+    SPLIT = 0            # entries per part of a split row; 0 = from the lanes per row (see __init__)
 
     def __init__(self, edges: "EdgeIndex", R: int, target: torch.Tensor, C: int, ignore_index: int = -100):
         if edges.index_dtype != torch.int32 or R >= 2 ** 31 - 1:
@@ -139,19 +139,31 @@ class HeadLossPlan:
         self.meta = (t8[e] | (role.long() << 7)).to(torch.uint8).contiguous()
         active = torch.nonzero(self.eptr[1:] > self.eptr[:-1]).flatten()            # rows with at least one entry
         beg, end = self.eptr[:-1][active].long(), self.eptr[1:][active].long()
-        # Hubs of the labelled edges: a group of at most 16 lanes walks a row's entries, so one node incident to 20 000 of them
+        # Hubs of the labelled edges: a group of G <= 16 lanes walks a row's entries, so one node incident to 20 000 of them
         # (real interaction graphs; the negatives of link prediction multiply them by 20) costs the launch 1.5 ms where the
-        # uniform case takes 0.1.  Rows of more than SPLIT entries are cut into parts of SPLIT (include/tmgcn.h: every sum
-        # of the kernel is linear in the entries; dZ shares are added up by tmgcn_head_loss_combine_f32).
-        n_part = torch.clamp((end - beg + self.SPLIT - 1) // self.SPLIT, min=1)
+        # uniform case takes 0.1 — and in the sparse regime (G = 1) already a row of 600 costs 0.19 ms instead of 0.045.  Rows
+        # that would take their group more than about eight trips are cut into parts of that size (include/tmgcn.h: every
+        # sum of the kernel is linear in the entries; dZ shares are added up by tmgcn_head_loss_combine_f32).  The part size
+        # follows the lanes the launcher will use (tmgcn_head_loss_lanes), which depend on the number of arow entries:
+        # settled in at most two rounds (more parts can only lower the lane count).
+        lanes = _lib.load().tmgcn_head_loss_lanes
         self.srow, self.n_parts = None, 0
+        n_arow = int(active.numel())
+        for _ in range(3):
+            G = int(lanes(edges.E, max(1, n_arow)))
+            split = self.SPLIT if self.SPLIT else 8 * (2 if G == 1 else 8) * G          # 16 / 256 / 1 024 entries
+            n_part = torch.clamp((end - beg + split - 1) // split, min=1)
+            n_new = int(n_part.sum()) if active.numel() else 0
+            if n_new == n_arow or int(lanes(edges.E, max(1, n_new))) == G:
+                break
+            n_arow = n_new
         if active.numel() and int(n_part.max()) > 1:
             own = torch.repeat_interleave(torch.arange(active.numel(), device=dev), n_part)     # arow entry -> active row
             k = torch.arange(own.numel(), device=dev) - (torch.cumsum(n_part, 0) - n_part)[own]    # part index inside its row
             is_split = n_part[own] > 1
             pid = torch.cumsum(is_split.long(), 0) * is_split                                    # 1, 2, … over all split rows' parts
-            pbeg = beg[own] + k * self.SPLIT
-            pend = torch.minimum(pbeg + self.SPLIT, end[own])
+            pbeg = beg[own] + k * split
+            pend = torch.minimum(pbeg + split, end[own])
             self.arow = torch.stack((active[own], pbeg, pend, pid), dim=1).to(torch.int32).contiguous()
             sp = n_part > 1
             first = (torch.cumsum(n_part * sp, 0) - n_part * sp)[sp]                             # first part - 1 of every split row
@@ -563,7 +575,15 @@ def layer12(H: torch.Tensor, W1: torch.Tensor, act1, A: BatchedCSR, W2: torch.Te
     need = torch.is_grad_enabled() and W1.requires_grad
     # row blocks cut by entries where 256-row blocks would hold several tiles (real, skewed data): csr.BatchedCSR.row_blocks
     blk = A.row_blocks() if (A.N >= 256 and L12_ROW_BLOCKS) else None
-    t_blk = A.transpose().row_blocks() if (need and A.N >= 256 and L12_ROW_BLOCKS) else None
+    t_blk = None
+    if need and A.N >= 256 and L12_ROW_BLOCKS:
+        # the backward takes its entry-major kernel whenever it is handed a partition (include/tmgcn.h): sparse rows take that
+        # kernel anyway, skewed ones (hub rows) are 1.7x faster on it, evenly filled denser ones are not — no partition there
+        At = A.transpose()
+        if At.avg_nnz_per_row < 4 or At.is_skewed():
+            t_blk = At.row_blocks()
+            if t_blk is None and At.avg_nnz_per_row >= 4:          # skewed, but no 256-row block over the limit: the trivial partition
+                t_blk = torch.arange(0, At.n_rows + 256, 256, device=At.device, dtype=torch.int64).clamp_(max=At.n_rows)
     return kernels.ops.layer12(H, W1.contiguous(), W2.contiguous(), A.rowptr, A.col, A.val, *_csr_t(A, need), A.N, A.avg_nnz_per_row,
                                _lib.ACT_IDS[act1], _lib.ACT_IDS[act2], blk, t_blk)
 

@@ -207,6 +207,11 @@ CONFIGS = {
     "S1": dict(T=95, N=6000, edges_per_slice=250),                        # Bitcoin-OTC-shaped
     "S2": dict(T=65, N=3800, edges_per_slice=2500, neg_per_pos=19),       # Reddit-LP-shaped
     "S3": dict(T=150, N=1000, edges_per_slice=500),                       # AMLSim-shaped
+    # the Reddit-LP shape with HUB source nodes (one node is the source of a third of every slice's edges): skewed rows in Â
+    # (up to ~3 800 entries, mean 12) and in the inverted index of the labelled edges — not a BASELINE config; parity:
+    # tests/test_gpu_configs.py::test_S2_shape_with_hub_nodes, epoch times: tools/epoch_bench.py S2z S2z2
+    "S2z": dict(T=65, N=3800, edges_per_slice=1500, neg_per_pos=4, zipf=1.5),
+    "S2z2": dict(T=65, N=3800, edges_per_slice=1500, neg_per_pos=4, zipf=1.5),
     # the two model-level probes of BASELINE.md §2 (uniform random graphs, wide features)
     "P128": dict(T=32, N=20000, edges_per_slice=16000, window=1, F0=128), # F = 128 -> 128 -> 128
 }
