@@ -246,15 +246,18 @@ int tmgcn_gemm_dw_act_f32(const float* A, const float* dY, const float* pre_act,
  * (tmgcn_layer12_supported).  Against tmgcn_gemm_f32 + tmgcn_spmm_gemm_f32: another fp32 summation order per row (<= 1e-6).
  * AX (optional) receives Â ⋆ act1(H·W1) for dW2 = AXᵀ·dZ' (tmgcn_gemm_dw_f32); pre2 the pre-activation of layer 2
  * when act2 is not none.  The backward takes the TRANSPOSED batched CSR.
- * row_blocks / n_row_blocks (optional, both 0 = blocks of 256 consecutive rows): a partition of the rows for the
- *   entry-major kernels — n_row_blocks + 1 ascending first-row indices from 0 to n_rows, at most 256 rows per block
- *   (N >= 256: a block then holds at most one slice boundary).  A caller that knows its row lengths cuts the blocks so
- *   that none holds more than about two 1 024-entry tiles (csr.BatchedCSR.row_blocks): with real, skewed data the
- *   longest block otherwise sets the launch time.  The BACKWARD takes its entry-major kernel whenever a partition is given
- *   (otherwise only for fewer than 4 entries per row): a caller passes one for skewed adjacencies — hub rows — and none for
- *   evenly filled ones, where lanes-per-row is the faster walk above 4 entries per row.  The forward's and the backward's partitions are independent (the
- *   backward's is over the TRANSPOSED rows); results do not depend on the partition in the forward (whole rows) and
- *   are bit-reproducible for a given partition in the backward (dW1 is summed per block, blocks in order). */
+ * row_blocks / n_row_blocks (optional, both 0 = blocks of 256 consecutive rows, ascending): a partition of the rows for
+ *   the entry-major kernels — n_row_blocks pairs (first row, number of rows <= 256) of int64 that together cover every row
+ *   exactly once (N >= 256: a block then holds at most one slice boundary), IN THE ORDER THEY ARE TO BE STARTED.  A caller
+ *   that knows its row lengths cuts the blocks so that none holds more than about one 1 024-entry tile and lists the heaviest
+ *   first (csr.BatchedCSR.row_blocks): with real, skewed data the longest block otherwise sets the launch time, and heavy
+ *   blocks started last leave the chip idle behind them.  The BACKWARD takes its entry-major kernel whenever a partition is
+ *   given (otherwise only for fewer than 4 entries per row): a caller passes one for skewed adjacencies — hub rows — and none
+ *   for evenly filled ones, where lanes-per-row is the faster walk above 4 entries per row.  The forward's and the
+ *   backward's partitions are independent (the backward's is over the TRANSPOSED rows); results do not depend on the
+ *   partition in the forward (whole rows) and are bit-reproducible for a given partition in the backward (dW1 is summed per
+ *   row block, the row blocks' sums in a fixed order — whichever thread block worked on which).
+ * tmgcn_layer12_bwd_workspace_bytes: for the call's n_rows and n_row_blocks (0 without a partition). */
 int tmgcn_layer12_supported(int32_t K0, int32_t F, int32_t Nf);
 int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* H,
                           const float* W1, int32_t act1, const float* W2, int32_t act2, int64_t n_rows,
@@ -264,7 +267,7 @@ int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, const float
  * slices whose layer-1 output is formed once per node in LDS; short rows); 0: form act1(H·W1) with tmgcn_gemm_f32 and call
  * tmgcn_spmm_gemm_f32 (same Z up to fp32 summation order). */
 int tmgcn_layer12_fwd_pays(int64_t n_rows, int32_t N, int32_t F, float avg_nnz_per_row);
-int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F);
+int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F, int64_t n_rows, int32_t n_row_blocks);
 int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const float* dZ,
                           const float* pre2, const float* H, const float* W1, int32_t act1, const float* W2,
                           int32_t act2, int64_t n_rows, int32_t N, int32_t K0, int32_t F, int32_t Nf,

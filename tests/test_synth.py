@@ -45,10 +45,10 @@ def test_powerlaw_csr_is_seeded_per_slice_sorted_and_row_normalised():
 
 
 def test_row_blocks_partition_by_entries():
-    """csr.BatchedCSR.row_blocks (the partition the entry-major layer kernels take): ascending from 0 to R, at most 256 rows
+    """csr.BatchedCSR.row_blocks (the partition the entry-major layer kernels take): (first row, rows) pairs that tile the rows, heaviest block first, at most 256 rows
     and at most max_entries + the longest row of entries per block, cut at row boundaries; None when nothing needs cutting."""
     from tmgcn_amd.csr import BatchedCSR
-    assert synth.device_er_csr(2, 1000, 3, "cpu").row_blocks() is None          # 4 per row: 1 024 entries per 256 rows
+    assert synth.device_er_csr(2, 1000, 2, "cpu").row_blocks() is None          # 3 per row: 768 entries per 256 rows
     g = torch.Generator().manual_seed(0)
     T, N = 3, 1300
     cnt = torch.randint(0, 4, (T * N,), generator=g)
@@ -59,13 +59,20 @@ def test_row_blocks_partition_by_entries():
     torch.cumsum(cnt, 0, out=rowptr[1:])
     nnz = int(rowptr[-1])
     A = BatchedCSR(rowptr, torch.randint(0, N, (nnz,), generator=g, dtype=torch.int32), torch.rand(nnz, generator=g), T, N)
-    blk = A.row_blocks()
-    assert blk is A.row_blocks() and blk.dtype == torch.int64
+    pairs = A.row_blocks()
+    assert pairs is A.row_blocks() and pairs.dtype == torch.int64 and pairs.shape[1] == 2
+    ent_listed = rowptr[pairs[:, 0] + pairs[:, 1]] - rowptr[pairs[:, 0]]
+    assert bool((ent_listed[1:] <= ent_listed[:-1]).all())                    # the heaviest blocks first
+    order = torch.argsort(pairs[:, 0])
+    blk = torch.cat((pairs[order, 0], torch.tensor([T * N])))
+    assert bool((pairs[order, 0] + pairs[order, 1] == blk[1:]).all())         # the blocks tile the rows: each row exactly once
     assert int(blk[0]) == 0 and int(blk[-1]) == T * N and bool((blk[1:] > blk[:-1]).all())
     rows = blk[1:] - blk[:-1]
     ent = rowptr[blk[1:]] - rowptr[blk[:-1]]
-    assert int(rows.max()) <= 256 and int(ent.max()) <= 2048 + int(cnt.max())
-    assert int((ent > 2048).sum()) == 1                                       # only the block of the 5 000-entry row
+    assert int(rows.max()) <= 256 and int(ent.max()) <= 1024 + int(cnt.max())
+    assert int((ent > 1024).sum()) == 1                                       # only the block of the 5 000-entry row
     assert blk.numel() - 1 > (T * N + 255) // 256                             # the dense region was cut further
     # every multiple of 256 rows is still a boundary (blocks are only ever cut, never merged)
     assert set(range(0, T * N, 256)) <= set(blk.tolist())
+    tri = A.trivial_row_blocks()
+    assert tri.shape == ((T * N + 255) // 256, 2) and int(tri[:, 1].sum()) == T * N and int(tri[:, 1].max()) == 256

@@ -189,12 +189,14 @@ class BatchedCSR:
         m = self.max_row_length()
         return m > 64 and m > 8 * self.avg_nnz_per_row
 
-    def row_blocks(self, max_rows: int = 256, max_entries: int = 2048) -> Optional[torch.Tensor]:
+    def row_blocks(self, max_rows: int = 256, max_entries: int = 1024) -> Optional[torch.Tensor]:
         """Partition of the rows for the entry-major layer kernels (tmgcn_layer12_fwd/bwd_f32's `row_blocks`), cached:
         blocks of `max_rows` consecutive rows, and every such block that holds more than `max_entries` stored entries
         cut further — at row boundaries, into ceil(entries / max_entries) parts of about equal entry counts — so that
-        no block holds more than max_entries + its longest row.  int64 [n_blocks + 1] first-row indices on the
-        adjacency's device; None when no block needs cutting (balanced data: the kernels' own 256-row blocks)."""
+        no block holds more than max_entries + its longest row.  int64 [n_blocks, 2] pairs (first row, rows) on the
+        adjacency's device, the blocks with the most entries FIRST (the kernels start them in this order: heavy blocks
+        started last would leave the chip idle behind them; equal blocks keep their ascending order); None when no block
+        needs cutting (balanced data: the kernels' own 256-row blocks)."""
         key = (int(max_rows), int(max_entries))
         if key not in self._blocks:
             R, dev = self.n_rows, self.device
@@ -213,7 +215,22 @@ class BatchedCSR:
                 cut = torch.minimum(torch.maximum(cut, starts[owner]), ends[owner])
                 cut = torch.where(i == 0, starts[owner], cut)
                 blk = torch.unique(torch.cat([cut, torch.tensor([R], device=dev, dtype=torch.int64)]))   # sorted; empty parts vanish
-                self._blocks[key] = blk.contiguous()
+                self._blocks[key] = self._heaviest_first(blk)
+        return self._blocks[key]
+
+    def _heaviest_first(self, bounds: torch.Tensor) -> torch.Tensor:
+        """Ascending block boundaries [n + 1] -> the (first row, rows) pairs [n, 2], most entries first (stable)."""
+        first, rows = bounds[:-1], bounds[1:] - bounds[:-1]
+        entries = self.rowptr[bounds[1:]] - self.rowptr[first]
+        order = torch.sort(entries, descending=True, stable=True).indices
+        return torch.stack((first[order], rows[order]), dim=1).contiguous()
+
+    def trivial_row_blocks(self, max_rows: int = 256) -> torch.Tensor:
+        """The kernels' own blocks of `max_rows` consecutive rows as an explicit partition (heaviest first)."""
+        key = ("trivial", int(max_rows))
+        if key not in self._blocks:
+            b = torch.arange(0, self.n_rows + max_rows, max_rows, device=self.device, dtype=torch.int64).clamp_(max=self.n_rows)
+            self._blocks[key] = self._heaviest_first(torch.unique(b))
         return self._blocks[key]
 
     GIANT_ROW, GIANT_CHUNK = 32768, 4096          # include/tmgcn.h: TMGCN_GIANT_ROW, TMGCN_GIANT_CHUNK

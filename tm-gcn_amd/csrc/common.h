@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 #include "tmgcn.h"
 
 namespace tmgcn {
@@ -99,7 +100,7 @@ inline int device_cu_count(int dev) {
 }
 
 template <typename K>
-inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0) {
+inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0, int max_per_cu = 4) {
   // K is the function-pointer TYPE, which every kernel with the same argument list shares, so the
   // cache is a small per-thread table keyed on (kernel address, device, block size): alternating
   // between instantiations (fp32 / bf16 weights, layers of different widths) hits it every time.
@@ -120,7 +121,7 @@ inline int persistent_grid(K kernel, int block_threads, size_t dyn_smem = 0) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dyn_smem) != hipSuccess ||
       per_cu < 1)
     per_cu = 1;
-  if (per_cu > 4) per_cu = 4;
+  if (per_cu > max_per_cu) per_cu = max_per_cu;
   (void)hipGetLastError();
   if (dyn_smem == 0) {
     table[next] = Entry{key, dev, block_threads, per_cu};
@@ -174,6 +175,44 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], int j) {
   }
 }
 
+// Σ over the 64 lanes of a wave, the same value in every lane, without the LDS crossbar: four DPP steps inside each row of
+// 16 lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then the four rows' sums read as scalars and added
+// in row order.  A fixed order (reproducible); 11 VALU operations where a __shfl_xor butterfly is six ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_lane_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += dpp_lane_f32<0xB1>(v);
+  v += dpp_lane_f32<0x4E>(v);
+  v += dpp_lane_f32<0x141>(v);
+  v += dpp_lane_f32<0x140>(v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return ((r0 + r1) + r2) + r3;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {        // the same steps on the two halves of an fp64
+  auto step = [](double x, auto ctrl) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, decltype(ctrl)::value, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), decltype(ctrl)::value, 0xF, 0xF, true);
+    return x + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+  };
+  v = step(v, std::integral_constant<int, 0xB1>{});
+  v = step(v, std::integral_constant<int, 0x4E>{});
+  v = step(v, std::integral_constant<int, 0x141>{});
+  v = step(v, std::integral_constant<int, 0x140>{});
+  auto lane = [&](int l) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+  };
+  return ((lane(0) + lane(16)) + lane(32)) + lane(48);
+}
+
 // A thread's share of the last block's slab reduction: Σ slab[c][o] over the slabs c = first, first + stride, … below n,
 // read with sc1 loads (see last_block_ticket), DEPTH of them in flight — issued together and masked, not branched, past
 // the end — and added in slab order (reproducible).  The loads come from memory, about a microsecond a round trip: with
@@ -206,13 +245,20 @@ __device__ __forceinline__ double slab_sum_f32(const unsigned* slabs, int n, int
 // were capped at 1 024 blocks), all sums in a fixed order.  Called by every thread of every block after the block's own
 // slab (NO floats, write-through) is stored at part[blockIdx.x]; `part` holds n_blocks + kSyncGroups slabs.  True in the
 // one block that ends up with the totals, in total[0 .. NO) (LDS); that block has also reset the launch's counters.
+// `n_slabs` (default: one per block) — the slabs may also belong to units of work the blocks of a group share (slab s to
+// group s mod 16: the entry-major layer backward stores one per ROW BLOCK, whichever block of the group worked on it).
+// slab_tree_finish_in: the same with the caller's LDS for the partial sums (`fin`: 256 / NO · NO doubles — a kernel whose
+// tile buffers are free by then stays under the LDS of one more resident block).
 template <int NO>
-__device__ __forceinline__ bool slab_tree_finish(unsigned* part, int n_blocks, int32_t* sync, double* total /* LDS [NO] */) {
+__device__ __forceinline__ bool slab_tree_finish_in(unsigned* part, int n_blocks, int32_t* sync, double* total /* LDS [NO] */, int n_slabs,
+                                                    double* fin) {
   constexpr int SUBS = 256 / NO;
-  __shared__ double tree_fin[SUBS][NO];
+  double (*tree_fin)[NO] = reinterpret_cast<double (*)[NO]>(fin);
   __shared__ int tree_flag;
+  if (n_slabs < 0) n_slabs = n_blocks;
   const int g = blockIdx.x % kSyncGroups;
   const int members = (n_blocks - g + kSyncGroups - 1) / kSyncGroups;
+  const int slabs = (n_slabs - g + kSyncGroups - 1) / kSyncGroups;          // of this group
   const int groups = n_blocks < kSyncGroups ? n_blocks : kSyncGroups;
   int32_t* mine = sync + (1 + g) * kSyncStride;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -226,13 +272,13 @@ __device__ __forceinline__ bool slab_tree_finish(unsigned* part, int n_blocks, i
   if (!tree_flag) return false;
   // the group's slabs g, g + 16, …: SUBS threads per output, then the SUBS partial sums in order
   const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
-  if (sub < SUBS) tree_fin[sub][o] = slab_sum_f32<8>(part + (int64_t)g * NO, members, sub, SUBS, NO * kSyncGroups, o);
+  if (sub < SUBS) tree_fin[sub][o] = slab_sum_f32<8>(part + (int64_t)g * NO, slabs, sub, SUBS, NO * kSyncGroups, o);
   __syncthreads();
   if (threadIdx.x < NO) {
     double t = 0.0;
 #pragma unroll
     for (int q = 0; q < SUBS; ++q) t += tree_fin[q][threadIdx.x];
-    __hip_atomic_store(part + (int64_t)(n_blocks + g) * NO + threadIdx.x, __float_as_uint((float)t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + (int64_t)(n_slabs + g) * NO + threadIdx.x, __float_as_uint((float)t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -240,9 +286,15 @@ __device__ __forceinline__ bool slab_tree_finish(unsigned* part, int n_blocks, i
   __syncthreads();
   if (!tree_flag) return false;
   if (threadIdx.x == 0) __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (threadIdx.x < NO) total[threadIdx.x] = slab_sum_f32<kSyncGroups>(part + (int64_t)n_blocks * NO, groups, 0, 1, NO, threadIdx.x);
+  if (threadIdx.x < NO) total[threadIdx.x] = slab_sum_f32<kSyncGroups>(part + (int64_t)n_slabs * NO, groups, 0, 1, NO, threadIdx.x);
   __syncthreads();
   return true;
+}
+
+template <int NO>
+__device__ __forceinline__ bool slab_tree_finish(unsigned* part, int n_blocks, int32_t* sync, double* total /* LDS [NO] */, int n_slabs = -1) {
+  __shared__ double tree_fin_own[256 / NO][NO];
+  return slab_tree_finish_in<NO>(part, n_blocks, sync, total, n_slabs, &tree_fin_own[0][0]);
 }
 
 // The same tree for slabs of fp64 bit patterns (8-byte write-through stores / loads): the head + loss kernel.

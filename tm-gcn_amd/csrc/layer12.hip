@@ -70,6 +70,15 @@ __device__ __forceinline__ T pick_at(const T (&v)[N], int i) {
 // NB consecutive non-zeros starting at `base`, as unaligned 16-byte loads (four column indices / four values each) while they
 // lie inside the arrays, element loads clamped to the last entry otherwise (the tail of the last rows only).  Every load
 // is unconditional and every column index returned is a valid one: the caller skips the positions past its row's end.
+// Development build only (-DTMGCN_L12_TRACE, tools/l12_trace.py): thread 0 of every block leaves 100 MHz wall-clock stamps of
+// the entry-major backward's phases in a device array, read back through tmgcn_debug_l12_trace.  Not part of the library.
+#ifdef TMGCN_L12_TRACE
+__device__ unsigned long long l12_trace_words[8192 * 16];
+#define L12_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && (i) < 16) l12_trace_words[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define L12_STAMP(i) do { } while (0)
+#endif
+
 struct __attribute__((packed, aligned(4))) Int4u { int32_t v[4]; };
 struct __attribute__((packed, aligned(4))) Float4u { float v[4]; };
 
@@ -261,7 +270,20 @@ __global__ __launch_bounds__(256) void l12_fwd_kernel(L12Args a) {
 #define TMGCN_L12_LONG_TRIPS 8     // trips of a row's G lanes beyond which the whole wave gathers it (l12_bwd_kernel; 16: S2z2 backward 90 us)
 #endif
 constexpr int kEmTile = 1024;      // 512: chess 56.6 us, 2 048: the synthetic shape 26.7 (two blocks per CU)
-constexpr int kEmLong = 64;        // entries of one row inside a tile beyond which the row's WAVE sums them (below)
+#ifndef TMGCN_L12_EM_LONG
+#define TMGCN_L12_EM_LONG 64
+#endif
+#ifndef TMGCN_L12_EM_UNROLL
+#define TMGCN_L12_EM_UNROLL 4
+#endif
+constexpr int kEmLong = TMGCN_L12_EM_LONG;      // entries of one row inside a tile beyond which the row's WAVE sums them (below)
+constexpr int kEmUnroll = TMGCN_L12_EM_UNROLL;
+
+// Which row of its block thread t owns (sums from LDS, finishes).  A full block: row t.  A block the caller's partition cut
+// short — few rows holding a tile or two of entries, so long ones — deals its rows over the four waves (row 4·lane + wave): the
+// row sums of such a block otherwise all fall to wave 0 while three waves wait (tools/l12_trace.py, chess: the backward's
+// heaviest row blocks spent 10 of their 20 us there).
+__device__ __forceinline__ int em_row_of_thread(int t, int rows) { return rows > 192 ? t : ((t & 63) << 2) + (t >> 6); }
 
 // Thread t adds the entries [lo, hi) of ITS row that lie in the tile parked in LDS (value in plane 0, the W planes behind
 // it), in entry order.  A segment of more than kEmLong entries — a hub row: one lane walking 1 024 entries is 50 us per tile
@@ -271,7 +293,23 @@ template <int W>
 __device__ __forceinline__ void em_row_sum(const float (&park)[1 + W][kEmTile], int tile, int lo, int hi, float (&acc)[W]) {
   const bool seg_long = hi - lo > kEmLong;
   if (!seg_long) {
-    for (int e = lo; e < hi; ++e) {
+    // kEmUnroll entries' LDS reads in flight at a time (a lane walking its row one entry per LDS round trip is what the
+    // densest row of a wave costs: tools/l12_trace.py, chess — 10 us of a heavy row block's 20); the fmaf chain keeps its order
+    int e = lo;
+    for (; e + kEmUnroll <= hi; e += kEmUnroll) {
+      float w[kEmUnroll], x[kEmUnroll][W];
+#pragma unroll
+      for (int u = 0; u < kEmUnroll; ++u) {
+        w[u] = park[0][e + u - tile];
+#pragma unroll
+        for (int f = 0; f < W; ++f) x[u][f] = park[1 + f][e + u - tile];
+      }
+#pragma unroll
+      for (int u = 0; u < kEmUnroll; ++u)
+#pragma unroll
+        for (int f = 0; f < W; ++f) acc[f] = fmaf(w[u], x[u][f], acc[f]);
+    }
+    for (; e < hi; ++e) {
       const float w = park[0][e - tile];
 #pragma unroll
       for (int f = 0; f < W; ++f) acc[f] = fmaf(w, park[1 + f][e - tile], acc[f]);
@@ -290,9 +328,7 @@ __device__ __forceinline__ void em_row_sum(const float (&park)[1 + W][kEmTile], 
       for (int f = 0; f < W; ++f) part[f] = fmaf(w, park[1 + f][e - tile], part[f]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-      for (int f = 0; f < W; ++f) part[f] += __shfl_xor(part[f], o);
+    for (int f = 0; f < W; ++f) part[f] = wave_sum_f32(part[f]);
     if (lane == src) {
 #pragma unroll
       for (int f = 0; f < W; ++f) acc[f] += part[f];
@@ -317,10 +353,11 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
   const ActApply act1(a.act1), act2(a.act2);
   const int t = threadIdx.x;
   // the block's rows: 256 consecutive ones, or — with a partition (tmgcn_layer12_fwd_f32's row_blocks: row blocks cut so
-  // that none holds more than about two tiles of entries) — rows [blk[b], blk[b+1])
-  const int64_t first = a.blk ? a.blk[blockIdx.x] : (int64_t)blockIdx.x * 256;
-  const int64_t r = first + t;
-  const int rows = a.blk ? (int)(a.blk[blockIdx.x + 1] - first) : (a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256);
+  // that none holds more than about a tile of entries, the heaviest first) — blk[2b + 1] rows from row blk[2b]
+  const int64_t first = a.blk ? a.blk[2 * (int64_t)blockIdx.x] : (int64_t)blockIdx.x * 256;
+  const int rows = a.blk ? (int)a.blk[2 * (int64_t)blockIdx.x + 1] : (a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256);
+  const int rt = em_row_of_thread(t, rows);         // the row of the block this thread sums and finishes
+  const int64_t r = first + rt;
   {
     const int64_t q = first + (t < rows ? t : rows);
     rp[t] = a.rowptr[q];
@@ -334,7 +371,7 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
   const int64_t next_first = (slice0 + 1) * a.N;                                  // first row of the next slice
   const int split = next_first - first < rows ? (int)(rp[next_first - first] - base) : n_ent;
   const int64_t xoff0 = slice0 * a.N;
-  const int my_lo = (int)(rp[t < rows ? t : rows] - base), my_hi = (int)(rp[t < rows ? t + 1 : rows] - base);
+  const int my_lo = (int)(rp[rt < rows ? rt : rows] - base), my_hi = (int)(rp[rt < rows ? rt + 1 : rows] - base);
   float acc[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.f;
@@ -379,7 +416,7 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) c[u] = c_next[u], v[u] = v_next[u];
   }
-  if (t >= rows) return;
+  if (rt >= rows) return;
   if (a.AX) {
 #pragma unroll
     for (int f = 0; f < F; ++f) a.AX[r * F + f] = acc[f];
@@ -638,27 +675,40 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
     for (int n = 0; n < NT; ++n) W2[f][n] = a.W2[f * NT + n];
   const ActGrad dact1(a.act1), dact2(a.act2);
   const int t = threadIdx.x;
-  double acc[NO];
-#pragma unroll
-  for (int j = 0; j < NO; ++j) acc[j] = 0.0;
   constexpr int PER = kEmTile / 256;
   const int64_t n_row_blocks = a.blk ? a.n_blk : (a.n_rows + 255) / 256;
-  for (int64_t rb = blockIdx.x; rb < n_row_blocks; rb += gridDim.x) {
-    const int64_t first = a.blk ? a.blk[rb] : rb * 256;
-    const int64_t r = first + t;
-    const int rows = a.blk ? (int)(a.blk[rb + 1] - first) : (a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256);
-    __syncthreads();                                  // the previous row block's readers of rp are done
-    rp[t] = a.rowptr[first + (t < rows ? t : rows)];
+  __shared__ double red[4][NO];
+  L12_STAMP(0);
+  [[maybe_unused]] int trace_it = 0;
+  // Row blocks are DRAWN, not dealt: the blocks of hand-off group g (blockIdx ≡ g mod 16, common.h) share the row blocks
+  // rb ≡ g mod 16 — a block's first one by its place in the group, every further one from the group's counter (an int of the
+  // launch's hand-off block: sixteen addresses, agent-scope atomics on one are served one at a time), drawn while the
+  // current row block is being worked on.  A block that waits on a heavy row block no longer holds others back, and the
+  // ticket tail (4.6 us of latency, tools/l12_trace.py) is paid once per resident block instead of once per row block.
+  // The dW1 partial sums are kept per ROW BLOCK (slab rb: the rows' H[r]ᵀ·dP[r] folded over the block in a fixed order), not
+  // per executing block: which block draws which row block varies from run to run, the slabs and the order they are added
+  // in (slab_tree_finish: group g adds the slabs ≡ g mod 16, then the sixteen group sums) do not — bit-reproducible.
+  __shared__ int64_t s_next;
+  const int grp = blockIdx.x % kSyncGroups;
+  const int64_t grp_members = ((int64_t)gridDim.x - grp + kSyncGroups - 1) / kSyncGroups;
+  int* draw = a.sync + (1 + grp) * kSyncStride + 8;
+  for (int64_t rb = blockIdx.x; rb < n_row_blocks;) {
+    const int64_t first = a.blk ? a.blk[2 * rb] : rb * 256;
+    const int rows = a.blk ? (int)a.blk[2 * rb + 1] : (a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256);
+    const int rt = em_row_of_thread(t, rows);
+    const int64_t r = first + rt;
+    rp[t] = a.rowptr[first + (t < rows ? t : rows)];   // (the previous row block's readers of rp are done: the barrier at the loop's end)
     if (t == 0) rp[256] = a.rowptr[first + rows];
-    const float2 hv = *reinterpret_cast<const float2*>(a.H + (t < rows ? r : first) * KI);   // this row's H, early
+    const float2 hv = *reinterpret_cast<const float2*>(a.H + (rt < rows ? r : first) * KI);   // this row's H, early
     __syncthreads();
+    if (trace_it < 3) L12_STAMP(1 + 4 * trace_it);
     const int64_t base = rp[0];
     const int n_ent = (int)(rp[rows] - base);
     const int64_t slice0 = first / a.N;
     const int64_t next_first = (slice0 + 1) * a.N;
     const int split = next_first - first < rows ? (int)(rp[next_first - first] - base) : n_ent;
     const int64_t xoff0 = slice0 * a.N;
-    const int my_lo = (int)(rp[t < rows ? t : rows] - base), my_hi = (int)(rp[t < rows ? t + 1 : rows] - base);
+    const int my_lo = (int)(rp[rt < rows ? rt : rows] - base), my_hi = (int)(rp[rt < rows ? rt + 1 : rows] - base);
     float ts[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) ts[n] = 0.f;
@@ -674,6 +724,12 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
       }
     };
     if (n_ent > 0) load_cv(0, c, v);
+    int drawn = 0;
+    if (t == 0) drawn = __hip_atomic_fetch_add(draw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // behind the (col, val) loads: back with the gathers
+#ifdef TMGCN_L12_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (trace_it < 3) L12_STAMP(2 + 4 * trace_it);
+#endif
     for (int tile = 0; tile < n_ent; tile += kEmTile) {
       float g[PER][NT];
 #pragma unroll
@@ -708,15 +764,21 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
         }
       }
       __syncthreads();
+      if (tile == 0 && trace_it < 3) L12_STAMP(3 + 4 * trace_it);
       const int lo = my_lo > tile ? my_lo : tile, hi = my_hi < tile + kEmTile ? my_hi : tile + kEmTile;
       em_row_sum<NT>(park, tile, lo, hi, ts);
       __syncthreads();
 #pragma unroll
       for (int u = 0; u < PER; ++u) c[u] = c_next[u], v[u] = v_next[u];
     }
-    if (t < rows) {
-      // dY = t·W2ᵀ, P = H·W1, dP = dY ⊙ act1'(P): as l12_bwd_kernel
+    if (trace_it < 3) L12_STAMP(4 + 4 * trace_it);
+    ++trace_it;
+    if (t == 0) s_next = grp + kSyncGroups * (grp_members + drawn);
+    {
+      // dY = t·W2ᵀ, P = H·W1, dP = dY ⊙ act1'(P): as l12_bwd_kernel; the row's share of dW1 (zero for a thread without a row)
+      // summed over the wave, the four waves' sums over the block
       const float h[KI] = {hv.x, hv.y};
+      const int lane = t & 63, wave = t >> 6;
 #pragma unroll
       for (int f = 0; f < F; ++f) {
         float sy = 0.f;
@@ -725,13 +787,32 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
         float pf = 0.f;
 #pragma unroll
         for (int k = 0; k < KI; ++k) pf = fmaf(h[k], W1[k][f], pf);
-        const float dP = sy * dact1(pf);
+        const float dP = rt < rows ? sy * dact1(pf) : 0.f;
 #pragma unroll
-        for (int k = 0; k < KI; ++k) acc[k * F + f] = fma((double)h[k], (double)dP, acc[k * F + f]);
+        for (int k = 0; k < KI; ++k) {
+          const double w = wave_sum_f64((double)h[k] * (double)dP);
+          if (lane == 0) red[wave][k * F + f] = w;
+        }
       }
     }
+    __syncthreads();
+    if (t < NO)
+      __hip_atomic_store(reinterpret_cast<unsigned*>(a.part) + rb * NO + t,
+                         __float_as_uint((float)(((red[0][t] + red[1][t]) + red[2][t]) + red[3][t])), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    rb = s_next;
   }
-  l12_bwd_finish<NO, 1>(acc, a);
+  L12_STAMP(13);
+  __shared__ double total[NO];
+  static_assert(sizeof(park) >= sizeof(double) * 256, "the tile planes double as the finisher's partial sums");
+  if (slab_tree_finish_in<NO>(reinterpret_cast<unsigned*>(a.part), (int)gridDim.x, a.sync, total, (int)n_row_blocks,
+                              reinterpret_cast<double*>(&park[0][0]))) {      // (park: every reader passed the loop's last barrier)
+    // (the last block of all: every other block drew its last row block before it took its ticket — the draw counters go
+    // back to zero with the tickets)
+    if (t < kSyncGroups) __hip_atomic_store(a.sync + (1 + t) * kSyncStride + 8, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < NO) a.dW1[t] = (float)total[t];
+  }
+  L12_STAMP(14);
 }
 
 // lanes per row: chains of about four non-zeros per lane, walked NB at a time (kernel durations under rocprofv3, captured
@@ -805,15 +886,21 @@ static void l12_em_launch(const L12Args& a, int F, int NT, unsigned blocks, hipS
   }
 }
 
+// (grid: as many blocks as stay resident — five per CU without a layer-2 activation, 91 VGPRs and 31 KB of LDS; four with)
+template <int F, int NT, bool ACT2>
+static void l12_bwd_em_launch_g(const L12Args& a, int64_t row_blocks, hipStream_t st) {
+  const int64_t resident = persistent_grid(l12_bwd_em_kernel<2, F, NT, ACT2>, 256, 0, 5);
+  hipLaunchKernelGGL((l12_bwd_em_kernel<2, F, NT, ACT2>), dim3((unsigned)(row_blocks < resident ? row_blocks : resident)), dim3(256), 0, st, a);
+}
 template <int F, bool ACT2>
-static void l12_bwd_em_launch_n(const L12Args& a, int NT, unsigned blocks, hipStream_t st) {
+static void l12_bwd_em_launch_n(const L12Args& a, int NT, int64_t row_blocks, hipStream_t st) {
   switch (NT) {
-    case 2: hipLaunchKernelGGL((l12_bwd_em_kernel<2, F, 2, ACT2>), dim3(blocks), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((l12_bwd_em_kernel<2, F, 4, ACT2>), dim3(blocks), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((l12_bwd_em_kernel<2, F, 6, ACT2>), dim3(blocks), dim3(256), 0, st, a);
+    case 2: l12_bwd_em_launch_g<F, 2, ACT2>(a, row_blocks, st); break;
+    case 4: l12_bwd_em_launch_g<F, 4, ACT2>(a, row_blocks, st); break;
+    default: l12_bwd_em_launch_g<F, 6, ACT2>(a, row_blocks, st);
   }
 }
-static void l12_bwd_em_launch(const L12Args& a, int F, int NT, unsigned blocks, hipStream_t st) {
+static void l12_bwd_em_launch(const L12Args& a, int F, int NT, int64_t blocks, hipStream_t st) {
 #define TMGCN_EM_B(F_) (a.pre2 ? l12_bwd_em_launch_n<F_, true>(a, NT, blocks, st) : l12_bwd_em_launch_n<F_, false>(a, NT, blocks, st))
   switch (F) {
     case 2: TMGCN_EM_B(2); break;
@@ -888,8 +975,11 @@ extern "C" int tmgcn_layer12_fwd_pays(int64_t n_rows, int32_t N, int32_t F, floa
   return (N >= 256 || (avg_nnz_per_row >= 0.f && avg_nnz_per_row <= 6.f) || l12_staged(n_rows, N, F, avg_nnz_per_row)) ? 1 : 0;
 }
 
-extern "C" int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F) {
-  return (int64_t)(kL12MaxBlocks + kSyncGroups) * K0 * F * (int64_t)sizeof(float);    // block slabs + group slabs (slab_tree_finish)
+extern "C" int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F, int64_t n_rows, int32_t n_row_blocks) {
+  // slabs of the blocks (lanes-per-row and staged kernels: at most kL12MaxBlocks) or of the row blocks (entry-major) + group slabs
+  int64_t slabs = n_row_blocks > 0 ? n_row_blocks : (n_rows + 255) / 256;
+  if (slabs < kL12MaxBlocks) slabs = kL12MaxBlocks;
+  return (slabs + kSyncGroups) * K0 * F * (int64_t)sizeof(float);
 }
 
 extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const float* dZ,
@@ -906,7 +996,7 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
   TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(H) % 8 == 0 && reinterpret_cast<uintptr_t>(dZ) % 8 == 0 &&
                     (!pre2 || reinterpret_cast<uintptr_t>(pre2) % 8 == 0),
                 "layer12_bwd: H, dZ and pre2 must be 8-byte aligned");
-  if (workspace_bytes < tmgcn_layer12_bwd_workspace_bytes(K0, F)) {
+  if (workspace_bytes < tmgcn_layer12_bwd_workspace_bytes(K0, F, n_rows, n_row_blocks)) {
     set_error("layer12_bwd: workspace too small");
     return TMGCN_ERR_WORKSPACE;
   }
@@ -926,17 +1016,13 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
     // the rows — it does for SKEWED adjacencies (ops.layer12: hub rows; the Reddit-LP shape with Zipf sources, 11.8 entries per
     // row and hubs of 3 800: 45.8 us against 80.1 for the lanes-per-row kernel; uniform rows of 8 / 16 / 40 entries: 38 / 53 /
     // 132 against 30 / 62 / 106 — no partition is passed there).  Captured steps, kernel durations under rocprofv3: the synthetic Bitcoin-OTC shape
-    // 31.1 -> 27.9 us; the chess data 60 -> 62 (no gain there: 512 / 1 024 / 1 536 / 4 096 blocks 79.8 / 65.7 / 58.8 / 59.5)
-    // Grid: persistent blocks (all resident, each walking its row blocks one after the other) while a row block is less than
-    // a tile of entries; one block per row block when row blocks hold a tile or more on average — with real skew some hold
-    // several, and chaining those behind each other costs more than the extra slabs (chess, 1 016 entries per row block:
-    // 50.8 us against 61.7; the synthetic shape, 784: 30.0 against 26.6)
+    // 31.1 -> 27.9 us.  Grid: resident blocks that DRAW their row blocks (see the kernel).  One block per row block with the
+    // hardware as the scheduler cost every row block the slab / ticket tail and a block launch (chess: 2 661 blocks of mean
+    // life 12.9 us, 4.6 of it the tail: 49.0 us); row blocks dealt statically chained heavy ones (61.7); drawn: 42.3, and
+    // 37.8 with the partition cut at one tile of entries instead of two (tools/l12_trace.py, profiles/r5s_*).
     a.blk = row_blocks;
     a.n_blk = n_row_blocks;
-    int64_t blocks = row_blocks ? n_row_blocks : (n_rows + 255) / 256;
-    const int64_t cap = avg_nnz_per_row * 256.f > 0.9f * kEmTile ? kL12MaxBlocks : kL12ResidentBlocks;
-    if (blocks > cap) blocks = cap;
-    l12_bwd_em_launch(a, F, Nf, (unsigned)blocks, st);
+    l12_bwd_em_launch(a, F, Nf, row_blocks ? n_row_blocks : (n_rows + 255) / 256, st);
   } else {
     int64_t blocks = (n_rows * G + 255) / 256;
     if (blocks > kL12ResidentBlocks) blocks = kL12ResidentBlocks;      // all resident at 4 waves per SIMD; 1 280 - 2 048 blocks measured slower (32 - 36 us vs 31)
@@ -944,3 +1030,15 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
   }
   return check_launch("layer12_bwd");
 }
+
+#ifdef TMGCN_L12_TRACE
+extern "C" int tmgcn_debug_l12_trace(unsigned long long* dst, long n_words, int clear) {
+  hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(tmgcn::l12_trace_words), (size_t)n_words * 8);
+  if (e == hipSuccess && clear) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(tmgcn::l12_trace_words));
+    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 16);
+  }
+  return (int)e;
+}
+#endif

@@ -880,9 +880,9 @@ struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
     at::AutoDispatchBelowADInplaceOrView guard;
     want(H, "layer12 H");
     for (const OptTensor* b : {&blk, &t_blk})
-      TORCH_CHECK(!b->has_value() || ((*b)->is_cuda() && (*b)->scalar_type() == at::kLong && (*b)->is_contiguous() && (*b)->dim() == 1 &&
-                                      (*b)->numel() >= 2),
-                  "layer12: a row-block partition is a contiguous int64 vector of at least two first-row indices on the device");
+      TORCH_CHECK(!b->has_value() || ((*b)->is_cuda() && (*b)->scalar_type() == at::kLong && (*b)->is_contiguous() && (*b)->dim() == 2 &&
+                                      (*b)->size(1) == 2 && (*b)->size(0) >= 1),
+                  "layer12: a row-block partition is a contiguous int64 [n, 2] tensor of (first row, rows) pairs on the device");
     want(W1, "layer12 W1");
     want(W2, "layer12 W2");
     check_csr(rowptr, col, val, H, N, "layer12");
@@ -904,7 +904,7 @@ struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
       ok(tmgcn_layer12_fwd_f32((const int64_t*)ptr(rowptr), (const int32_t*)ptr(col), (const float*)ptr(val), (const float*)ptr(H),
                                (const float*)ptr(W1), (int32_t)act1, (const float*)ptr(W2), (int32_t)act2, R, (int32_t)N,
                                (int32_t)K0, (int32_t)F, (int32_t)Nf, (float*)ptr(Z), (float*)ptr(AX), (float*)ptr(pre2), (float)avg,
-                               blk.has_value() ? (const int64_t*)ptr(*blk) : nullptr, blk.has_value() ? (int32_t)(blk->numel() - 1) : 0,
+                               blk.has_value() ? (const int64_t*)ptr(*blk) : nullptr, blk.has_value() ? (int32_t)(blk->numel() / 2) : 0,
                                stream_of(H)),
          "tmgcn_layer12_fwd_f32");
     } else {
@@ -941,13 +941,14 @@ struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
     const int64_t K0 = H.size(2), F = W1.size(1), Nf = W2.size(1), R = H.size(0) * H.size(1);
     if (ctx->needs_input_grad(1)) {
       dW1 = at::empty_like(W1);
-      const int64_t need = tmgcn_layer12_bwd_workspace_bytes((int32_t)K0, (int32_t)F);
+      const int32_t n_blk = sv[8].numel() >= 2 ? (int32_t)(sv[8].numel() / 2) : 0;
+      const int64_t need = tmgcn_layer12_bwd_workspace_bytes((int32_t)K0, (int32_t)F, R, n_blk);
       Tensor ws = at::empty({need}, H.options().dtype(at::kByte));
       ok(tmgcn_layer12_bwd_f32((const int64_t*)ptr(sv[5]), (const int32_t*)ptr(sv[6]), (const float*)ptr(sv[7]), (const float*)ptr(dZ),
                                act2 != TMGCN_ACT_NONE ? (const float*)ptr(pre2) : nullptr, (const float*)ptr(H), (const float*)ptr(W1),
                                (int32_t)act1, (const float*)ptr(W2), (int32_t)act2, R, (int32_t)N, (int32_t)K0, (int32_t)F,
-                               (int32_t)Nf, (float*)ptr(dW1), (float)avg, sv[8].numel() >= 2 ? (const int64_t*)ptr(sv[8]) : nullptr,
-                               sv[8].numel() >= 2 ? (int32_t)(sv[8].numel() - 1) : 0, ptr(ws), ws.numel(), stream_of(H)),
+                               (int32_t)Nf, (float*)ptr(dW1), (float)avg, n_blk ? (const int64_t*)ptr(sv[8]) : nullptr, n_blk, ptr(ws), ws.numel(),
+                               stream_of(H)),
          "tmgcn_layer12_bwd_f32");
     }
     if (ctx->needs_input_grad(2)) {

@@ -116,6 +116,7 @@ class HeadLossPlan:
     between launches, so launches that share a plan must not overlap (one training loop does not)."""
 
     SPLIT = 0            # entries per part of a split row; 0 = from the lanes per row (see __init__)
+    WORTH = 6            # … and rows are only split when the longest holds more than WORTH parts
 
     def __init__(self, edges: "EdgeIndex", R: int, target: torch.Tensor, C: int, ignore_index: int = -100):
         if edges.index_dtype != torch.int32 or R >= 2 ** 31 - 1:
@@ -149,10 +150,15 @@ class HeadLossPlan:
         lanes = _lib.load().tmgcn_head_loss_lanes
         self.srow, self.n_parts = None, 0
         n_arow = int(active.numel())
+        longest = int((end - beg).max()) if active.numel() else 0
         for _ in range(3):
             G = int(lanes(edges.E, max(1, n_arow)))
             split = self.SPLIT if self.SPLIT else 8 * (2 if G == 1 else 8) * G          # 16 / 256 / 1 024 entries
             n_part = torch.clamp((end - beg + split - 1) // split, min=1)
+            if not self.SPLIT and longest <= self.WORTH * split:
+                # the 2-layer models pay a launch for adding the parts' dZ shares (about 5 us): not for a few trips more (the
+                # reference's chess data, longest row a few dozen entries: head + loss 22.9 us whole, 20.9 + 4.8 split)
+                n_part = torch.ones_like(n_part)
             n_new = int(n_part.sum()) if active.numel() else 0
             if n_new == n_arow or int(lanes(edges.E, max(1, n_new))) == G:
                 break
@@ -583,7 +589,7 @@ def layer12(H: torch.Tensor, W1: torch.Tensor, act1, A: BatchedCSR, W2: torch.Te
         if At.avg_nnz_per_row < 4 or At.is_skewed():
             t_blk = At.row_blocks()
             if t_blk is None and At.avg_nnz_per_row >= 4:          # skewed, but no 256-row block over the limit: the trivial partition
-                t_blk = torch.arange(0, At.n_rows + 256, 256, device=At.device, dtype=torch.int64).clamp_(max=At.n_rows)
+                t_blk = At.trivial_row_blocks()
     return kernels.ops.layer12(H, W1.contiguous(), W2.contiguous(), A.rowptr, A.col, A.val, *_csr_t(A, need), A.N, A.avg_nnz_per_row,
                                _lib.ACT_IDS[act1], _lib.ACT_IDS[act2], blk, t_blk)
 
