@@ -919,6 +919,36 @@ def test_layer12_hub_rows(base_deg, act2):
     _assert_layer12_vs_oracle(outs[0], H, W1, "selu", A, W2, act2, dZ, f"hub rows, {base_deg} per row")
 
 
+@pytest.mark.parametrize("T,N,deg,skew", [(5, 250_000, 2.0, False),       # 4 883 row blocks of 256 rows: more slabs than thread blocks stay resident
+                                          (3, 30_000, 10.0, True),         # hub rows: a partition of (first row, rows) pairs, heaviest first
+                                          (2, 1500, 2.0, False)])          # 12 row blocks: fewer than the sixteen hand-off groups
+def test_layer12_backward_draws_row_blocks_reproducibly(T, N, deg, skew):
+    """The entry-major backward (csrc/layer12.hip): resident thread blocks DRAW the row blocks they work on, so which block
+    sums which rows differs from run to run — dW1 must not: it is summed per row block and the row blocks' sums in a fixed
+    order.  Ten runs bit-equal, and equal to the unfused route (GEMM + fused SpMM + their autograd) to fp32 rounding."""
+    if skew:
+        A = synth.device_powerlaw_csr(T, N, int(deg), DEV, first_slice=3, hub_cap=4000, symmetric=True)
+        assert A.transpose().is_skewed() and A.transpose().row_blocks() is not None
+    else:
+        A = synth.device_er_csr(T, N, int(deg), DEV, first_slice=3)
+    g = torch.Generator().manual_seed(11)
+    H = torch.randn(T, N, 2, generator=g).to(DEV)
+    W1, W2 = (torch.randn(2, 6, generator=g) * 0.7).to(DEV), (torch.randn(6, 6, generator=g) * 0.7).to(DEV)
+    dZ = torch.randn(T, N, 6, generator=g).to(DEV)
+    dZ[:, N // 3:] = 0                                    # (as in training: most rows of the embedding's gradient are zero)
+    runs = []
+    for _ in range(10):
+        a1, a2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+        ops.layer12(H, a1, "selu", A, a2, None, fuse=True).backward(dZ)
+        runs.append((a1.grad.clone(), a2.grad.clone()))
+    assert all(torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) for r in runs[1:])
+    b1, b2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+    ops.layer12(H, b1, "selu", A, b2, None, fuse=False).backward(dZ)
+    for got, ref, name in ((runs[0][0], b1.grad, "dW1"), (runs[0][1], b2.grad, "dW2")):
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err <= 2e-6, (name, err)
+
+
 @pytest.mark.parametrize("act1,act2", [("selu", None), ("relu", None), ("leaky", "relu"), (None, "selu")])
 @pytest.mark.parametrize("T,N,deg,F,Nf", [(5, 300, 3.0, 6, 6), (3, 77, 12.0, 6, 2), (4, 500, 0.4, 2, 6), (2, 64, 40.0, 8, 4),
                                           # staged variants (slice in LDS): several blocks per slice with a ragged last
