@@ -392,7 +392,7 @@ def cpu_epochs(g, spec, epochs, threads):
     return first, times[len(times) // 2]
 
 
-def epochs_block(args, configs=("S1", "S2", "S3", "chess"), modes=("eager", "graph", "fused", "graph_fused", "graph_fused8", "script")):
+def epochs_block(args, configs=("S1", "S2", "S3", "S2z2", "chess"), modes=("eager", "graph", "fused", "graph_fused", "graph_fused8", "script")):
     """north_star's epoch-throughput target (>= 10x the reference's CPU epoch on Reddit link
     prediction at 1 GPU), as a record: per config the GPU epoch in every mode, the CPU oracle's
     epoch (median of --cpu-epoch-reps at 8 and at 32 threads, both recorded, the better one reported) and the
@@ -448,7 +448,9 @@ def epochs_block(args, configs=("S1", "S2", "S3", "chess"), modes=("eager", "gra
             out["chess"] = {"error": repr(e)}
         gc.collect()
     out["note"] = ("epoch = zero_grad, gcn(), class-weighted CE, backward, SGD step (experiment_reddit_our_link_prediction.py:75-81); "
-                   "S1/S2/S3 are synthetic stand-ins of the Bitcoin-OTC / Reddit-LP / AMLSim shapes (SURVEY §8d); CPU = the oracle "
+                   "S1/S2/S3 are synthetic stand-ins of the Bitcoin-OTC / Reddit-LP / AMLSim shapes (SURVEY §8d), S2z2 the Reddit-LP shape "
+                   "with Zipf(1.5) source nodes (hub rows of 3 800 entries in the adjacency, 19 700 in the labelled edges) under the "
+                   "2-layer model; CPU = the oracle "
                    f"run the reference's way on {_cpu_model()}, median epoch")
     return out
 
