@@ -280,9 +280,9 @@ constexpr int kEmLong = TMGCN_L12_EM_LONG;      // entries of one row inside a t
 constexpr int kEmUnroll = TMGCN_L12_EM_UNROLL;
 
 // Which row of its block thread t owns (sums from LDS, finishes).  A full block: row t.  A block the caller's partition cut
-// short — few rows holding a tile or two of entries, so long ones — deals its rows over the four waves (row 4·lane + wave): the
-// row sums of such a block otherwise all fall to wave 0 while three waves wait (tools/l12_trace.py, chess: the backward's
-// heaviest row blocks spent 10 of their 20 us there).
+// short — few rows holding a tile of entries, so long ones — deals its rows over the four waves (row 4·lane + wave), so that
+// several hub rows of one block are summed by different waves instead of one after the other by wave 0 (the Reddit-LP shape
+// with Zipf sources, traced backward: 45.1 -> 43.4 us; the reference's chess data, rows of at most 83 entries: unchanged).
 __device__ __forceinline__ int em_row_of_thread(int t, int rows) { return rows > 192 ? t : ((t & 63) << 2) + (t >> 6); }
 
 // Thread t adds the entries [lo, hi) of ITS row that lie in the tile parked in LDS (value in plane 0, the W planes behind
