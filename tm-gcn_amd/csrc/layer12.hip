@@ -74,9 +74,12 @@ __device__ __forceinline__ T pick_at(const T (&v)[N], int i) {
 // the entry-major backward's phases in a device array, read back through tmgcn_debug_l12_trace.  Not part of the library.
 #ifdef TMGCN_L12_TRACE
 __device__ unsigned long long l12_trace_words[8192 * 16];
+__device__ unsigned long long l12_trace_fwd_words[8192 * 16];
 #define L12_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && (i) < 16) l12_trace_words[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define L12_STAMP_FWD(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && (i) < 16) l12_trace_fwd_words[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define L12_STAMP(i) do { } while (0)
+#define L12_STAMP_FWD(i) do { } while (0)
 #endif
 
 struct __attribute__((packed, aligned(4))) Int4u { int32_t v[4]; };
@@ -352,6 +355,10 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
     for (int n = 0; n < NT; ++n) W2[f][n] = a.W2[f * NT + n];
   const ActApply act1(a.act1), act2(a.act2);
   const int t = threadIdx.x;
+  L12_STAMP_FWD(0);
+  // (one block per row block, the hardware as the scheduler: persistent blocks walking the list with a stride and the next
+  // row block's pointers prefetched were measured — chess 27.8 -> 32.9 us, the Zipf Reddit-LP shape 22.2 -> 29.2, S1 18.2 ->
+  // 19.4: a block's three or four row blocks in a row balance worse than 3 700 blocks on 1 280 slots; tools/l12_trace.py --fwd)
   // the block's rows: 256 consecutive ones, or — with a partition (tmgcn_layer12_fwd_f32's row_blocks: row blocks cut so
   // that none holds more than about a tile of entries, the heaviest first) — blk[2b + 1] rows from row blk[2b]
   const int64_t first = a.blk ? a.blk[2 * (int64_t)blockIdx.x] : (int64_t)blockIdx.x * 256;
@@ -364,6 +371,7 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
     if (t == 0) rp[256] = a.rowptr[first + rows];
   }
   __syncthreads();
+  L12_STAMP_FWD(1);
   const int64_t base = rp[0];
   const int n_ent = (int)(rp[rows < 256 ? rows : 256] - base);
   // the slice boundary inside the block, as an entry position
@@ -388,6 +396,10 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
     }
   };
   if (n_ent > 0) load_cv(0, c, v);
+#ifdef TMGCN_L12_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  L12_STAMP_FWD(2);
+#endif
   for (int tile = 0; tile < n_ent; tile += kEmTile) {
     float2 hv[PER];
 #pragma unroll
@@ -410,25 +422,30 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
       }
     }
     __syncthreads();
+    if (tile == 0) L12_STAMP_FWD(3);
     const int lo = my_lo > tile ? my_lo : tile, hi = my_hi < tile + kEmTile ? my_hi : tile + kEmTile;
     em_row_sum<F>(park, tile, lo, hi, acc);
     __syncthreads();
+    if (tile == 0) L12_STAMP_FWD(4);
 #pragma unroll
     for (int u = 0; u < PER; ++u) c[u] = c_next[u], v[u] = v_next[u];
   }
-  if (rt >= rows) return;
-  if (a.AX) {
+  L12_STAMP_FWD(5);
+  if (rt < rows) {
+    if (a.AX) {
 #pragma unroll
-    for (int f = 0; f < F; ++f) a.AX[r * F + f] = acc[f];
+      for (int f = 0; f < F; ++f) a.AX[r * F + f] = acc[f];
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int f = 0; f < F; ++f) s2 = fmaf(acc[f], W2[f][n], s2);
+      if (a.pre2_out) a.pre2_out[r * NT + n] = s2;
+      a.Z[r * NT + n] = act2(s2);
+    }
   }
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    float s2 = 0.f;
-#pragma unroll
-    for (int f = 0; f < F; ++f) s2 = fmaf(acc[f], W2[f][n], s2);
-    if (a.pre2_out) a.pre2_out[r * NT + n] = s2;
-    a.Z[r * NT + n] = act2(s2);
-  }
+  L12_STAMP_FWD(14);
 }
 
 // The end of a backward block: its dW1 partial sums (NO values, dealt over the G lanes of a row group: lane gl owns
@@ -1032,13 +1049,11 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
 }
 
 #ifdef TMGCN_L12_TRACE
-extern "C" int tmgcn_debug_l12_trace(unsigned long long* dst, long n_words, int clear) {
-  hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(tmgcn::l12_trace_words), (size_t)n_words * 8);
-  if (e == hipSuccess && clear) {
-    void* p = nullptr;
-    e = hipGetSymbolAddress(&p, HIP_SYMBOL(tmgcn::l12_trace_words));
-    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 16);
-  }
+extern "C" int tmgcn_debug_l12_trace(unsigned long long* dst, long n_words, int clear) {   // clear & 2: the forward's stamps
+  void* p = nullptr;
+  hipError_t e = (clear & 2) ? hipGetSymbolAddress(&p, HIP_SYMBOL(tmgcn::l12_trace_fwd_words)) : hipGetSymbolAddress(&p, HIP_SYMBOL(tmgcn::l12_trace_words));
+  if (e == hipSuccess && n_words > 0) e = hipMemcpy(dst, p, (size_t)n_words * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && (clear & 1)) e = hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 16);
   return (int)e;
 }
 #endif

@@ -50,6 +50,7 @@ def model(which):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "chess"
+    fwd = "--fwd" in sys.argv[2:]                               # the entry-major FORWARD's stamps (0 entry, 1 row pointers, 2 (col, val), 3 parked, 4 summed, 5 before the stores, 14 end)
     from tmgcn_amd import _lib
     lib = _lib.load()
     fn = getattr(lib, "tmgcn_debug_l12_trace", None)
@@ -64,11 +65,28 @@ def main():
             p.grad = None
         if it == 5:
             torch.cuda.synchronize()
-            fn(words.ctypes.data, 0, 1)                       # clear
+            fn(words.ctypes.data, 0, 1 | (2 if fwd else 0))   # clear
         m.loss(crit, tgt).backward()
     torch.cuda.synchronize()
-    assert fn(words.ctypes.data, words.size, 0) == 0
+    assert fn(words.ctypes.data, words.size, 2 if fwd else 0) == 0
     w = words.reshape(8192, 16).astype(np.int64)
+    if fwd:
+        w = w[w[:, 0] > 0]
+        t0 = w[:, 0].min()
+        q = lambda x: [round(float(v), 2) for v in np.percentile(x, [0, 10, 50, 90, 100])]
+        d = lambda i, j: q((w[:, i] - w[:, j]) / 100.0)
+        life = (w[:, 14] - w[:, 0]) / 100.0
+        span = float((w[:, 14].max() - t0) / 100.0)
+        rec = {"config": which, "kernel": "l12_fwd_em", "blocks": len(w), "unit": "us; [min, p10, median, p90, max]",
+               "block_start_after_first": q((w[:, 0] - t0) / 100.0), "kernel_span_us": round(span, 2), "rowptr_in_lds": d(1, 0),
+               "col_val_arrived": d(2, 1), "gathers_layer1_parked": d(3, 2), "first_tile_summed": d(4, 3), "further_tiles": d(5, 4),
+               "stores_issued": d(14, 5), "block_lifetime": q(life), "block_lifetime_mean": round(float(life.mean()), 2),
+               "resident_on_average": round(float(life.sum() / span), 1)}
+        print(json.dumps(rec))
+        with open(os.path.join(root, "gpurun_out", f"l12_trace_fwd_{which}.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+        np.save(os.path.join(root, "gpurun_out", f"l12_trace_fwd_{which}.npy"), w - t0)
+        return
     used = w[:, 0] > 0
     w = w[used]
     nb = len(w)

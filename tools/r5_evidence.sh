@@ -15,8 +15,12 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output
 python3 tools/mfma_util.py "$OUT/pmc_mfma" > "$OUT/mfma_utilisation_bench.json" 2>> "$OUT/pmc_mfma.err"
 rm -rf "$OUT/pmc_mfma"
 # 4. epochs: kernel stats + one-epoch sequences of the captured steps
-for c in S1 S2 S3; do tools/epoch_profile.sh "$TAG" $c graph_fused > /dev/null 2>&1; done
-tools/epoch_profile.sh "$TAG" S2 "fused script" > /dev/null 2>&1
+for c in S1 S2 S3 S2z2; do timeout 300 tools/epoch_profile.sh "$TAG" $c graph_fused > /dev/null 2>&1; done
+timeout 300 tools/epoch_profile.sh "$TAG" S2 "fused script" > /dev/null 2>&1
+# 4b. the reference's chess data: kernel stats of 1 900 steps (eager + captured)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_chess" -- python3 tools/chess_epoch.py --epochs 200 --only graph_fused > "$OUT/chess_epoch.json" 2> "$OUT/chess_epoch.err"
+f=$(find "$OUT/prof_chess" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/chess_graph_fused_kernel_stats.csv"
+rm -rf "$OUT/prof_chess"
 ls "$OUT"
 tail -3 "$OUT/bench_20_steps_5_warmup.err"
 # 5. the -m gpu suite (writes gpurun_out/parity_clauses.json and tolerance_record.jsonl) and their summaries
@@ -24,3 +28,12 @@ python3 -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=
 cp gpurun_out/parity_clauses.json "$OUT/parity_clauses.json" 2>/dev/null
 python3 tools/tolerance_summary.py gpurun_out/tolerance_record.jsonl "$OUT/tolerance_summary.json" > /dev/null 2>&1
 tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/status.log"
+# 6. LAST (it replaces the in-tree library of this scratch copy by the development build with phase stamps): where the time of
+#    the entry-major layer kernels goes, block by block
+if [ -f build/variants/trace/libtmgcn_hip.so ]; then
+  cp build/variants/trace/libtmgcn_hip.so tm-gcn_amd/libtmgcn_hip.so
+  for c in chess S1; do
+    timeout 200 python3 tools/l12_trace.py $c > /dev/null 2>&1 && cp gpurun_out/l12_trace_$c.json "$OUT/l12_trace_bwd_$c.json"
+    timeout 200 python3 tools/l12_trace.py $c --fwd > /dev/null 2>&1 && cp gpurun_out/l12_trace_fwd_$c.json "$OUT/l12_trace_fwd_$c.json"
+  done
+fi
