@@ -139,6 +139,69 @@ def test_synth_configs_have_the_scripts_shapes():
 from hypothesis import given, settings, strategies as st  # noqa: E402
 
 
+@settings(max_examples=80, deadline=None)
+@given(st.lists(st.integers(0, 70), min_size=1, max_size=40), st.integers(1, 24), st.integers(0, 5))
+def test_head_loss_plan_splits_rows_into_parts_that_tile_them(lengths, split, shift):
+    """ops.HeadLossPlan.split_rows (the row list of the one-pass head + loss kernel, include/tmgcn.h `arow`): every active
+    row's entry range is tiled by its parts in order, a part holds at most `split` entries, whole rows carry part id 0, the
+    parts of split rows are numbered 1, 2, … in list order, and `srow` names each split row with its first part and count."""
+    cnt = torch.tensor(lengths, dtype=torch.int64)
+    eptr = torch.zeros(len(lengths) + 1, dtype=torch.int64)
+    torch.cumsum(cnt, 0, out=eptr[1:])
+    active = torch.nonzero(cnt > 0).flatten()
+    beg, end = eptr[:-1][active] + shift, eptr[1:][active] + shift
+    n_part = torch.clamp((end - beg + split - 1) // split, min=1)
+    arow, srow, n_parts = ops.HeadLossPlan.split_rows(active, beg, end, n_part, split)
+    assert arow.dtype == torch.int32 and arow.shape == (int(n_part.sum()) if active.numel() else 0, 4)
+    a = arow.long()
+    assert bool((a[:, 2] - a[:, 1] <= split).all()) and bool((a[:, 2] > a[:, 1]).all())
+    pos = 0
+    next_id = 1
+    for i, r in enumerate(active.tolist()):
+        parts = a[pos:pos + int(n_part[i])]
+        pos += int(n_part[i])
+        assert bool((parts[:, 0] == r).all())
+        assert int(parts[0, 1]) == int(beg[i]) and int(parts[-1, 2]) == int(end[i]) and bool((parts[1:, 1] == parts[:-1, 2]).all())
+        if len(parts) == 1:
+            assert int(parts[0, 3]) == 0
+        else:
+            assert parts[:, 3].tolist() == list(range(next_id, next_id + len(parts)))
+            row = srow.long()[(srow[:, 0] == r).nonzero().flatten()]
+            assert row.shape[0] == 1 and row[0].tolist() == [r, next_id - 1, len(parts), 0]
+            next_id += len(parts)
+    assert n_parts == next_id - 1 and (srow is None) == (n_parts == 0)
+    if srow is not None:
+        assert srow.shape[0] == int((n_part > 1).sum())
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.integers(0, 40), min_size=1, max_size=700), st.integers(1, 3), st.sampled_from([16, 64, 256]), st.integers(20, 400))
+def test_row_block_partition_tiles_the_rows_heaviest_first(lengths, T, max_rows, max_entries):
+    """csr.BatchedCSR.row_blocks for any row lengths: (first row, rows) pairs that cover every row exactly once, at most
+    max_rows rows and at most max_entries + the longest row of entries each, listed by entries descending; None exactly when
+    no block of max_rows consecutive rows exceeds max_entries."""
+    N = (len(lengths) + T - 1) // T
+    cnt = torch.tensor((lengths + [0] * (T * N))[:T * N], dtype=torch.int64)
+    rowptr = torch.zeros(T * N + 1, dtype=torch.int64)
+    torch.cumsum(cnt, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    A = BatchedCSR(rowptr, torch.zeros(nnz, dtype=torch.int32), torch.ones(nnz), T, N)
+    pairs = A.row_blocks(max_rows, max_entries)
+    whole = [int(rowptr[min(s + max_rows, T * N)] - rowptr[s]) for s in range(0, T * N, max_rows)]
+    assert (pairs is None) == (max(whole) <= max_entries)
+    for p in ([] if pairs is None else [pairs]) + [A.trivial_row_blocks(max_rows)]:
+        first, rows = p[:, 0], p[:, 1]
+        ent = rowptr[first + rows] - rowptr[first]
+        assert bool((ent[1:] <= ent[:-1]).all()) and bool((rows >= 1).all()) and int(rows.max()) <= max_rows
+        covered = torch.zeros(T * N, dtype=torch.int64)
+        for f, n in p.tolist():
+            covered[f:f + n] += 1
+        assert bool((covered == 1).all())
+    if pairs is not None:
+        ent = rowptr[pairs[:, 0] + pairs[:, 1]] - rowptr[pairs[:, 0]]
+        assert int(ent.max()) <= max_entries + int(cnt.max())
+
+
 @settings(max_examples=60, deadline=None)
 @given(st.integers(1, 4), st.integers(1, 9), st.lists(st.tuples(st.integers(0, 3), st.integers(0, 8), st.integers(0, 8),
                                                                   st.floats(-4, 4, allow_nan=False, width=32)), max_size=60))

@@ -148,7 +148,6 @@ class HeadLossPlan:
         # follows the lanes the launcher will use (tmgcn_head_loss_lanes), which depend on the number of arow entries:
         # settled in at most two rounds (more parts can only lower the lane count).
         lanes = _lib.load().tmgcn_head_loss_lanes
-        self.srow, self.n_parts = None, 0
         n_arow = int(active.numel())
         longest = int((end - beg).max()) if active.numel() else 0
         for _ in range(3):
@@ -163,24 +162,32 @@ class HeadLossPlan:
             if n_new == n_arow or int(lanes(edges.E, max(1, n_new))) == G:
                 break
             n_arow = n_new
-        if active.numel() and int(n_part.max()) > 1:
-            own = torch.repeat_interleave(torch.arange(active.numel(), device=dev), n_part)     # arow entry -> active row
-            k = torch.arange(own.numel(), device=dev) - (torch.cumsum(n_part, 0) - n_part)[own]    # part index inside its row
-            is_split = n_part[own] > 1
-            pid = torch.cumsum(is_split.long(), 0) * is_split                                    # 1, 2, … over all split rows' parts
-            pbeg = beg[own] + k * split
-            pend = torch.minimum(pbeg + split, end[own])
-            self.arow = torch.stack((active[own], pbeg, pend, pid), dim=1).to(torch.int32).contiguous()
-            sp = n_part > 1
-            first = (torch.cumsum(n_part * sp, 0) - n_part * sp)[sp]                             # first part - 1 of every split row
-            self.srow = torch.stack((active[sp], first, n_part[sp], torch.zeros_like(first)), dim=1).to(torch.int32).contiguous()
-            self.n_parts = int((n_part * sp).sum())
-        else:
-            self.arow = torch.stack((active, beg, end, torch.zeros_like(active)), dim=1).to(torch.int32).contiguous()
+        self.arow, self.srow, self.n_parts = self.split_rows(active, beg, end, n_part, split)
         self.counts = torch.bincount(t[~ignored], minlength=C)[:C].to(torch.int64).contiguous()
         self.sync = torch.zeros(_lib.SYNC_INTS, dtype=torch.int32, device=dev)   # include/tmgcn.h: TMGCN_SYNC_INTS
         self.R, self.C, self.ignore_index = R, C, ignore_index
         self._target, self._version = target, target._version
+
+    @staticmethod
+    def split_rows(active: torch.Tensor, beg: torch.Tensor, end: torch.Tensor, n_part: torch.Tensor, split: int):
+        """The kernel's row list for active rows `active` with entry ranges [beg, end), row i cut into n_part[i] parts of
+        `split` entries (the last one shorter): (arow int32 [n, 4] = (row, first entry, end entry, part id — 0 for a whole
+        row, else 1, 2, … over all parts of all split rows in list order), srow int32 [m, 4] = (row, its first part id − 1,
+        its number of parts, 0) for the split rows or None, the number of parts).  Pure index arithmetic (tests/test_abi_and_host.py)."""
+        dev = active.device
+        if not active.numel() or int(n_part.max()) <= 1:
+            return torch.stack((active, beg, end, torch.zeros_like(active)), dim=1).to(torch.int32).contiguous(), None, 0
+        own = torch.repeat_interleave(torch.arange(active.numel(), device=dev), n_part)     # arow entry -> active row
+        k = torch.arange(own.numel(), device=dev) - (torch.cumsum(n_part, 0) - n_part)[own]    # part index inside its row
+        is_split = n_part[own] > 1
+        pid = torch.cumsum(is_split.long(), 0) * is_split                                    # 1, 2, … over all split rows' parts
+        pbeg = beg[own] + k * split
+        pend = torch.minimum(pbeg + split, end[own])
+        arow = torch.stack((active[own], pbeg, pend, pid), dim=1).to(torch.int32).contiguous()
+        sp = n_part > 1
+        first = (torch.cumsum(n_part * sp, 0) - n_part * sp)[sp]                             # first part - 1 of every split row
+        srow = torch.stack((active[sp], first, n_part[sp], torch.zeros_like(first)), dim=1).to(torch.int32).contiguous()
+        return arow, srow, int((n_part * sp).sum())
 
     def matches(self, target: torch.Tensor, R: int, C: int, ignore_index: int) -> bool:
         return (self._target is target and self._version == target._version and self.R == R and self.C == C
