@@ -19,9 +19,11 @@
 // the vector memory path (measured 6.5 clocks per non-zero per CU) and a fraction of that from LDS.
 // Three walks of the rows, chosen per call from the shape (tmgcn_layer12_fwd_f32 / _bwd_f32):
 //   entry-major   slices of >= 256 nodes that the staged variants do not take — the forward at every density, the backward
-//                 for sparse rows (< 4 non-zeros per row on average): a block walks the contiguous entry range of its 256
-//                 rows tile by tile and sums each row from LDS (l12_fwd_em_kernel, l12_bwd_em_kernel) — three dependent
-//                 round trips per block whatever the row lengths; the Bitcoin-OTC shape and real, skewed data;
+//                 for sparse rows (< 4 non-zeros per row on average) and whenever the caller brings a partition of the rows
+//                 (skewed adjacencies): a block walks the contiguous entry range of a row block — 256 rows, or the caller's
+//                 (first row, rows) pair — tile by tile and sums each row from LDS (l12_fwd_em_kernel: one block per row
+//                 block; l12_bwd_em_kernel: resident blocks that draw row blocks) — three dependent round trips per row
+//                 block whatever the row lengths; the Bitcoin-OTC shape and real, skewed data;
 //   staged        small dense slices (above);
 //   lanes per row everything else: G = 1 … 16 lanes per row, entries strided over them (l12_fwd_kernel, l12_bwd_kernel).
 // dW2 = (Â⋆Y)ᵀ·dZ stays the narrow dW kernel (gemm.hip) on the Â⋆Y the forward stores for it (folding its 36 sums into
