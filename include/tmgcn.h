@@ -248,16 +248,23 @@ int tmgcn_gemm_dw_act_f32(const float* A, const float* dY, const float* pre_act,
  * when act2 is not none.  The backward takes the TRANSPOSED batched CSR.
  * row_blocks / n_row_blocks (optional, both 0 = blocks of 256 consecutive rows, ascending): a partition of the rows for
  *   the entry-major kernels — n_row_blocks pairs (first row, number of rows <= 256) of int64 that together cover every row
- *   exactly once (N >= 256: a block then holds at most one slice boundary), IN THE ORDER THEY ARE TO BE STARTED.  A caller
- *   that knows its row lengths cuts the blocks so that none holds more than about one 1 024-entry tile and lists the heaviest
- *   first (csr.BatchedCSR.row_blocks): with real, skewed data the longest block otherwise sets the launch time, and heavy
- *   blocks started last leave the chip idle behind them.  The BACKWARD takes its entry-major kernel whenever a partition is
- *   given (otherwise only for fewer than 4 entries per row): a caller passes one for skewed adjacencies — hub rows — and none
- *   for evenly filled ones, where lanes-per-row is the faster walk above 4 entries per row.  The forward's and the
- *   backward's partitions are independent (the backward's is over the TRANSPOSED rows); results do not depend on the
- *   partition in the forward (whole rows) and are bit-reproducible for a given partition in the backward (dW1 is summed per
- *   row block, the row blocks' sums in a fixed order — whichever thread block worked on which).
- * tmgcn_layer12_bwd_workspace_bytes: for the call's n_rows and n_row_blocks (0 without a partition). */
+ *   exactly once (N >= 256: a block then holds at most one slice boundary).  A caller that knows its row lengths
+ *   (csr.BatchedCSR.row_blocks) cuts the blocks so that none holds more than about one 1 024-entry tile: with real, skewed
+ *   data the longest block otherwise sets the launch time.  The FORWARD starts the blocks in list order: the heaviest first
+ *   (heavy blocks started last leave the chip idle behind them).  The BACKWARD's resident thread blocks draw their row blocks
+ *   from min(TMGCN_L12_RUNS, n_row_blocks) RUNS of the list — run g = entries [n·g / runs, n·(g + 1) / runs) — each run worked on
+ *   by the thread blocks of one XCD, first entry to last: its caller fills each run with NEIGHBOURING row blocks (an XCD's L2
+ *   then sees whole slices and fetches the rows they gather once instead of every XCD fetching them) and lists the heaviest
+ *   first inside a run (csr.BatchedCSR.row_block_runs).  Any list that covers
+ *   the rows is correct; the order is performance only.  The backward takes its
+ *   entry-major kernel whenever a partition is given (otherwise only for fewer than 4 entries per row): a caller passes one for
+ *   skewed adjacencies — hub rows — and none for evenly filled ones, where lanes-per-row is the faster walk above 4 entries per
+ *   row.  The forward's and the backward's partitions are independent (the backward's is over the TRANSPOSED rows); results
+ *   do not depend on the partition in the forward (whole rows) and are bit-reproducible for a given partition in the
+ *   backward (dW1 / dW2 are summed per row block, the row blocks' sums in a fixed order — whichever thread block worked on which).
+ * tmgcn_layer12_bwd_workspace_bytes: for the call's widths, n_rows and n_row_blocks (0 without a partition).
+ * AX / dW2 of the backward (optional, both or neither): see tmgcn_layer12_bwd_forms_dw2 below. */
+#define TMGCN_L12_RUNS 16
 int tmgcn_layer12_supported(int32_t K0, int32_t F, int32_t Nf);
 int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, const float* val, const float* H,
                           const float* W1, int32_t act1, const float* W2, int32_t act2, int64_t n_rows,
@@ -267,12 +274,17 @@ int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, const float
  * slices whose layer-1 output is formed once per node in LDS; short rows); 0: form act1(H·W1) with tmgcn_gemm_f32 and call
  * tmgcn_spmm_gemm_f32 (same Z up to fp32 summation order). */
 int tmgcn_layer12_fwd_pays(int64_t n_rows, int32_t N, int32_t F, float avg_nnz_per_row);
-int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F, int64_t n_rows, int32_t n_row_blocks);
+int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F, int32_t Nf, int64_t n_rows, int32_t n_row_blocks);
+/* 1 when tmgcn_layer12_bwd_f32 will take its entry-major kernel for this call (slices of >= 256 nodes that are sparse —
+ * fewer than 4 entries per row — or come with a partition): that kernel can form dW2 = AXᵀ·(dZ ⊙ act2'(pre2)) — layer 2's
+ * weight gradient, ehf:348-349's autograd — in the same launch, from the AX the forward stored: pass AX and dW2 then, and
+ * leave tmgcn_gemm_dw(_act)_f32 out.  0: AX and dW2 must be NULL. */
+int tmgcn_layer12_bwd_forms_dw2(int64_t n_rows, int32_t N, int32_t F, int32_t Nf, float avg_nnz_per_row, int32_t n_row_blocks);
 int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const float* dZ,
                           const float* pre2, const float* H, const float* W1, int32_t act1, const float* W2,
                           int32_t act2, int64_t n_rows, int32_t N, int32_t K0, int32_t F, int32_t Nf,
-                          float* dW1, float avg_nnz_per_row, const int64_t* row_blocks, int32_t n_row_blocks,
-                          void* workspace, int64_t workspace_bytes, void* stream);
+                          float* dW1, const float* AX, float* dW2, float avg_nnz_per_row, const int64_t* row_blocks,
+                          int32_t n_row_blocks, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- P5: pointwise non-linearity between layers (ehf:284-289, 332-334, 486) -------
  *   fwd: y = act(x);   bwd: dx = dy * act'(x)   (x = the pre-activation input)

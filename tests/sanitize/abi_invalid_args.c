@@ -109,9 +109,10 @@ int main(void) {
   BAD(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 5, 4, 2, 6, 6, 0, 0, 0, 1.f, 0, 0, 0));                 /* rows not a multiple of N */
   NOP(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 2, 6, 6, 0, 0, 0, 1.f, 0, 0, 0));                 /* nothing to do */
   BAD(tmgcn_layer12_fwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 6, 6, 0, 0, 0, 1.f, 0, 3, 0));                 /* a block count without a partition */
-  BAD(tmgcn_layer12_bwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 5, 6, 0, 1.f, 0, 0, 0, 0, 0));           /* odd width */
-  BAD(tmgcn_layer12_bwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 6, 6, 0, 1.f, 0, 0, 0, 0, 0));           /* null pointers */
-  if (tmgcn_layer12_bwd_workspace_bytes(2, 6, 1000, 0) <= 0) { ++failures; printf("FAIL layer12 workspace size\n"); }
+  BAD(tmgcn_layer12_bwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 5, 6, 0, 0, 0, 1.f, 0, 0, 0, 0, 0));           /* odd width */
+  BAD(tmgcn_layer12_bwd_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 2, 6, 6, 0, 0, 0, 1.f, 0, 0, 0, 0, 0));           /* null pointers */
+  NOP(tmgcn_layer12_bwd_forms_dw2(0, 0, 6, 6, 1.f, 0));
+  if (tmgcn_layer12_bwd_workspace_bytes(2, 6, 6, 1000, 0) <= 0) { ++failures; printf("FAIL layer12 workspace size\n"); }
   BAD(tmgcn_scale2_f32(0, 0, 0, 4, 0, 0, 4, 0));
   BAD(tmgcn_cast_multi(0, 0, 0, 2, 0, 0));                                                 /* null host arrays */
   BAD(tmgcn_cast_multi(hg, hp, hn, 2, 1, 0));                                              /* null device pointers */

@@ -192,7 +192,8 @@ def test_row_block_partition_tiles_the_rows_heaviest_first(lengths, T, max_rows,
     for p in ([] if pairs is None else [pairs]) + [A.trivial_row_blocks(max_rows)]:
         first, rows = p[:, 0], p[:, 1]
         ent = rowptr[first + rows] - rowptr[first]
-        assert bool((ent[1:] <= ent[:-1]).all()) and bool((rows >= 1).all()) and int(rows.max()) <= max_rows
+        assert bool((rows >= 1).all()) and int(rows.max()) <= max_rows
+        assert bool((ent[1:] <= ent[:-1]).all())       # heaviest first (the forward's starting order)
         covered = torch.zeros(T * N, dtype=torch.int64)
         for f, n in p.tolist():
             covered[f:f + n] += 1
@@ -200,6 +201,18 @@ def test_row_block_partition_tiles_the_rows_heaviest_first(lengths, T, max_rows,
     if pairs is not None:
         ent = rowptr[pairs[:, 0] + pairs[:, 1]] - rowptr[pairs[:, 0]]
         assert int(ent.max()) <= max_entries + int(cnt.max())
+    # the backward's form: the same row blocks as min(16, n) runs of equal length — neighbouring rows, heaviest first inside a run
+    lst = A.row_block_runs(max_rows, max_entries)
+    want = pairs if pairs is not None else A.trivial_row_blocks(max_rows)
+    assert sorted(map(tuple, lst.tolist())) == sorted(map(tuple, want.tolist()))
+    ent = rowptr[lst[:, 0] + lst[:, 1]] - rowptr[lst[:, 0]]
+    n, runs, last = lst.shape[0], min(16, lst.shape[0]), -1
+    for g in range(runs):
+        e, f = ent[n * g // runs:n * (g + 1) // runs], lst[n * g // runs:n * (g + 1) // runs, 0]
+        assert bool((e[1:] <= e[:-1]).all())
+        if f.numel():
+            assert int(f.min()) > last
+            last = int(f.max())
 
 
 @settings(max_examples=60, deadline=None)

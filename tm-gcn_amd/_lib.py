@@ -51,8 +51,9 @@ SIGNATURES = {
     "tmgcn_layer12_supported": (C.c_int, [_i32, _i32, _i32]),
     "tmgcn_layer12_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, C.c_float, _p, _i32, _p]),
     "tmgcn_layer12_fwd_pays": (C.c_int, [_i64, _i32, _i32, C.c_float]),
-    "tmgcn_layer12_bwd_workspace_bytes": (_i64, [_i32, _i32, _i64, _i32]),
-    "tmgcn_layer12_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _i32, _p, C.c_float, _p, _i32, _p, _i64, _p]),
+    "tmgcn_layer12_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i64, _i32]),
+    "tmgcn_layer12_bwd_forms_dw2": (C.c_int, [_i64, _i32, _i32, _i32, C.c_float, _i32]),
+    "tmgcn_layer12_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, C.c_float, _p, _i32, _p, _i64, _p]),
     "tmgcn_edge_head_supported": (C.c_int, [_i32, _i32]),
     "tmgcn_edge_head_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "tmgcn_edge_head_bwd_workspace_bytes": (_i64, [_i64, _i32, _i32]),

@@ -194,9 +194,9 @@ class BatchedCSR:
         blocks of `max_rows` consecutive rows, and every such block that holds more than `max_entries` stored entries
         cut further — at row boundaries, into ceil(entries / max_entries) parts of about equal entry counts — so that
         no block holds more than max_entries + its longest row.  int64 [n_blocks, 2] pairs (first row, rows) on the
-        adjacency's device, the blocks with the most entries FIRST (the kernels start them in this order: heavy blocks
+        adjacency's device, the blocks with the most entries FIRST (the forward starts them in this order: heavy blocks
         started last would leave the chip idle behind them; equal blocks keep their ascending order); None when no block
-        needs cutting (balanced data: the kernels' own 256-row blocks)."""
+        needs cutting (balanced data: the kernels' own 256-row blocks).  The backward's form: row_block_runs."""
         key = (int(max_rows), int(max_entries))
         if key not in self._blocks:
             R, dev = self.n_rows, self.device
@@ -218,12 +218,37 @@ class BatchedCSR:
                 self._blocks[key] = self._heaviest_first(blk)
         return self._blocks[key]
 
+    RUNS = 16          # include/tmgcn.h: TMGCN_L12_RUNS
+
     def _heaviest_first(self, bounds: torch.Tensor) -> torch.Tensor:
-        """Ascending block boundaries [n + 1] -> the (first row, rows) pairs [n, 2], most entries first (stable)."""
+        """Ascending block boundaries [n + 1] -> the (first row, rows) pairs [n, 2], most entries first (stable): the order
+        the forward starts its blocks in."""
         first, rows = bounds[:-1], bounds[1:] - bounds[:-1]
         entries = self.rowptr[bounds[1:]] - self.rowptr[first]
         order = torch.sort(entries, descending=True, stable=True).indices
         return torch.stack((first[order], rows[order]), dim=1).contiguous()
+
+    def row_block_runs(self, max_rows: int = 256, max_entries: int = 1024) -> torch.Tensor:
+        """The backward's form of the partition (tmgcn_layer12_bwd_f32's row_blocks), cached: the same row blocks as
+        row_blocks() (the trivial 256-row ones when nothing needs cutting), listed for a kernel that reads the list as
+        min(RUNS, n) runs of equal length — run g = list entries [n·g / runs, n·(g + 1) / runs), worked on by the thread blocks
+        of one XCD: the ascending order cut into those runs (neighbouring row blocks gather the same rows: the XCD's L2 then
+        fetches them once), and inside a run the row blocks with the most entries first (stable)."""
+        key = ("runs", int(max_rows), int(max_entries))
+        if key not in self._blocks:
+            pairs = self.row_blocks(max_rows, max_entries)
+            if pairs is None:
+                pairs = self.trivial_row_blocks(max_rows)
+            pairs = pairs[torch.argsort(pairs[:, 0])]
+            n = int(pairs.shape[0])
+            entries = self.rowptr[pairs[:, 0] + pairs[:, 1]] - self.rowptr[pairs[:, 0]]
+            runs = min(self.RUNS, n)
+            ends = (torch.arange(1, runs + 1, device=pairs.device) * n) // runs                # run g ends at n·(g+1)/runs
+            run = torch.searchsorted(ends, torch.arange(n, device=pairs.device), right=True)
+            order = torch.sort(entries, descending=True, stable=True).indices
+            order = order[torch.sort(run[order], stable=True).indices]                          # by (run, entries descending)
+            self._blocks[key] = pairs[order].contiguous()
+        return self._blocks[key]
 
     def trivial_row_blocks(self, max_rows: int = 256) -> torch.Tensor:
         """The kernels' own blocks of `max_rows` consecutive rows as an explicit partition (heaviest first)."""

@@ -194,6 +194,13 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   return ((r0 + r1) + r2) + r3;
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_f64(double x) {          // x + (x of the lane the DPP control names): two 32-bit moves
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return x + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {        // the same steps on the two halves of an fp64
   auto step = [](double x, auto ctrl) {
     const long long b = __builtin_bit_cast(long long, x);
@@ -249,17 +256,20 @@ __device__ __forceinline__ double slab_sum_f32(const unsigned* slabs, int n, int
 // group s mod 16: the entry-major layer backward stores one per ROW BLOCK, whichever block of the group worked on it).
 // slab_tree_finish_in: the same with the caller's LDS for the partial sums (`fin`: 256 / NO · NO doubles — a kernel whose
 // tile buffers are free by then stays under the LDS of one more resident block).
+// `ranges`: group g's slabs are the consecutive ones [n_slabs·g / groups, n_slabs·(g + 1) / groups) instead of those ≡ g mod 16
+// (the entry-major layer backward gives every group — the thread blocks of one XCD — a run of neighbouring row blocks).
 template <int NO>
 __device__ __forceinline__ bool slab_tree_finish_in(unsigned* part, int n_blocks, int32_t* sync, double* total /* LDS [NO] */, int n_slabs,
-                                                    double* fin) {
+                                                    double* fin, bool ranges = false) {
   constexpr int SUBS = 256 / NO;
   double (*tree_fin)[NO] = reinterpret_cast<double (*)[NO]>(fin);
   __shared__ int tree_flag;
   if (n_slabs < 0) n_slabs = n_blocks;
   const int g = blockIdx.x % kSyncGroups;
   const int members = (n_blocks - g + kSyncGroups - 1) / kSyncGroups;
-  const int slabs = (n_slabs - g + kSyncGroups - 1) / kSyncGroups;          // of this group
   const int groups = n_blocks < kSyncGroups ? n_blocks : kSyncGroups;
+  const int64_t range_lo = (int64_t)n_slabs * g / groups;
+  const int slabs = ranges ? (int)((int64_t)n_slabs * (g + 1) / groups - range_lo) : (n_slabs - g + kSyncGroups - 1) / kSyncGroups;   // of this group
   int32_t* mine = sync + (1 + g) * kSyncStride;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -272,7 +282,9 @@ __device__ __forceinline__ bool slab_tree_finish_in(unsigned* part, int n_blocks
   if (!tree_flag) return false;
   // the group's slabs g, g + 16, …: SUBS threads per output, then the SUBS partial sums in order
   const int sub = threadIdx.x / NO, o = threadIdx.x - sub * NO;
-  if (sub < SUBS) tree_fin[sub][o] = slab_sum_f32<8>(part + (int64_t)g * NO, slabs, sub, SUBS, NO * kSyncGroups, o);
+  if (sub < SUBS)
+    tree_fin[sub][o] = ranges ? slab_sum_f32<8>(part + range_lo * NO, slabs, sub, SUBS, NO, o)
+                              : slab_sum_f32<8>(part + (int64_t)g * NO, slabs, sub, SUBS, NO * kSyncGroups, o);
   __syncthreads();
   if (threadIdx.x < NO) {
     double t = 0.0;

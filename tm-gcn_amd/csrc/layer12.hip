@@ -45,13 +45,14 @@ struct L12Args {
   float* AX;               // forward, optional: Â⋆Y [R][F]
   float* pre2_out;         // forward, optional
   float* dW1;              // backward: [KI][F]
-  float* part;             // backward: [blocks][KI·F] slabs
+  float* dW2;              // backward, entry-major kernel only, optional: [F][NT] = AXᵀ·(dZ ⊙ act2'(pre2)) (AX then holds the forward's Â⋆Y)
+  float* part;             // backward: [blocks][KI·F] slabs (entry-major: one per row block, + F·NT with dW2)
   int32_t* sync;
   int64_t n_rows;
   int32_t N;
   int32_t act1, act2;
   int32_t chunks, chunk_rows;   // staged variants: blocks per slice and rows per block
-  const int64_t* blk;           // entry-major variants, optional: first row of every row block (n_blk + 1 values, <= 256 rows each)
+  const int64_t* blk;           // entry-major variants, optional: (first row, rows <= 256) of every row block, n_blk pairs
   int32_t n_blk;
 };
 
@@ -357,12 +358,14 @@ __global__ __launch_bounds__(256) void l12_fwd_em_kernel(L12Args a) {
     for (int n = 0; n < NT; ++n) W2[f][n] = a.W2[f * NT + n];
   const ActApply act1(a.act1), act2(a.act2);
   const int t = threadIdx.x;
-  L12_STAMP_FWD(0);
   // (one block per row block, the hardware as the scheduler: persistent blocks walking the list with a stride and the next
   // row block's pointers prefetched were measured — chess 27.8 -> 32.9 us, the Zipf Reddit-LP shape 22.2 -> 29.2, S1 18.2 ->
   // 19.4: a block's three or four row blocks in a row balance worse than 3 700 blocks on 1 280 slots; tools/l12_trace.py --fwd)
   // the block's rows: 256 consecutive ones, or — with a partition (tmgcn_layer12_fwd_f32's row_blocks: row blocks cut so
-  // that none holds more than about a tile of entries, the heaviest first) — blk[2b + 1] rows from row blk[2b]
+  // that none holds more than about a tile of entries, the heaviest first) — blk[2b + 1] rows from row blk[2b].  (Handing
+  // each XCD a run of neighbouring row blocks, as the backward does, brought the forward's fabric fetch from 2.3x the
+  // algorithmic bytes to 1.03x — 53.9 -> 23.9 MB on the Bitcoin-OTC shape — and its time nowhere: 18.1 us both ways.)
+  L12_STAMP_FWD(0);
   const int64_t first = a.blk ? a.blk[2 * (int64_t)blockIdx.x] : (int64_t)blockIdx.x * 256;
   const int rows = a.blk ? (int)a.blk[2 * (int64_t)blockIdx.x + 1] : (a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256);
   const int rt = em_row_of_thread(t, rows);         // the row of the block this thread sums and finishes
@@ -479,6 +482,7 @@ __device__ __forceinline__ void l12_bwd_finish(const double (&acc)[(NO + G - 1) 
 
 // Backward.  Groups of G lanes walk rows r = group, group + n_groups, …; the KI·F fp64 accumulators of dW1 are dealt
 // over the lanes of a group (lane gl owns q = gl + j·G).
+static_assert(kSyncGroups == TMGCN_L12_RUNS, "include/tmgcn.h states the number of runs a row-block list is read as");
 constexpr int kL12MaxBlocks = 4096;          // slabs the workspace holds
 constexpr int kL12ResidentBlocks = 1024;     // a persistent grid: four blocks per CU
 
@@ -678,9 +682,14 @@ __global__ __launch_bounds__(256) void l12_bwd_kernel(L12Args a) {
 // each entry's dZ row (⊙ act2'(pre2) when layer 2 has an activation) parked in LDS with its value —, thread t sums ITS
 // row in entry order (the one-lane-per-row chain: the same bits), finishes the row (·W2ᵀ, act1', H[r]ᵀ·dP into its fp64
 // dW1 partial sums) and the block ends like every backward block (l12_bwd_finish).
-template <int KI, int F, int NT, bool ACT2>
+// DW2: the kernel also forms dW2 = AXᵀ·(dZ ⊙ act2'(pre2)) — layer 2's weight gradient, which needs nothing but the rows of
+// two [R][6] tensors: at the start of a row block, while the row pointers are in flight, four lanes per row (the narrow dW
+// kernel's 3 x 3 quadrants, gemm.hip) load the row block's own rows of AX and dZ, multiply and fold over the wave (two DPP
+// row rotations, two shuffles); the sums join the row block's slab behind the dW1 ones.  A launch of its own for these
+// 28 MB cost 10.3 us of every step (5 of them its ticket tail).
+template <int KI, int F, int NT, bool ACT2, bool DW2>
 __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
-  constexpr int NO = KI * F;
+  constexpr int NO1 = KI * F, NO = NO1 + (DW2 ? F * NT : 0);
   __shared__ int64_t rp[257];
   __shared__ float park[1 + NT][kEmTile];            // val, g[0..NT)
   float W1[KI][F], W2[F][NT];
@@ -699,19 +708,28 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
   __shared__ double red[4][NO];
   L12_STAMP(0);
   [[maybe_unused]] int trace_it = 0;
-  // Row blocks are DRAWN, not dealt: the blocks of hand-off group g (blockIdx ≡ g mod 16, common.h) share the row blocks
-  // rb ≡ g mod 16 — a block's first one by its place in the group, every further one from the group's counter (an int of the
+  // Row blocks are DRAWN, not dealt: the blocks of hand-off group g (blockIdx ≡ g mod 16, common.h) share a run of the list
+  // (below) — a block's first one by its place in the group, every further one from the group's counter (an int of the
   // launch's hand-off block: sixteen addresses, agent-scope atomics on one are served one at a time), drawn while the
   // current row block is being worked on.  A block that waits on a heavy row block no longer holds others back, and the
   // ticket tail (4.6 us of latency, tools/l12_trace.py) is paid once per resident block instead of once per row block.
   // The dW1 partial sums are kept per ROW BLOCK (slab rb: the rows' H[r]ᵀ·dP[r] folded over the block in a fixed order), not
   // per executing block: which block draws which row block varies from run to run, the slabs and the order they are added
-  // in (slab_tree_finish: group g adds the slabs ≡ g mod 16, then the sixteen group sums) do not — bit-reproducible.
+  // in (slab_tree_finish_in: group g adds the slabs of its run, then the sixteen group sums) do not — bit-reproducible.
   __shared__ int64_t s_next;
   const int grp = blockIdx.x % kSyncGroups;
   const int64_t grp_members = ((int64_t)gridDim.x - grp + kSyncGroups - 1) / kSyncGroups;
   int* draw = a.sync + (1 + grp) * kSyncStride + 8;
-  for (int64_t rb = blockIdx.x; rb < n_row_blocks;) {
+  // (group g — the thread blocks of one XCD, as long as blocks are dealt to the XCDs in turn — works on the run of row blocks
+  // [n·g / groups, n·(g + 1) / groups) of the list: neighbouring row blocks gather the same rows of dZ, and an XCD's L2 that
+  // sees a slice alone fetches its lines once instead of every XCD fetching them — fabric fetch of the Bitcoin-OTC-shaped
+  // backward 126 -> 53 MB, 31.2 -> 27.8 us; with row blocks ≡ g mod 16 every XCD touched every slice.  Runs of equal LENGTH:
+  // runs of equal estimated work, given by the caller, were measured too — the Zipf Reddit-LP shape 40.7 us against 38.4,
+  // the reference's chess data 48.1 against 48.9, where row blocks ≡ g mod 16 of one heaviest-first list ran 42.5 / 45.9)
+  const int n_grp = gridDim.x < kSyncGroups ? (int)gridDim.x : kSyncGroups;
+  const int64_t run_lo = n_row_blocks * grp / n_grp, run_hi = n_row_blocks * (grp + 1) / n_grp;
+  const int64_t run_first = run_lo + blockIdx.x / kSyncGroups;
+  for (int64_t rb = run_first < run_hi ? run_first : n_row_blocks; rb < n_row_blocks;) {
     const int64_t first = a.blk ? a.blk[2 * rb] : rb * 256;
     const int rows = a.blk ? (int)a.blk[2 * rb + 1] : (a.n_rows - first < 256 ? (int)(a.n_rows - first) : 256);
     const int rt = em_row_of_thread(t, rows);
@@ -719,6 +737,24 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
     rp[t] = a.rowptr[first + (t < rows ? t : rows)];   // (the previous row block's readers of rp are done: the barrier at the loop's end)
     if (t == 0) rp[256] = a.rowptr[first + rows];
     const float2 hv = *reinterpret_cast<const float2*>(a.H + (rt < rows ? r : first) * KI);   // this row's H, early
+    constexpr int KH = F / 2, NH = NT / 2;
+    [[maybe_unused]] float qx[4][KH], qg[4][NH];
+    if constexpr (DW2) {                              // rows q, q + 64, … of the row block: lane j = t & 3 holds quadrant (j >> 1, j & 1)
+      const int q = t >> 2, kh = (t >> 1) & 1, nh = t & 1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = q + 64 * u < rows;
+        const int64_t row = first + (in ? q + 64 * u : 0);
+#pragma unroll
+        for (int i = 0; i < KH; ++i) qx[u][i] = a.AX[row * F + kh * KH + i];
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+          float gq = a.dZ[row * NT + nh * NH + i];
+          if constexpr (ACT2) gq *= dact2(a.pre2[row * NT + nh * NH + i]);
+          qg[u][i] = in ? gq : 0.f;
+        }
+      }
+    }
     __syncthreads();
     if (trace_it < 3) L12_STAMP(1 + 4 * trace_it);
     const int64_t base = rp[0];
@@ -745,6 +781,26 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
     if (n_ent > 0) load_cv(0, c, v);
     int drawn = 0;
     if (t == 0) drawn = __hip_atomic_fetch_add(draw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // behind the (col, val) loads: back with the gathers
+    // (dW2's sums while the first (col, val) tile is in flight: its rows were asked for ahead of the row pointers' barrier)
+    if constexpr (DW2) {
+      const int lane = t & 63, wave = t >> 6, kh = (t >> 1) & 1, nh = t & 1;
+#pragma unroll
+      for (int k = 0; k < KH; ++k)
+#pragma unroll
+        for (int n = 0; n < NH; ++n) {
+          // the 64 rows of a wave in fp32 (a dot product of 64 terms: 4 rows per lane, 16 lanes per quadrant), fp64 from there
+          // on — across the waves, the row blocks and the groups; in fp64 throughout (conversions, half-rate FMAs, three
+          // instructions per DPP step) this was 5 us of vector-ALU time per launch at 4-5 waves per SIMD, not latency
+          float w = 0.f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w = fmaf(qx[u][k], qg[u][n], w);
+          w += dpp_lane_f32<0x124>(w);                // row_ror:4, row_ror:8: the four lanes of a 16-lane row with this quadrant
+          w += dpp_lane_f32<0x128>(w);
+          w += __shfl_xor(w, 16);
+          w += __shfl_xor(w, 32);
+          if (lane < 4) red[wave][NO1 + (kh * KH + k) * NT + nh * NH + n] = (double)w;
+        }
+    }
 #ifdef TMGCN_L12_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (trace_it < 3) L12_STAMP(2 + 4 * trace_it);
@@ -792,7 +848,7 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
     }
     if (trace_it < 3) L12_STAMP(4 + 4 * trace_it);
     ++trace_it;
-    if (t == 0) s_next = grp + kSyncGroups * (grp_members + drawn);
+    if (t == 0) s_next = run_lo + grp_members + drawn < run_hi ? run_lo + grp_members + drawn : n_row_blocks;
     {
       // dY = t·W2ᵀ, P = H·W1, dP = dY ⊙ act1'(P): as l12_bwd_kernel; the row's share of dW1 (zero for a thread without a row)
       // summed over the wave, the four waves' sums over the block
@@ -823,13 +879,14 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
   }
   L12_STAMP(13);
   __shared__ double total[NO];
-  static_assert(sizeof(park) >= sizeof(double) * 256, "the tile planes double as the finisher's partial sums");
+  static_assert(sizeof(park) >= sizeof(double) * (256 / NO) * NO, "the tile planes double as the finisher's partial sums");
   if (slab_tree_finish_in<NO>(reinterpret_cast<unsigned*>(a.part), (int)gridDim.x, a.sync, total, (int)n_row_blocks,
-                              reinterpret_cast<double*>(&park[0][0]))) {      // (park: every reader passed the loop's last barrier)
+                              reinterpret_cast<double*>(&park[0][0]), true)) {      // (park: every reader passed the loop's last barrier)
     // (the last block of all: every other block drew its last row block before it took its ticket — the draw counters go
     // back to zero with the tickets)
     if (t < kSyncGroups) __hip_atomic_store(a.sync + (1 + t) * kSyncStride + 8, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t < NO) a.dW1[t] = (float)total[t];
+    if (t < NO1) a.dW1[t] = (float)total[t];
+    else if (t < NO) a.dW2[t - NO1] = (float)total[t];
   }
   L12_STAMP(14);
 }
@@ -906,10 +963,15 @@ static void l12_em_launch(const L12Args& a, int F, int NT, unsigned blocks, hipS
 }
 
 // (grid: as many blocks as stay resident — five per CU without a layer-2 activation, 91 VGPRs and 31 KB of LDS; four with)
+template <int F, int NT, bool ACT2, bool DW2>
+static void l12_bwd_em_launch_d(const L12Args& a, int64_t row_blocks, hipStream_t st) {
+  const int64_t resident = persistent_grid(l12_bwd_em_kernel<2, F, NT, ACT2, DW2>, 256, 0, 5);
+  hipLaunchKernelGGL((l12_bwd_em_kernel<2, F, NT, ACT2, DW2>), dim3((unsigned)(row_blocks < resident ? row_blocks : resident)), dim3(256), 0, st, a);
+}
 template <int F, int NT, bool ACT2>
 static void l12_bwd_em_launch_g(const L12Args& a, int64_t row_blocks, hipStream_t st) {
-  const int64_t resident = persistent_grid(l12_bwd_em_kernel<2, F, NT, ACT2>, 256, 0, 5);
-  hipLaunchKernelGGL((l12_bwd_em_kernel<2, F, NT, ACT2>), dim3((unsigned)(row_blocks < resident ? row_blocks : resident)), dim3(256), 0, st, a);
+  if (a.dW2) l12_bwd_em_launch_d<F, NT, ACT2, true>(a, row_blocks, st);
+  else l12_bwd_em_launch_d<F, NT, ACT2, false>(a, row_blocks, st);
 }
 template <int F, bool ACT2>
 static void l12_bwd_em_launch_n(const L12Args& a, int NT, int64_t row_blocks, hipStream_t st) {
@@ -967,7 +1029,7 @@ extern "C" int tmgcn_layer12_fwd_f32(const int64_t* rowptr, const int32_t* col, 
   TMGCN_REQUIRE(rowptr && H && W1 && W2 && Z, "layer12: null pointer");
   TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(H) % 8 == 0, "layer12: H must be 8-byte aligned");
   TMGCN_REQUIRE((row_blocks == nullptr) == (n_row_blocks == 0) && n_row_blocks >= 0, "layer12: row_blocks and n_row_blocks go together");
-  L12Args a{rowptr, col, val, H, W1, W2, nullptr, nullptr, Z, AX, pre2, nullptr, nullptr, nullptr, n_rows, N, act1, act2, 0, 0, nullptr, 0};
+  L12Args a{rowptr, col, val, H, W1, W2, nullptr, nullptr, Z, AX, pre2, nullptr, nullptr, nullptr, nullptr, n_rows, N, act1, act2, 0, 0, nullptr, 0};
   const bool staged = l12_staged(n_rows, N, F, avg_nnz_per_row);
   const int G = l12_lanes(avg_nnz_per_row, staged);
   if (staged) {
@@ -994,18 +1056,29 @@ extern "C" int tmgcn_layer12_fwd_pays(int64_t n_rows, int32_t N, int32_t F, floa
   return (N >= 256 || (avg_nnz_per_row >= 0.f && avg_nnz_per_row <= 6.f) || l12_staged(n_rows, N, F, avg_nnz_per_row)) ? 1 : 0;
 }
 
-extern "C" int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F, int64_t n_rows, int32_t n_row_blocks) {
-  // slabs of the blocks (lanes-per-row and staged kernels: at most kL12MaxBlocks) or of the row blocks (entry-major) + group slabs
+extern "C" int64_t tmgcn_layer12_bwd_workspace_bytes(int32_t K0, int32_t F, int32_t Nf, int64_t n_rows, int32_t n_row_blocks) {
+  // slabs of the blocks (lanes-per-row and staged kernels: at most kL12MaxBlocks) or of the row blocks (entry-major) + group
+  // slabs, each wide enough for dW1 and dW2
   int64_t slabs = n_row_blocks > 0 ? n_row_blocks : (n_rows + 255) / 256;
   if (slabs < kL12MaxBlocks) slabs = kL12MaxBlocks;
-  return (slabs + kSyncGroups) * K0 * F * (int64_t)sizeof(float);
+  return (slabs + kSyncGroups) * ((int64_t)K0 * F + (int64_t)F * Nf) * (int64_t)sizeof(float);
+}
+
+// the walk tmgcn_layer12_bwd_f32 takes (see there)
+static bool l12_bwd_entry_major(int64_t n_rows, int32_t N, int32_t F, int32_t Nf, float avg_nnz_per_row, bool partition) {
+  const bool staged = l12_staged(n_rows, N, Nf, avg_nnz_per_row);
+  return !staged && (l12_lanes(avg_nnz_per_row, staged) == 1 || partition) && N >= 256 && F <= 6 && Nf <= 6;
+}
+
+extern "C" int tmgcn_layer12_bwd_forms_dw2(int64_t n_rows, int32_t N, int32_t F, int32_t Nf, float avg_nnz_per_row, int32_t n_row_blocks) {
+  return (n_rows > 0 && N > 0 && l12_bwd_entry_major(n_rows, N, F, Nf, avg_nnz_per_row, n_row_blocks > 0)) ? 1 : 0;
 }
 
 extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const float* dZ,
                                       const float* pre2, const float* H, const float* W1, int32_t act1, const float* W2,
                                       int32_t act2, int64_t n_rows, int32_t N, int32_t K0, int32_t F, int32_t Nf,
-                                      float* dW1, float avg_nnz_per_row, const int64_t* row_blocks, int32_t n_row_blocks,
-                                      void* workspace, int64_t workspace_bytes, void* stream) {
+                                      float* dW1, const float* AX, float* dW2, float avg_nnz_per_row, const int64_t* row_blocks,
+                                      int32_t n_row_blocks, void* workspace, int64_t workspace_bytes, void* stream) {
   TMGCN_REQUIRE(tmgcn_layer12_supported(K0, F, Nf), "layer12_bwd: unsupported widths %d -> %d -> %d", K0, F, Nf);
   TMGCN_REQUIRE(n_rows > 0 && N > 0 && n_rows % N == 0, "layer12_bwd: bad shape n_rows=%lld N=%d", (long long)n_rows, N);
   TMGCN_REQUIRE(act1 >= TMGCN_ACT_NONE && act1 <= TMGCN_ACT_SELU && act2 >= TMGCN_ACT_NONE && act2 <= TMGCN_ACT_SELU,
@@ -1015,13 +1088,16 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
   TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(H) % 8 == 0 && reinterpret_cast<uintptr_t>(dZ) % 8 == 0 &&
                     (!pre2 || reinterpret_cast<uintptr_t>(pre2) % 8 == 0),
                 "layer12_bwd: H, dZ and pre2 must be 8-byte aligned");
-  if (workspace_bytes < tmgcn_layer12_bwd_workspace_bytes(K0, F, n_rows, n_row_blocks)) {
+  TMGCN_REQUIRE((AX == nullptr) == (dW2 == nullptr), "layer12_bwd: AX and dW2 go together");
+  TMGCN_REQUIRE(!dW2 || l12_bwd_entry_major(n_rows, N, F, Nf, avg_nnz_per_row, n_row_blocks > 0),
+                "layer12_bwd: this call does not take the entry-major kernel and cannot form dW2 (ask tmgcn_layer12_bwd_forms_dw2)");
+  if (workspace_bytes < tmgcn_layer12_bwd_workspace_bytes(K0, F, Nf, n_rows, n_row_blocks)) {
     set_error("layer12_bwd: workspace too small");
     return TMGCN_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
   TMGCN_REQUIRE((row_blocks == nullptr) == (n_row_blocks == 0) && n_row_blocks >= 0, "layer12_bwd: row_blocks and n_row_blocks go together");
-  L12Args a{t_rowptr, t_col, t_val, H, W1, W2, dZ, pre2, nullptr, nullptr, nullptr, dW1, (float*)workspace,
+  L12Args a{t_rowptr, t_col, t_val, H, W1, W2, dZ, pre2, nullptr, const_cast<float*>(AX), nullptr, dW1, dW2, (float*)workspace,
             acquire_sync_word(st), n_rows, N, act1, act2, 0, 0, nullptr, 0};
   TMGCN_REQUIRE(a.sync, "layer12_bwd: no hand-off block: %s", pool_error());
   const bool staged = l12_staged(n_rows, N, Nf, avg_nnz_per_row);
@@ -1030,7 +1106,7 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
     a.chunks = l12_chunks(n_rows / N, N);
     a.chunk_rows = (N + a.chunks - 1) / a.chunks;
     l12_launch<true, true>(a, F, Nf, G, (unsigned)(n_rows / N * a.chunks), (size_t)N * Nf * 4 + (a.chunk_rows + 1) * 8, st);
-  } else if ((G == 1 || row_blocks) && N >= 256 && F <= 6 && Nf <= 6) {
+  } else if (l12_bwd_entry_major(n_rows, N, F, Nf, avg_nnz_per_row, row_blocks != nullptr)) {
     // entry-major (l12_bwd_em_kernel): sparse rows (one lane per row otherwise), and whenever the caller brings a partition of
     // the rows — it does for SKEWED adjacencies (ops.layer12: hub rows; the Reddit-LP shape with Zipf sources, 11.8 entries per
     // row and hubs of 3 800: 45.8 us against 80.1 for the lanes-per-row kernel; uniform rows of 8 / 16 / 40 entries: 38 / 53 /

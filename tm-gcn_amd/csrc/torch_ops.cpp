@@ -939,19 +939,24 @@ struct Layer12Fn : public torch::autograd::Function<Layer12Fn> {
     c10::DeviceGuard g(H.device());
     Tensor dW1, dW2;
     const int64_t K0 = H.size(2), F = W1.size(1), Nf = W2.size(1), R = H.size(0) * H.size(1);
+    bool dw2_done = false;
     if (ctx->needs_input_grad(1)) {
       dW1 = at::empty_like(W1);
       const int32_t n_blk = sv[8].numel() >= 2 ? (int32_t)(sv[8].numel() / 2) : 0;
-      const int64_t need = tmgcn_layer12_bwd_workspace_bytes((int32_t)K0, (int32_t)F, R, n_blk);
+      const int64_t need = tmgcn_layer12_bwd_workspace_bytes((int32_t)K0, (int32_t)F, (int32_t)Nf, R, n_blk);
       Tensor ws = at::empty({need}, H.options().dtype(at::kByte));
+      // the entry-major backward forms dW2 in the same launch (include/tmgcn.h: tmgcn_layer12_bwd_forms_dw2)
+      dw2_done = ctx->needs_input_grad(2) && AX.numel() > 0 &&
+                 tmgcn_layer12_bwd_forms_dw2(R, (int32_t)N, (int32_t)F, (int32_t)Nf, (float)avg, n_blk) != 0;
+      if (dw2_done) dW2 = at::empty_like(W2);
       ok(tmgcn_layer12_bwd_f32((const int64_t*)ptr(sv[5]), (const int32_t*)ptr(sv[6]), (const float*)ptr(sv[7]), (const float*)ptr(dZ),
                                act2 != TMGCN_ACT_NONE ? (const float*)ptr(pre2) : nullptr, (const float*)ptr(H), (const float*)ptr(W1),
                                (int32_t)act1, (const float*)ptr(W2), (int32_t)act2, R, (int32_t)N, (int32_t)K0, (int32_t)F,
-                               (int32_t)Nf, (float*)ptr(dW1), (float)avg, n_blk ? (const int64_t*)ptr(sv[8]) : nullptr, n_blk, ptr(ws), ws.numel(),
-                               stream_of(H)),
+                               (int32_t)Nf, (float*)ptr(dW1), dw2_done ? (const float*)ptr(AX) : nullptr, dw2_done ? (float*)ptr(dW2) : nullptr,
+                               (float)avg, n_blk ? (const int64_t*)ptr(sv[8]) : nullptr, n_blk, ptr(ws), ws.numel(), stream_of(H)),
          "tmgcn_layer12_bwd_f32");
     }
-    if (ctx->needs_input_grad(2)) {
+    if (ctx->needs_input_grad(2) && !dw2_done) {
       if (act2 != TMGCN_ACT_NONE) dW2 = bgemm_dW_act(AX, dZ, pre2, act2, false);
       else dW2 = bgemm_dW(AX, dZ, false, TMGCN_DW_AUTO);
     }

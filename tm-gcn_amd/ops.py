@@ -591,12 +591,10 @@ def layer12(H: torch.Tensor, W1: torch.Tensor, act1, A: BatchedCSR, W2: torch.Te
     t_blk = None
     if need and A.N >= 256 and L12_ROW_BLOCKS:
         # the backward takes its entry-major kernel whenever it is handed a partition (include/tmgcn.h): sparse rows take that
-        # kernel anyway, skewed ones (hub rows) are 1.7x faster on it, evenly filled denser ones are not — no partition there
+        # kernel anyway, skewed ones (hub rows) are 1.7x faster on it, evenly filled denser ones are not — no partition there.
         At = A.transpose()
-        if At.avg_nnz_per_row < 4 or At.is_skewed():
-            t_blk = At.row_blocks()
-            if t_blk is None and At.avg_nnz_per_row >= 4:          # skewed, but no 256-row block over the limit: the trivial partition
-                t_blk = At.trivial_row_blocks()
+        if (At.avg_nnz_per_row < 4 or At.is_skewed()) and (At.row_blocks() is not None or At.avg_nnz_per_row >= 4):
+            t_blk = At.row_block_runs()
     return kernels.ops.layer12(H, W1.contiguous(), W2.contiguous(), A.rowptr, A.col, A.val, *_csr_t(A, need), A.N, A.avg_nnz_per_row,
                                _lib.ACT_IDS[act1], _lib.ACT_IDS[act2], blk, t_blk)
 
