@@ -44,7 +44,7 @@ typedef enum {
 /* activation ids for the fused P3 epilogue / P5 pointwise (ehf:284-289, 455-460) */
 enum { TMGCN_ACT_NONE = 0, TMGCN_ACT_RELU = 1, TMGCN_ACT_LEAKY = 2, TMGCN_ACT_SELU = 3 };
 
-/* ABI version 5 = version 4 + tmgcn_pool_stats + the row_blocks partition argument of tmgcn_layer12_fwd/bwd_f32 + tmgcn_head_loss_combine_f32 / tmgcn_head_loss_lanes (split rows of the one-pass head + loss plan) + the giant-row
+/* ABI version 5 = version 4 + tmgcn_pool_stats + the row_blocks partition argument of tmgcn_layer12_fwd/bwd_f32, the backward's AX / dW2 pair and tmgcn_layer12_bwd_forms_dw2 + tmgcn_head_loss_combine_f32 / tmgcn_head_loss_lanes (split rows of the one-pass head + loss plan) + the giant-row
  *   plan entry points tmgcn_spmm_csr_batched_f32_plan / tmgcn_spmm_gemm_f32_plan / tmgcn_spmm_giant_workspace_bytes; the launchers' scratch words (tile counters, hand-off blocks) are kept apart
  *   per stream (eager launches) and per recorded launch (hipGraph capture), and a launcher that cannot keep two launches
  *   apart returns TMGCN_ERR_INVALID with the reason instead of re-using a word that may be in flight (csrc/pools.hip).
