@@ -122,7 +122,7 @@ def main():
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(root, "gpurun_out", f"l12_trace_{which}.npy"), w - t0)
     At = m.At.transpose()
-    blk = At.row_blocks()
+    blk = At.row_block_runs() if At.row_blocks() is not None else None     # the list the backward was given (ops.layer12)
     if blk is not None:                                          # the partition's row blocks: rows, entries, longest row, rows over 64
         rp = At.rowptr.cpu().numpy()
         b = blk.cpu().numpy()                                    # (first row, rows), in the order the kernel hands them out
