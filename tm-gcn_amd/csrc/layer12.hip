@@ -962,10 +962,11 @@ static void l12_em_launch(const L12Args& a, int F, int NT, unsigned blocks, hipS
   }
 }
 
-// (grid: as many blocks as stay resident — five per CU without a layer-2 activation, 91 VGPRs and 31 KB of LDS; four with)
 template <int F, int NT, bool ACT2, bool DW2>
 static void l12_bwd_em_launch_d(const L12Args& a, int64_t row_blocks, hipStream_t st) {
-  const int64_t resident = persistent_grid(l12_bwd_em_kernel<2, F, NT, ACT2, DW2>, 256, 0, 5);
+  // (with dW2 inside, four blocks per CU beat the five that fit: chess 46.0 against 48.6 us, S1 26.5 / 28.3, the Zipf Reddit-LP
+  // shape 38.0 / 40.4; three: 52.3 / 30.8 / 42.3 — without dW2 five and four were 37.1 / 37.8 on chess)
+  const int64_t resident = persistent_grid(l12_bwd_em_kernel<2, F, NT, ACT2, DW2>, 256, 0, DW2 ? 4 : 5);
   hipLaunchKernelGGL((l12_bwd_em_kernel<2, F, NT, ACT2, DW2>), dim3((unsigned)(row_blocks < resident ? row_blocks : resident)), dim3(256), 0, st, a);
 }
 template <int F, int NT, bool ACT2>
