@@ -725,7 +725,8 @@ __global__ __launch_bounds__(256) void l12_bwd_em_kernel(L12Args a) {
   // sees a slice alone fetches its lines once instead of every XCD fetching them — fabric fetch of the Bitcoin-OTC-shaped
   // backward 126 -> 53 MB, 31.2 -> 27.8 us; with row blocks ≡ g mod 16 every XCD touched every slice.  Runs of equal LENGTH:
   // runs of equal estimated work, given by the caller, were measured too — the Zipf Reddit-LP shape 40.7 us against 38.4,
-  // the reference's chess data 48.1 against 48.9, where row blocks ≡ g mod 16 of one heaviest-first list ran 42.5 / 45.9)
+  // the reference's chess data 48.1 against 48.9, where row blocks ≡ g mod 16 of one heaviest-first list ran 42.5 / 45.9 — all at
+  // five blocks per CU; at four: runs 38.2-39.1 / 45.9, ≡ g mod 16 38.7-39.3 / 45.0)
   const int n_grp = gridDim.x < kSyncGroups ? (int)gridDim.x : kSyncGroups;
   const int64_t run_lo = n_row_blocks * grp / n_grp, run_hi = n_row_blocks * (grp + 1) / n_grp;
   const int64_t run_first = run_lo + blockIdx.x / kSyncGroups;
