@@ -20,6 +20,9 @@
 #ifndef TMGCN_SPMM_U
 #define TMGCN_SPMM_U 4      // gathers in flight per lane (F >= 64)
 #endif
+#ifndef TMGCN_SPMM_US
+#define TMGCN_SPMM_US 2     // ... on short tiles (spmm_row.h), as a multiple of the above
+#endif
 
 namespace tmgcn {
 
@@ -31,7 +34,7 @@ namespace tmgcn {
 // them in flight per lane.  Rows of more than kLongRow entries are shared by the block's four
 // waves, and the heaviest tiles are taken first (spmm_row.h).
 // ---------------------------------------------------------------------------------
-template <int LPR, int U>
+template <int LPR, int U, int US>       // US: gathers in flight per lane on short tiles
 __global__ __launch_bounds__(256) void spmm_vec4_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
     const float* __restrict__ val, const float4* __restrict__ X, float4* __restrict__ Y,
@@ -40,8 +43,8 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   __shared__ unsigned int s_tile;
   __shared__ float4 s_part[4 * LPR];      // partial sums of a long row, one per wave (spmm_row.h)
-  const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
-  const TileMap tm{n_rows, n_rows, n_tiles, n_tiles};
+  const TileMap tm = make_tile_map(n_rows, N);          // tiles restart at every slice (spmm_row.h)
+  const int64_t n_tiles = tm.n_tiles;
   HeavyScan heavy;
   heavy.init(rowptr, tm);
   for (;;) {
@@ -57,12 +60,24 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
       tile = s_tile;
       if (tile >= n_tiles) break;
     }
-    const int64_t r_begin = tile * kTileRows;
-    int64_t r_end = r_begin + kTileRows;
-    if (r_end > n_rows) r_end = n_rows;
+    int64_t slice0, r_begin, r_end;
+    tile_extent(tm, tile, slice0, r_begin, r_end);
+    if (r_begin + kTileRows < r_end) r_end = r_begin + kTileRows;
     TileRows rows;
     rows.load(rowptr, r_begin, r_end, lane);
     if (TMGCN_HEAVY_FIRST && !scanning && rows.entries > heavy.thr) continue;   // done in somebody's pass 1
+    // a tile of few entries is walked entry-major, several rows per wave at once (spmm_row.h "Short tiles")
+    const int n_tile_rows = (int)(r_end - r_begin);
+    if (short_tile(rows, true)) {
+      for (int c0 = 0; c0 < F4; c0 += kWave) {
+        const int w4 = F4 - c0 < kWave ? F4 - c0 : kWave;
+        gather_short_tile<LPR, US>(col, val, X + slice0 * (int64_t)N * F4 + c0, rows, n_tile_rows, w4, lane, wave, F4,
+                                   [&](int rr, const float4& acc, int fl) {
+                                     if (fl < w4) store_f4(&Y[(r_begin + rr) * F4 + c0 + fl], acc);
+                                   });
+      }
+      continue;
+    }
     // a row wider than 64 float4 (F > 256; LPR = 64 then) is gathered as column chunks of 256 floats: the row's entries are
     // walked once per chunk (col / val come from L1 the second time), every gather is still a contiguous 1 KB piece
     for (int c0 = 0; c0 < F4; c0 += kWave) {
@@ -70,15 +85,14 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
       for (int rr = wave; rr < (int)(r_end - r_begin); rr += 4) {
         if ((rows.long_mask >> rr) & 1) continue;
         const int64_t r = r_begin + rr;
-        const int64_t slice = r / N;
-        const float4 acc = gather_row<LPR, U>(col, val, X + slice * (int64_t)N * F4 + c0, readlane64(rows.beg, rr),
+        const float4 acc = gather_row<LPR, U>(col, val, X + slice0 * (int64_t)N * F4 + c0, readlane64(rows.beg, rr),
                                               readlane64(rows.end, rr), w4, lane, F4);
         if (lane < LPR && lane < w4) store_f4(&Y[r * F4 + c0 + lane], acc);
       }
       for (uint64_t m = rows.long_mask; m; m &= m - 1) {          // long rows: all four waves on each
         const int rr = __builtin_ctzll(m);
         const int64_t r = r_begin + rr;
-        const int64_t slice = r / N;
+        const int64_t slice = slice0;
         const int64_t beg = readlane64(rows.beg, rr), end = readlane64(rows.end, rr);
         float4 acc;
         if (giant.rows && end - beg > kGiantRow) {               // summed chunk by chunk in front of this launch
@@ -305,7 +319,7 @@ extern "C" int tmgcn_spmm_csr_batched_f32_plan(const int64_t* rowptr, const int3
     const int F4 = F / 4;
     int lpr = 4;
     while (lpr < F4 && lpr < 64) lpr <<= 1;                 // F > 256: 64 lanes, column chunks of 256 floats
-    const int64_t n_tiles = (n_rows + kTileRows - 1) / kTileRows;
+    const int64_t n_tiles = make_tile_map(n_rows, N).n_tiles;
     TMGCN_REQUIRE(n_tiles < (int64_t)0x7fffffff, "spmm: too many row tiles");
     GiantPlan giant{nullptr, nullptr, nullptr, 0};
     if (n_giant > 0) {
@@ -320,9 +334,9 @@ extern "C" int tmgcn_spmm_csr_batched_f32_plan(const int64_t* rowptr, const int3
     float4* Y4 = reinterpret_cast<float4*>(Y);
 #define TMGCN_VEC_CASE(L, UU)                                                                \
   case L: {                                                                                  \
-    int64_t gx = 2 * (int64_t)persistent_grid(spmm_vec4_kernel<L, UU>, 256);                 \
+    int64_t gx = 2 * (int64_t)persistent_grid(spmm_vec4_kernel<L, UU, TMGCN_SPMM_US * UU>, 256);         \
     if (gx > n_tiles) gx = n_tiles;                                                          \
-    hipLaunchKernelGGL((spmm_vec4_kernel<L, UU>), dim3((unsigned)gx), dim3(256), 0, st,      \
+    hipLaunchKernelGGL((spmm_vec4_kernel<L, UU, TMGCN_SPMM_US * UU>), dim3((unsigned)gx), dim3(256), 0, st, \
                        rowptr, col, val, X4, Y4, n_rows, N, F4, counter, giant);             \
     break;                                                                                   \
   }

@@ -50,13 +50,16 @@ struct FusedArgs {
   float* AX;        // optional: the SpMM result itself ([n_rows][K]), for dW
   float* pre;       // optional: pre-activation
   int32_t act;
-  int64_t tiles_per_batch;
+  TileMap tiles;               // tiles restart at every slice (spmm_row.h), whatever the weight layout
   int64_t n_tiles;
   unsigned int* tile_counter;  // dynamic tile scheduling (common.h): two counters, [0] tiles, [1] scan windows (spmm_row.h)
   GiantPlan giant;             // rows summed chunk by chunk in front of this launch (spmm_row.h), or rows == nullptr
 };
 
-template <int LPR, int U, int NJ>  // NJ = K / 8 (K is a multiple of 8 here)
+#ifndef TMGCN_FUSED_US
+#define TMGCN_FUSED_US 1    // gathers in flight per lane on short tiles, as a multiple of U
+#endif
+template <int LPR, int U, int NJ, int US = TMGCN_FUSED_US * U>  // NJ = K / 8 (K is a multiple of 8 here)
 __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedArgs a) {
   __shared__ float As[FBM * FLDA];
   __shared__ float4 s_part[4 * LPR];      // partial sums of a long row, one per wave (spmm_row.h)
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
   const int F4 = a.K / 4;
   constexpr int nj = NJ;
   const int n0 = wave * 32;
-  const TileMap tm{a.n_rows, a.rows_per_batch ? a.rows_per_batch : a.n_rows, a.tiles_per_batch, a.n_tiles};
+  const TileMap tm = a.tiles;
 
   float wreg[NJ][4];
   int64_t cur_batch = -1;
@@ -87,8 +90,9 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
       tile = s_tile;
       if (tile >= a.n_tiles) break;
     }
-    int64_t batch, row0, row_end;
-    tile_extent(tm, tile, batch, row0, row_end);
+    int64_t unit, row0, row_end;
+    tile_extent(tm, tile, unit, row0, row_end);
+    const int64_t batch = a.rows_per_batch ? row0 / a.rows_per_batch : 0;
     TileRows rows;
     rows.load(a.rowptr, row0, row_end, lane);
     if (TMGCN_HEAVY_FIRST && !scanning && rows.entries > heavy.thr) {   // done in somebody's pass 1
@@ -112,8 +116,20 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
       cur_batch = batch;
     }
 
-    // ---- phase 1: gather 16 rows per wave into the LDS tile; long rows afterwards, on all four waves
-    for (int rr = wave; rr < FBM; rr += 4) {
+    // ---- phase 1: gather 16 rows per wave into the LDS tile; long rows afterwards, on all four waves;
+    //      a tile of few entries entry-major, several rows per wave at once (spmm_row.h "Short tiles")
+    const int n_tile_rows = row_end - row0 < FBM ? (int)(row_end - row0) : FBM;
+    const int64_t slice0 = row0 / a.N;
+    const bool is_short = short_tile(rows, row0 + n_tile_rows <= (slice0 + 1) * a.N);
+    if (is_short)
+      gather_short_tile<LPR, US>(a.col, a.val, a.X + slice0 * (int64_t)a.N * F4, rows, n_tile_rows, F4, lane, wave, F4,
+                                 [&](int rr, const float4& acc, int fl) {
+                                   if (fl < F4) {
+                                     *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * fl]) = acc;
+                                     if (a.AX) store_f4(&reinterpret_cast<float4*>(a.AX)[(row0 + rr) * F4 + fl], acc);
+                                   }
+                                 });
+    for (int rr = wave; rr < (is_short ? 0 : FBM); rr += 4) {
       const int64_t r = row0 + rr;
       const bool lng = (rows.long_mask >> rr) & 1;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -299,7 +315,7 @@ extern "C" int tmgcn_spmm_gemm_f32_plan(const int64_t* rowptr, const int32_t* co
   TMGCN_REQUIRE(n_rows % N == 0, "spmm_gemm: n_rows=%lld is not a multiple of N=%d", (long long)n_rows, N);
   if (fused_small_ok(K, Nf)) {
     FusedArgs s{rowptr, col, val, reinterpret_cast<const float4*>(X), n_rows, N, K, W, Nf, trans_w,
-                rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0, nullptr, GiantPlan{nullptr, nullptr, nullptr, 0}};
+                rows_per_batch, w_batch_stride, Y, AX, pre_act, act, TileMap{0, 0, 0, 0}, 0, nullptr, GiantPlan{nullptr, nullptr, nullptr, 0}};
     // lanes per row: from the caller's average row length where it is known (as in
     // tmgcn_spmm_csr_batched_f32_hint), else 8 — the row lengths live on the device and the
     // reference's M-transformed adjacencies have tens of entries per row
@@ -321,17 +337,16 @@ extern "C" int tmgcn_spmm_gemm_f32_plan(const int64_t* rowptr, const int32_t* co
   TMGCN_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 && (!AX || reinterpret_cast<uintptr_t>(AX) % 16 == 0),
                 "spmm_gemm: X / AX must be 16-byte aligned");
   FusedArgs a{rowptr, col, val, reinterpret_cast<const float4*>(X), n_rows, N, K, W, Nf, trans_w,
-              rows_per_batch, w_batch_stride, Y, AX, pre_act, act, 0, 0, nullptr, GiantPlan{nullptr, nullptr, nullptr, 0}};
+              rows_per_batch, w_batch_stride, Y, AX, pre_act, act, TileMap{0, 0, 0, 0}, 0, nullptr, GiantPlan{nullptr, nullptr, nullptr, 0}};
   if (n_giant > 0) {
     const int rc = launch_giant_partial("spmm_gemm (giant rows)", rowptr, col, val, X, N, K, giant_rows, giant_chunks, n_giant,
                                         n_giant_chunks, giant_ws, giant_ws_bytes, (hipStream_t)stream);
     if (rc != TMGCN_OK) return rc;
     a.giant = GiantPlan{giant_rows, giant_chunks, reinterpret_cast<const float4*>(giant_ws), n_giant};
   }
-  const int64_t br = rows_per_batch ? rows_per_batch : n_rows;
-  const int64_t nb = (n_rows + br - 1) / br;
-  a.tiles_per_batch = (br + FBM - 1) / FBM;
-  a.n_tiles = nb * a.tiles_per_batch;
+  // a unit of tiles = a slice, unless the caller's weight batches do not end on slice boundaries (no layer does that)
+  a.tiles = make_tile_map(n_rows, (rows_per_batch == 0 || rows_per_batch % N == 0) ? (int64_t)N : rows_per_batch);
+  a.n_tiles = a.tiles.n_tiles;
   TMGCN_REQUIRE(a.n_tiles < (int64_t)0x7fffffff, "spmm_gemm: too many row tiles");
   a.tile_counter = acquire_tile_counters((hipStream_t)stream, 2);      // [0] the main loop's tiles, [1] the heavy-tile scan windows
   TMGCN_REQUIRE(a.tile_counter, "spmm_gemm: no tile counter: %s", pool_error());

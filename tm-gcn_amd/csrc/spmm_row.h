@@ -100,14 +100,22 @@ __device__ __forceinline__ int64_t readlane64(int64_t v, int l) {   // l wave-un
   return ((int64_t)hi << 32) | lo;
 }
 
-// tile -> rows: tiles restart at every batch (one W per slice) or run over all rows (tiles_per_batch = n_tiles)
+// tile -> rows.  Tiles restart at every UNIT of rows — a slice (N rows) in every launch the layers make — in the plain and in
+// the fused kernel alike: a tile never straddles two slices, and a row falls into the same tile whichever kernel, weight
+// layout (shared / per slice) or slice window (the pipelined one-slice launches of dist.py) it is summed under.  Which path
+// sums a row (row per wave, four waves, entry-major) is a function of its tile, so this is what keeps all of them bit-equal.
 struct TileMap {
-  int64_t n_rows, batch_rows, tiles_per_batch, n_tiles;
+  int64_t n_rows, unit_rows, tiles_per_unit, n_tiles;
 };
-__device__ __forceinline__ void tile_extent(const TileMap& m, int64_t tile, int64_t& batch, int64_t& row0, int64_t& row_end) {
-  batch = tile / m.tiles_per_batch;
-  row0 = batch * m.batch_rows + (tile - batch * m.tiles_per_batch) * kTileRows;
-  row_end = (batch + 1) * m.batch_rows;
+__host__ __device__ __forceinline__ TileMap make_tile_map(int64_t n_rows, int64_t unit_rows) {
+  const int64_t per = (unit_rows + 63) / 64;
+  return TileMap{n_rows, unit_rows, per, ((n_rows + unit_rows - 1) / unit_rows) * per};
+}
+// first row of the tile and the end of its unit (the tile holds rows [row0, min(row0 + 64, row_end)))
+__device__ __forceinline__ void tile_extent(const TileMap& m, int64_t tile, int64_t& unit, int64_t& row0, int64_t& row_end) {
+  unit = tile / m.tiles_per_unit;
+  row0 = unit * m.unit_rows + (tile - unit * m.tiles_per_unit) * kTileRows;
+  row_end = (unit + 1) * m.unit_rows;
   if (row_end > m.n_rows) row_end = m.n_rows;
 }
 
@@ -201,6 +209,98 @@ __device__ __forceinline__ float4 gather_long_row(const int32_t* __restrict__ co
   }
   __syncthreads();
   return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Short tiles (round 6).  The reference's real operand — the M-product of its symmetrised, windowed chess slices,
+// read_data.py:116-127, 204-223 — holds 4 entries per row on average and the self loop alone in two rows of three.  One wave
+// per row then spends two dependent round trips (col / val, then ONE gather on half of its lanes) per row, sixteen rows one
+// after the other per wave and tile: the launch is a latency chain (measured: fused forward 23.6 ms where its compulsory bytes
+// are 6.3 ms of HBM time and its products 6.7 ms of MFMA time).  A tile of at most kShortTile entries without a long row is
+// therefore walked ENTRY-major: wave w owns tile rows [16w, 16w+16), each of its S = 64/LPR lane groups RG = 16/S consecutive
+// rows of those — a CONTIGUOUS run of entries, fetched LPR at a time with one coalesced load per array; every lane finds the
+// row of the entry it loaded by comparing its position with the group's row ends; the group then walks its entries in order,
+// U gathers in flight whatever rows they belong to, and hands a row's sum to `flush` when the row changes.  A row is summed
+// by ONE group in entry order (an fmaf chain: bitwise the serial sum); no atomics, no LDS, reproducible.  The predicate is a
+// function of the tile's row pointers alone, so the plain and the fused kernel, and every rerun, take the same path.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef TMGCN_SHORT_TILE
+#define TMGCN_SHORT_TILE 512
+#endif
+constexpr int kShortTile = TMGCN_SHORT_TILE;      // entries: a mean of at most 8 per row
+
+// flush(tile_row, sum, fl): called by the LPR lanes of the owning group (lane fl of the group holds float4 fl of the sum)
+// once for every row r < n_tile_rows of the wave's sixteen.  Xs = X of the tile's slice (a short tile lies in ONE slice).
+// The shuffles that hand out an entry's value and row run AFTER the batch's gathers are issued: only the U float4 in
+// flight and the lane's own (col, val, row) are live across the loads.
+template <int LPR, int U, class Flush>
+__device__ __forceinline__ void gather_short_tile(const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                  const float4* __restrict__ Xs, const TileRows& rows, int n_tile_rows,
+                                                  int F4, int lane, int wave, int stride4, Flush&& flush) {
+  constexpr int S = kWave / LPR;
+  constexpr int RG = 16 / S > 0 ? 16 / S : 1;      // LPR = 4 (F = 16): sixteen groups of one row
+  static_assert(S * RG == 16, "a wave owns sixteen tile rows");
+  const int sub = lane / LPR;
+  const int fl = lane % LPR;
+  const bool f_ok = fl < F4;
+  const int g0 = 16 * wave + sub * RG;             // first tile row of this lane's group
+  // row extents relative to the tile's first entry (<= kShortTile: int32); rows behind the tile's last are empty at its end
+  const int64_t tile_beg = readlane64(rows.beg, 0);
+  const int tile_ent = (int)rows.entries;
+  const int re = lane < n_tile_rows ? (int)(rows.end - tile_beg) : tile_ent;
+  const int gprev = __shfl(re, g0 ? g0 - 1 : 0);  // every lane takes part: ds_bpermute reads 0 from an inactive lane
+  const int gb = g0 ? gprev : 0, ge = __shfl(re, g0 + RG - 1);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cur = -1;
+  for (int b0 = gb; __any(b0 < ge); b0 += LPR) {
+    const int e = b0 + fl;                         // the entry this lane fetches for its group
+    int c = 0, rid = g0;
+    float v = 0.f;
+    if (e < ge) {
+      c = col[tile_beg + e];
+      v = val[tile_beg + e];
+    }
+#pragma unroll
+    for (int j = 0; j < RG; ++j) rid += __shfl(re, g0 + j) <= e;   // + the rows of the group that end at or before e
+    const int nb = ge - b0 < LPR ? ge - b0 : LPR;  // entries of this batch (<= 0: the group is done)
+    for (int p = 0; __any(p < nb); p += U) {
+      float4 x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cc = __shfl(c, sub * LPR + ((p + u) & (LPR - 1)));
+        x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p + u < nb && f_ok) x[u] = Xs[(int64_t)cc * stride4 + fl];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = sub * LPR + ((p + u) & (LPR - 1));
+        const float vv = __shfl(v, src);
+        const int rr = __shfl(rid, src);
+        if (p + u < nb) {
+          if (rr != cur) {
+            if (cur >= 0) flush(cur, acc, fl);
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            cur = rr;
+          }
+          acc.x = fmaf(vv, x[u].x, acc.x);
+          acc.y = fmaf(vv, x[u].y, acc.y);
+          acc.z = fmaf(vv, x[u].z, acc.z);
+          acc.w = fmaf(vv, x[u].w, acc.w);
+        }
+      }
+    }
+  }
+  if (cur >= 0) flush(cur, acc, fl);
+  // rows without entries are never met by the walk: their sum is zero
+  const uint64_t empty = __ballot(lane < n_tile_rows && rows.end == rows.beg) & (0xffffull << (16 * wave));
+  for (uint64_t m = empty; m; m &= m - 1)
+    if (sub == 0) flush(__builtin_ctzll(m), make_float4(0.f, 0.f, 0.f, 0.f), fl);
+}
+
+// Does the tile take the entry-major walk?  Block-uniform (every wave holds the same TileRows).  `one_slice`: all its rows
+// gather from the same slice of X (always, when tiles restart at every slice: TileMap).
+__device__ __forceinline__ bool short_tile(const TileRows& rows, bool one_slice) {
+  return kShortTile > 0 && rows.long_mask == 0 && rows.entries <= kShortTile && one_slice;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -331,10 +331,73 @@ def device_powerlaw_csr(T: int, N: int, deg: int, device, first_slice: int = 0, 
     return BatchedCSR(rowptr, torch.cat(cols), torch.cat(vals), T, N)
 
 
+# ---------------------------------------------------------------------------------------
+# S4 on the reference's REAL operand structure: a shipped adjacency replicated on the block diagonal
+# ---------------------------------------------------------------------------------------
+# The generators above draw columns uniformly and give no row fewer than 7 entries.  The one operand the
+# reference ships — the M-product of its symmetrised, windowed chess slices (read_data.py:116-127, 204-223;
+# N = 7 301, T = 80) — has 3.97 entries per row on average, half of its rows holding the self loop only, and
+# columns that stay inside communities.  `tile_block_diagonal` scales such an adjacency to bench size WITHOUT
+# changing either property: `reps` copies of every chosen slice on the block diagonal (a REPLICATION, not a
+# larger real graph: copy q's rows reference only copy q's columns).
+def tile_block_diagonal(A: BatchedCSR, reps: int, slices: Optional[List[int]] = None) -> BatchedCSR:
+    """Slices `slices` (default: all) of A, each as `reps` copies of itself on the block diagonal:
+    a BatchedCSR with T = len(slices), N = reps · A.N; row q·A.N + i of new slice s is row i of A's slice
+    slices[s] with its columns shifted by q·A.N.  Row lengths, values and the order inside a row are kept."""
+    ks = list(range(A.T)) if slices is None else [int(k) for k in slices]
+    N0, dev = A.N, A.device
+    bounds = A.rowptr[::N0].tolist()
+    shift = (torch.arange(reps, device=dev, dtype=torch.int32) * N0)[:, None]
+    cnt = A.rowptr[1:] - A.rowptr[:-1]
+    cols, vals, cnts = [], [], []
+    for k in ks:
+        a, b = bounds[k], bounds[k + 1]
+        cols.append((A.col[a:b][None, :] + shift).reshape(-1))
+        vals.append(A.val[a:b].repeat(reps))
+        cnts.append(cnt[k * N0:(k + 1) * N0].repeat(reps))
+    rowptr = torch.zeros(len(ks) * reps * N0 + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.cat(cnts), 0, out=rowptr[1:])
+    return BatchedCSR(rowptr, torch.cat(cols), torch.cat(vals), len(ks), reps * N0)
+
+
+_REAL_OPERAND: dict = {}
+
+
+def chess_operand(device, fixture: Optional[str] = None) -> BatchedCSR:
+    """The reference's own operand: Ât of its chess data (experiment_chess_our.py's 80 training slices of 7 301
+    players; read_data.py's symmetrise / edge-life 10 / normalise / M-product with its 20-diagonal band), built
+    by the device adjacency pipeline from the raw edge list of fixture G10 (tests/golden/g10_chess_full.npz: the
+    reference's data/chess/out.chess.csv as (slice, i, j) rows).  Cached per device."""
+    import os
+    key = str(device)
+    if key not in _REAL_OPERAND:
+        from . import adjacency
+        if fixture is None:
+            fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g10_chess_full.npz")
+        d = np.load(fixture)
+        TT, N, T = int(d["TT"]), int(d["N"]), int(d["S_train"])
+        k, i, j = (d[n].astype(np.int64) for n in ("raw_k", "raw_i", "raw_j"))
+        Chat, _ = adjacency.build_adjacency(k, i, j, np.ones(len(k), np.float32), TT, N, M=None, window=10, device=device)
+        _REAL_OPERAND[key] = adjacency.m_product_csr(Chat.slices(0, T), d["M"])
+    return _REAL_OPERAND[key]
+
+
+def device_chess_tiled_csr(T: int, N: int, device, first_slice: int = 0) -> BatchedCSR:
+    """T slices of the chess operand tiled to about N nodes (reps = round(N / 7 301) copies on the block
+    diagonal).  Global slice g of the tiled tensor is chess slice (5·g + 4) mod 80 — every fifth slice, so that
+    16 slices span the sparse early months and the dense late ones alike; any rank can build its own slices."""
+    A = chess_operand(device)
+    reps = max(1, int(round(N / A.N)))
+    return tile_block_diagonal(A, reps, [(5 * (first_slice + s) + 4) % A.T for s in range(T)])
+
+
 def device_csr(kind: str, T: int, N: int, deg: int, device, first_slice: int = 0) -> BatchedCSR:
-    """The S4 adjacency by name: "er" (the headline), "powerlaw", "powerlaw_sym"."""
+    """The S4 adjacency by name: "er" (the headline), "powerlaw", "powerlaw_sym", "chess_tiled"
+    (the reference's real operand replicated on the block diagonal; `deg` unused, N rounded to a multiple of 7 301)."""
     if kind == "er":
         return device_er_csr(T, N, deg, device, first_slice)
     if kind in ("powerlaw", "powerlaw_sym"):
         return device_powerlaw_csr(T, N, deg, device, first_slice, symmetric=kind == "powerlaw_sym")
+    if kind == "chess_tiled":
+        return device_chess_tiled_csr(T, N, device, first_slice)
     raise ValueError(f"unknown graph kind {kind!r}")

@@ -30,7 +30,8 @@ for n in names:
 
 T, N, F, deg = (int(os.environ.get("AB_T", 4)), int(os.environ.get("AB_N", 2_000_000)), int(os.environ.get("AB_F", 128)),
                 int(os.environ.get("AB_DEG", 32)))
-A = synth.device_csr(os.environ.get("AB_GRAPH", "er"), T, N, deg, "cuda")       # er | powerlaw | powerlaw_sym
+A = synth.device_csr(os.environ.get("AB_GRAPH", "er"), T, N, deg, "cuda")       # er | powerlaw | powerlaw_sym | chess_tiled
+N = A.N                                                                          # chess_tiled rounds N to a multiple of 7 301
 X = torch.rand(T, N, F, device="cuda")
 W = torch.randn(F, F, device="cuda") * 0.1
 Y = torch.empty_like(X)
