@@ -85,14 +85,60 @@ open(os.path.join(out, "host", "1", "x_counter_collection.csv"), "w").write("\\n
     script.chmod(script.stat().st_mode | stat.S_IEXEC)
     monkeypatch.setenv("PATH", str(fake) + os.pathsep + os.environ["PATH"])
     args = bench.parse([])
-    total, src = bench.measure_traffic(args)
-    assert total == int(270883771.9 * 1024 * 2 + 32031017.0 * 1024)              # the forward launch (larger WRITE_SIZE)
+    src, why = bench.measure_traffic(args)
+    assert why is None
+    assert src["forward_bytes"] == int(270883771.9 * 1024 * 2 + 32031017.0 * 1024)    # the forward launch (larger WRITE_SIZE)
     assert src["kind"] == "measured in this run" and src["dispatches"] == 6
     assert abs(src["fetch_x2_calibration_on_band_mtransform"] - 2.0) < 1e-3        # 16.384 GB read exactly / raw counter
-    assert src["backward_launch_bytes"] == int(271501397.5 * 1024 * 2 + 16031017.2 * 1024)
+    assert src["backward_bytes"] == int(271501397.5 * 1024 * 2 + 16031017.2 * 1024)
+    # another workload's passes (a side leg): the child command line carries ITS shape, the calibration its slab
+    src, why = bench.measure_traffic(args, what="T128", nodes=250_000, slices_per_gpu=128)
+    assert why is None and abs(src["fetch_x2_calibration_on_band_mtransform"] - 2.0) < 1e-3
     monkeypatch.setenv("FAKE_ROCPROF_FAIL", "1")
-    total, why = bench.measure_traffic(args)
-    assert total is None and "exited 7" in why
+    src, why = bench.measure_traffic(args)
+    assert src is None and "exited 7" in why
+
+
+def test_launch_roofline_takes_measured_bytes_only_below_0p8_of_the_model():
+    """`if FETCH_SIZE + WRITE_SIZE is < 0.8x the gather model, use the measured bytes`; a launch is never quoted
+    above what it moved (the skewed leg's backward stood at 1.11x peak on model bytes)."""
+    import bench
+    model = 557.4e9
+    a = bench.launch_roofline(model, 0.97 * model, 80.0)
+    assert a["basis"] == "model" and abs(a["frac"] - model / 0.080 / 8e12) < 1e-9
+    b = bench.launch_roofline(model, 300e9, 62.68)                            # hubs' rows re-read from cache
+    assert b["basis"] == "measured" and b["frac"] < 0.61 and b["frac_model"] > 1.1
+    c = bench.launch_roofline(model, None, 62.68)                             # nothing measured: the model, flagged by frac_model == frac
+    assert c["basis"] == "model" and c["measured_bytes"] is None
+    d = bench.launch_roofline(model, 0.87 * model, 62.68)                     # 0.87x: not below 0.8x, but the model says 1.11x peak
+    assert d["basis"] == "measured" and d["frac"] < 1.0 < d["frac_model"]
+
+
+def test_side_leg_record_is_composed_from_the_child_line(monkeypatch):
+    """bench.measure_leg without a GPU: the child run and its two PMC passes are replaced by canned records; the leg's
+    frac is (bytes used forward + backward) / (their time) / peak with each launch on its prescribed basis."""
+    import bench
+    args = bench.parse([])
+    child = {"config": {"workload": "w", "row_lengths": {"mean": 4.0}}, "kernels_ms": {"mtransform": 5.9},
+             "roofline": {"bytes_per_edge_slice": 647.0, "edge_slices_per_launch": 1.3e8, "forward_launch_ms": 20.0,
+                          "backward_launch_ms": 18.0}, "ms_per_step": 60.0, "steps": 5, "value": 1e9,
+             "verify": {"ok": True, "max_rel_err_Y": 1e-7, "max_rel_err_dX": 1e-7, "max_rel_err_dW": 1e-6, "seconds": 3.0}}
+    seen = {}
+
+    def fake_child(flags, what, timeout=420):
+        seen["flags"] = flags
+        return child, 0, None
+
+    monkeypatch.setattr(bench, "run_child", fake_child)
+    monkeypatch.setattr(bench, "measure_traffic", lambda a, what="x", **over: ({"forward_bytes": 50e9, "backward_bytes": 80e9}, None))
+    rec = bench.measure_leg(args, "real_structure")
+    assert "chess_tiled" in seen["flags"] and rec["verify_ok"] is True
+    model = 647.0 * 1.3e8
+    assert rec["forward"]["basis"] == "measured" and rec["backward"]["basis"] == "model"      # 50 < 0.8 x 84.1 <= 80
+    assert abs(rec["frac"] - (50e9 + model) / 0.038 / 8e12) < 1e-9
+    assert abs(rec["mfma"]["flops_per_launch"] - 2 * (1.3e8 / 4.0) * 128 * 128) < 1
+    rec = bench.measure_leg(args, "T128")
+    assert seen["flags"][seen["flags"].index("--slices-per-gpu") + 1] == "128" and seen["flags"][seen["flags"].index("--nodes") + 1] == "250000"
 
 
 def test_timeline_gaps_tool_unions_overlapping_kernels(tmp_path):

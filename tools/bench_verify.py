@@ -85,12 +85,15 @@ def _spmm64(A, kk, X64, row_block=125_000):
 
 
 def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N, W, X, dY, Y, dX, dW,
-                 x_slice, dy_slice, a_slice, rows=128, tol=1e-5, seed=4242, fp64_dw=True):
+                 x_slice, dy_slice, a_slice, rows=128, tol=1e-5, seed=4242, fp64_dw=True, y_slices=None):
     """See the module docstring.  A: this rank's resident BatchedCSR (Tl slices); M64: [T,T] fp64
     numpy/torch; X, dY, Y, dX, dW: the step's tensors on this rank (X/dX node-sharded [T, N/G, F] when
     `node_sharded_input`, else slice-sharded [Tl, N, F]; dY/Y slice-sharded).  x_slice(j) -> [N,F] of
     input slice j, dy_slice(k) -> [N,F] of upstream-gradient slice k, a_slice(k) -> one-slice
     BatchedCSR of adjacency slice k — all REGENERATED from seeds, for any rank's data.
+    y_slices: check the rows of Y on that many evenly spaced local slices (the first and the last among them) instead of
+    on every one — the T = 128 leg of bench.py; dX (which every slice reaches through Mᵀ), dW and the identities always
+    cover all of them.
     Returns the `verify` record (errors are MAX over ranks); `ok` is the collective verdict."""
     # all ranks of a node check at the same time on the same host cores: give each its share
     # (libgomp reads OMP_NUM_THREADS when the oracle library is first loaded)
@@ -121,16 +124,19 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
     # ------------------------------------------------------------------ Y (and the fp64 dW partial)
     S = min(rows, N)
     ids = [torch.randperm(N, generator=g)[:S].sort().values.to(dev) for _ in range(Tl)]
-    segs = []
-    for kk in range(Tl):
+    check = list(range(Tl))
+    if y_slices is not None and 1 < y_slices < Tl:
+        check = sorted({round(i * (Tl - 1) / (y_slices - 1)) for i in range(y_slices)})
+    segs = {}
+    for kk in check:
         sub, off = _segments(A.rowptr, A.col, A.val, ids[kk] + kk * N)
-        segs.append((sub, A.col[off].long(), A.val[off].cpu()))
+        segs[kk] = (sub, A.col[off].long(), A.val[off].cpu())
     local_rows = M[k0:k0 + Tl]                                         # this rank's rows of M
     needed_j = torch.nonzero((local_rows != 0).any(0)).reshape(-1).tolist()
     # fibres of the neighbour columns, only the input slices M actually mixes into this rank's
     # output slices (band-M: Tl + b - 1 of T), in `needed_j` order
     Tn = len(needed_j)
-    fib = [torch.zeros(Tn, int(s[0][-1]), F, dtype=torch.float32) for s in segs]
+    fib = {kk: torch.zeros(Tn, int(segs[kk][0][-1]), F, dtype=torch.float32) for kk in check}
     want64 = fp64_dw
     if want64 and dev.type == "cuda":
         free_b, _ = torch.cuda.mem_get_info(dev)
@@ -145,15 +151,26 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
     Xt64 = torch.zeros(Tl, N, F, dtype=torch.float64, device=dev) if want64 else None
     for jj, j in enumerate(needed_j):
         Xj = x_slice(j)
-        for kk in range(Tl):
-            m = float(local_rows[kk, j])
-            if m != 0.0:
-                fib[kk][jj] = Xj[segs[kk][1]].cpu()
-                if Xt64 is not None:
-                    Xt64[kk].add_(Xj.double(), alpha=m)
+        hit = [kk for kk in check if float(local_rows[kk, j]) != 0.0]
+        if hit:
+            # one gather and one device-to-host copy per input slice (T = 128: 20 output slices share it), then split
+            rows_j = Xj[torch.cat([segs[kk][1] for kk in hit])].cpu()
+            at = 0
+            for kk in hit:
+                n = int(segs[kk][1].numel())
+                fib[kk][jj] = rows_j[at:at + n]
+                at += n
+            del rows_j
+        if Xt64 is not None:
+            Xd = Xj.double()
+            for kk in range(Tl):
+                m = float(local_rows[kk, j])
+                if m != 0.0:
+                    Xt64[kk].add_(Xd, alpha=m)
+            del Xd
         del Xj
     worst = 0.0
-    for kk in range(Tl):
+    for kk in check:
         sub, _cols, val = segs[kk]
         nnz = int(sub[-1])
         xt = torch.empty(1, nnz, F, dtype=torch.float32)
@@ -246,7 +263,7 @@ def verify_layer(*, dist, rank, world, dev, node_sharded_input, A, M64, T, k0, N
         dist.all_reduce(vec, op=dist.ReduceOp.MAX)
     out = {k: (None if v < 0 else float(v)) for k, v in zip(keys, vec.tolist())}
     ok = all(v <= tol for k, v in out.items() if v is not None)
-    out.update({"rows_Y_per_slice": S, "slices_checked": Tl * world, "nodes_dX": Sx, "tol": tol, "ok": bool(ok),
+    out.update({"rows_Y_per_slice": S, "slices_checked": len(check) * world, "slices_local": Tl, "nodes_dX": Sx, "tol": tol, "ok": bool(ok),
                 "dW_reference": "fp64 product of the regenerated inputs on the device (torch ops), all-reduced in fp64"
                 if out.get("max_rel_err_dW") is not None else "skipped: not enough free memory for the fp64 [T/G,N,F] buffer",
                 "reference": "oracle/tmgcn_ref.c (ref_mtransform_rows, ref_spmm, ref_gemm, ref_mtransform) on inputs regenerated "
