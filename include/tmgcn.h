@@ -353,9 +353,9 @@ int tmgcn_wce_bwd_f32(const float* logits, const int64_t* target, const float* w
  * no atomics, the tail reduction done by the last block: bitwise reproducible.
  *   eptr[R+1], ent[2E]   the inverted edge index of tmgcn_edge_head_bwd_i32_f32 (entry = 2*edge + role);
  *                        ent is read only when the logits are stored
- *   arow[n_active][4]    the rows with at least one entry, ascending: (row, eptr[row], eptr[row+1], 0), 16-byte aligned
  *   other[2E]            row index of the OTHER endpoint of each entry's edge
- *   arow[n_active][4]    (row, first entry, end entry, part) of every row with entries.  part = 0: the whole row.  A caller may
+ *   arow[n_active][4]    (row, first entry, end entry, part) of every row with entries, ascending, 16-byte aligned;
+ *                        n_active < 2^31.  part = 0: the whole row, i.e. (row, eptr[row], eptr[row+1], 0).  A caller may
  *                        SPLIT a long row (a hub of the labelled edges: a group of at most 16 lanes walks a row's entries) into
  *                        several consecutive ranges, part = 1, 2, … numbered over ALL split rows of the plan: every sum this
  *                        kernel forms is linear in the entries, so parts are independent — except that a part's share of dZ[row]

@@ -209,6 +209,92 @@ def test_host_operands_cross_pcie_once():
     assert float((out + big).sum()) == 600_004.0 and big._tmgcn_uploads == 2
 
 
+def _plain_logits(m):
+    """The logits of the model's CURRENT parameters through the plain route (no placeholder), detached."""
+    from tmgcn_amd import hosted as hosted_mod
+    hosted_mod.LAZY_LOGITS = False
+    try:
+        with torch.no_grad():
+            return m().detach().as_subclass(torch.Tensor).clone()
+    finally:
+        hosted_mod.LAZY_LOGITS = True
+
+
+def test_lazy_logits_after_a_step_behind_a_custom_loss_and_second_loss_terms():
+    """(i) `out = gcn(); <a loss F.cross_entropy never sees>; backward; optimizer.step(); out.argmax()` — a path the reference
+    supports — returns the logits of the pre-step parameters; (ii) a second loss term on the output is differentiated
+    (after the fused criterion call the placeholder held DETACHED logits and the term contributed no gradient):
+    every parameter gradient equals the LAZY_LOGITS = False run's; (iii) nn.CrossEntropyLoss on the placeholder still
+    reaches the one-pass kernel and on a formed DeviceResult the fused weighted-CE kernel (the interception rides on
+    `func is F.cross_entropy` inside __torch_function__: a torch upgrade that changes it fails HERE)."""
+    import tmgcn_amd.layers as layers
+    from tmgcn_amd import hosted as hosted_mod
+    from tmgcn_amd.hosted import LazyLogits
+    g = torch.Generator().manual_seed(8)
+    for no_layers in (1, 2):
+        def make():
+            torch.manual_seed(13)
+            Ct_train, X_train, e, M = _inputs()
+            if no_layers == 1:
+                return ehf.EmbeddingGCN(Ct_train, X_train, e, M, hidden_feat=[6, 2], condensed_W=True, use_Minv=False), e
+            return ehf.EmbeddingGCN2(Ct_train, X_train, e, M, hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False, nonlin2="selu"), e
+        # (i) custom loss, step, late read
+        m, e = make()
+        opt = torch.optim.SGD(m.parameters(), lr=0.5)
+        target = torch.randint(0, 2, (e.shape[1],), generator=g)
+        out = m()
+        assert type(out) is LazyLogits
+        pre = _plain_logits(m)
+        custom = (out.softmax(1)[:, 0] - target.float()).pow(2).mean()          # never passes F.cross_entropy
+        custom.backward()
+        opt.step()
+        assert_close(out.detach().as_subclass(torch.Tensor), pre, 1e-6, "logits read after a step behind a custom loss")
+        opt.zero_grad()
+        out = m()                                                                # no loss at all, parameters moved, first read late
+        pre = _plain_logits(m)
+        with torch.no_grad():
+            m.U.mul_(1.5)
+        assert torch.equal(out.argmax(1).as_subclass(torch.Tensor), pre.argmax(1))
+        # (ii) criterion + a second term on the same output
+        grads = {}
+        for lazy in (True, False):
+            hosted_mod.LAZY_LOGITS = lazy
+            try:
+                m, e = make()
+                crit = nn.CrossEntropyLoss(weight=torch.tensor([0.7, 0.3]))
+                out = m()
+                assert (type(out) is LazyLogits) == lazy
+                loss = crit(out, target) + 0.1 * out.pow(2).mean() + 0.05 * crit(out, 1 - target)
+                loss.backward()
+                grads[lazy] = {n: q.grad.detach().clone() for n, q in m.named_parameters()}
+            finally:
+                hosted_mod.LAZY_LOGITS = True
+        for n in grads[True]:
+            assert_close(grads[True][n], grads[False][n], 1e-5, f"{no_layers}-layer d{n} with a second loss term")
+        # (iii) the interception itself
+        calls = {"head": 0, "ce": 0}
+        real_head, real_ce = hosted_mod._fused_head_loss, hosted_mod._fused_cross_entropy
+
+        def count_head(*a, **k):
+            calls["head"] += 1
+            return real_head(*a, **k)
+
+        def count_ce(*a, **k):
+            calls["ce"] += 1
+            return real_ce(*a, **k)
+        hosted_mod._fused_head_loss, hosted_mod._fused_cross_entropy = count_head, count_ce
+        try:
+            m, e = make()
+            crit = nn.CrossEntropyLoss(weight=torch.tensor([0.7, 0.3]))
+            crit(m(), target)                                                   # placeholder -> one-pass head + loss
+            assert calls == {"head": 1, "ce": 0}
+            with torch.no_grad():
+                crit(m(), target)                                               # evaluation: formed logits -> fused weighted CE
+            assert calls["ce"] == 1
+        finally:
+            hosted_mod._fused_head_loss, hosted_mod._fused_cross_entropy = real_head, real_ce
+
+
 def test_lazy_logits_are_the_values_before_the_step_and_form_on_demand():
     """Script mode, training epoch: gcn() returns a placeholder (hosted.LazyLogits); the criterion's one launch forms loss,
     gradients AND the logits — the values before optimizer.step(), which is what the scripts' accuracy lines read afterwards
@@ -256,12 +342,18 @@ def test_lazy_logits_are_the_values_before_the_step_and_form_on_demand():
                 assert torch.equal(guess_before, want.detach().argmax(1))
             for (n, p), q in zip(m.named_parameters(), ref.parameters()):
                 assert_close(p.detach(), q.detach(), 2e-6, f"{no_layers}-layer {n} after step {step}")
-        # never through the criterion, first read after a parameter changed: refused, with a message that says why
+        # never through the criterion, first read after a parameter changed (a custom loss, or none, then a step): the
+        # reference's output_train is an ordinary tensor and still holds the logits of the parameters gcn() ran with
+        # (experiment_reddit_our_link_prediction.py:78-87) — formed here from the snapshot gcn() took
         out = m()
+        want_pre = _plain_logits(m)
         with torch.no_grad():
-            m.U.add_(1.0)
-        with pytest.raises(RuntimeError, match="modified"):
-            out.sum()
+            for q in m.parameters():
+                q.add_(0.37)
+        got = out.argmax(1)
+        assert torch.equal(got.as_subclass(torch.Tensor), want_pre.argmax(1))
+        assert_close(out.detach().as_subclass(torch.Tensor), want_pre, 1e-6, f"{no_layers}-layer logits read first after the parameters moved")
+        assert not out.detach().requires_grad and not _plain_logits(m).allclose(want_pre)    # (the live parameters give other logits)
         # evaluation calls and the opt-out form the logits at once
         with torch.no_grad():
             assert type(m()) is DeviceResult

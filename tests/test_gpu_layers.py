@@ -267,6 +267,21 @@ def test_tiny_and_degenerate_inputs():
         ehf.EmbeddingGCN([a0, empty], X[:, :3], edges, M, hidden_feat=[3, 2], condensed_W=True, use_Minv=False)
 
 
+def test_graphed_train_step_refuses_a_parameter_the_model_does_not_own():
+    """an optimizer parameter that is not a parameter of one of the model's modules cannot be aliased for the
+    captured forward; it would silently never be updated.  Refused at construction, with a message that says why."""
+    from tmgcn_amd.graphs import GraphedTrainStep
+    from tmgcn_amd.losses import WeightedCrossEntropy
+    d = golden("g6_sgd_gcn2")
+    i = _inputs(d)
+    torch.manual_seed(0)
+    m = ehf.EmbeddingGCN2(i["At"], i["X"], i["edges"], i["M"], hidden_feat=[6, 6, 2], condensed_W=True, use_Minv=False, nonlin2="selu")
+    stray = torch.nn.Parameter(torch.zeros(3, device="cuda"))
+    opt = torch.optim.SGD(list(m.parameters()) + [stray], lr=0.01, momentum=0.9)
+    with pytest.raises(RuntimeError, match="not parameters of"):
+        GraphedTrainStep(m, WeightedCrossEntropy(torch.tensor([0.9, 0.1])).cuda(), opt, i["labels"].cuda(), warmup=3)
+
+
 def test_graphed_train_step_wide_features():
     """Graph capture also covers the persistent MFMA kernels (their tile counters are zeroed by a
     memset node that is captured with the launch)."""

@@ -78,3 +78,21 @@ def test_host_operands_are_uploaded_once_per_content_and_keep_no_module_state():
             small.add_(1.0)
             hosted._device_copy(small, dev)
     assert not got
+
+
+def test_cross_entropy_reaches_torch_function_as_F_cross_entropy():
+    """The script-mode criterion path (hosted.DeviceResult.__torch_function__) recognises `criterion(gcn(), target)` by
+    `func is F.cross_entropy`.  That nn.CrossEntropyLoss dispatches exactly that function object through
+    __torch_function__ is a property of the installed torch: this test is the guard for a torch upgrade."""
+    import torch.nn.functional as F
+    seen = []
+
+    class Probe(torch.Tensor):
+        @classmethod
+        def __torch_function__(cls, func, types, args=(), kwargs=None):
+            seen.append(func)
+            return super().__torch_function__(func, types, args, kwargs or {})
+
+    x = torch.randn(5, 3).as_subclass(Probe)
+    torch.nn.CrossEntropyLoss(weight=torch.tensor([0.2, 0.3, 0.5]))(x, torch.tensor([0, 1, 2, 1, 0]))
+    assert any(f is F.cross_entropy for f in seen), [getattr(f, "__name__", f) for f in seen]

@@ -26,6 +26,20 @@ import torch
 _GIANT_PLAN = os.environ.get("TMGCN_GIANT_PLAN", "1") != "0"      # A/B switch (tools/): 0 = never build a giant-row plan
 
 
+def _header_constants(*names):
+    """Integer #defines of include/tmgcn.h (the header the kernels were compiled against ships with the package)."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "tmgcn.h")
+    text = open(path).read()
+    out = []
+    for n in names:
+        m = re.search(r"^#define\s+" + n + r"\s+(\d+)\b", text, re.M)
+        if m is None:
+            raise RuntimeError(f"{n} is not defined in {path}")
+        out.append(int(m.group(1)))
+    return tuple(out)
+
+
 class BatchedCSR:
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, T: int, N: int):
         assert rowptr.dtype == torch.int64 and col.dtype == torch.int32 and val.dtype == torch.float32
@@ -258,7 +272,7 @@ class BatchedCSR:
             self._blocks[key] = self._heaviest_first(torch.unique(b))
         return self._blocks[key]
 
-    GIANT_ROW, GIANT_CHUNK = 32768, 4096          # include/tmgcn.h: TMGCN_GIANT_ROW, TMGCN_GIANT_CHUNK
+    GIANT_ROW, GIANT_CHUNK = _header_constants("TMGCN_GIANT_ROW", "TMGCN_GIANT_CHUNK")   # include/tmgcn.h: what the kernels compiled with
 
     def giant_plan(self):
         """The giant-row plan of the SpMM launchers (include/tmgcn.h "Giant rows"), cached: rows of more than GIANT_ROW

@@ -509,8 +509,9 @@ extern "C" int tmgcn_head_loss_f32(const float* Z, const float* W_fold, int32_t 
                                     void* workspace, int64_t workspace_bytes, int32_t* sync, void* stream) {
   TMGCN_REQUIRE(tmgcn_head_loss_supported(F, C, K), "head_loss: unsupported widths F=%d C=%d K=%d (even F <= 8, 2 <= C <= 4, K in {0, 2})",
                 F, C, K);
-  TMGCN_REQUIRE(R > 0 && E > 0 && R < (int64_t)0x7fffffff && 2 * E < (int64_t)0x7fffffff && n_active > 0 && n_active <= R + 2 * E,
-                "head_loss: need 0 < R, 2E < 2^31 and 0 < n_active <= R + 2E (got R=%lld E=%lld n_active=%lld)", (long long)R,
+  TMGCN_REQUIRE(R > 0 && E > 0 && R < (int64_t)0x7fffffff && 2 * E < (int64_t)0x7fffffff && n_active > 0 && n_active <= R + 2 * E &&
+                    n_active < (int64_t)0x7fffffff,
+                "head_loss: need 0 < R, 2E < 2^31 and 0 < n_active <= R + 2E, n_active < 2^31 (got R=%lld E=%lld n_active=%lld)", (long long)R,
                 (long long)E, (long long)n_active);
   TMGCN_REQUIRE(Z && U && eptr && arow && other && meta && class_count && weight && workspace, "head_loss: null pointer");
   if (!sync) sync = acquire_sync_word((hipStream_t)stream);

@@ -95,9 +95,10 @@ __global__ __launch_bounds__(256) void spmm_vec4_kernel(
         const int64_t slice = slice0;
         const int64_t beg = readlane64(rows.beg, rr), end = readlane64(rows.end, rr);
         float4 acc;
-        if (giant.rows && end - beg > kGiantRow) {               // summed chunk by chunk in front of this launch
+        const int gi = (giant.rows && end - beg > kGiantRow) ? giant_find(giant, r) : -1;   // block-uniform
+        if (gi >= 0) {                                           // summed chunk by chunk in front of this launch
           if (wave != (rr & 3)) continue;
-          acc = giant_row_sum(giant, r, F4, lane, c0, w4);
+          acc = giant_row_sum(giant, gi, F4, lane, c0, w4);
         } else {
           acc = gather_long_row<LPR, U>(col, val, X + slice * (int64_t)N * F4 + c0, beg, end, w4, lane, wave, s_part, F4);
         }

@@ -149,9 +149,10 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
       const int64_t slice = r / a.N;
       const int64_t beg = readlane64(rows.beg, rr), end = readlane64(rows.end, rr);
       float4 acc;
-      if (a.giant.rows && end - beg > kGiantRow) {
+      const int gi = (a.giant.rows && end - beg > kGiantRow) ? giant_find(a.giant, r) : -1;   // block-uniform
+      if (gi >= 0) {
         if (wave != (rr & 3)) continue;
-        acc = giant_row_sum(a.giant, r, F4, lane, 0, F4);
+        acc = giant_row_sum(a.giant, gi, F4, lane, 0, F4);
       } else {
         acc = gather_long_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, beg, end, F4, lane, wave, s_part);
       }

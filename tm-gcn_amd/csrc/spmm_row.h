@@ -382,19 +382,26 @@ struct GiantPlan {
   int32_t n;
 };
 
-// Σ of the partial sums of giant row r (the caller saw more than kGiantRow entries, so r is in the plan); lanes < w4 of
-// the calling wave return their float4 of columns [4·(c0 + lane), …); wave-uniform control flow.
-__device__ __forceinline__ float4 giant_row_sum(const GiantPlan& g, int64_t r, int F4, int lane, int c0, int w4) {
+// Position of row r in the plan, or -1 when the plan does not list it (a plan built for another CSR or with another
+// threshold: the caller then gathers the row like any other long row instead of adding up somebody else's partial sums).
+// Wave-uniform; called by every wave of the block (a few L2 hits, once per giant row).
+__device__ __forceinline__ int giant_find(const GiantPlan& g, int64_t r) {
   int lo = 0, hi = g.n - 1;
-  while (lo < hi) {                                  // bisection: a few L2 hits, once per giant row
+  while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if (g.rows[mid] < r) lo = mid + 1;
     else hi = mid;
   }
+  return (g.n > 0 && g.rows[lo] == r) ? lo : -1;
+}
+
+// Σ of the partial sums of the plan's giant row `gi` (giant_find); lanes < w4 of the calling wave return their float4 of
+// columns [4·(c0 + lane), …); wave-uniform control flow.
+__device__ __forceinline__ float4 giant_row_sum(const GiantPlan& g, int gi, int F4, int lane, int c0, int w4) {
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (lane < w4) {
-    const int c_end = g.chunk_ptr[lo + 1];
-    for (int c = g.chunk_ptr[lo]; c < c_end; ++c) {
+    const int c_end = g.chunk_ptr[gi + 1];
+    for (int c = g.chunk_ptr[gi]; c < c_end; ++c) {
       const float4 t = g.partial[(int64_t)c * F4 + c0 + lane];
       s.x += t.x;
       s.y += t.y;

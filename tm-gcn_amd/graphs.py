@@ -72,6 +72,14 @@ class GraphedTrainStep:
                 if q is not None:
                     slots.setdefault(id(q), []).append((mod, name))
 
+        # an optimizer parameter the model does not OWN (no module slot) cannot be aliased below: the forward would reach it
+        # by another route, autograd.grad(…, allow_unused=True) would hand back None for it and it would silently never be
+        # updated — refuse at construction
+        homeless = [tuple(p.shape) for p in params if id(p) not in slots]
+        if homeless and not self.folded:
+            raise RuntimeError(f"GraphedTrainStep: {len(homeless)} optimizer parameter(s) of shape(s) {homeless} are not parameters of "
+                               "a module of the model; the captured step can only differentiate parameters the model owns")
+
         class _FreshLeaves:
             """The optimizer's parameters replaced, inside the model, by fresh leaf ALIASES (`p.detach().requires_grad_()`:
             same storage, no launch) for the duration of a forward.  Why: autograd binds a leaf's AccumulateGrad node to
@@ -114,6 +122,22 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):  # warm-up off the capture stream (allocator, lazy init, plans)
+            if not self.folded:
+                # the aliased forward must reach exactly the parameters an ordinary backward reaches (a cached attribute
+                # reference to a parameter would bypass the aliases): compare once, refuse to capture on a mismatch
+                optimizer.zero_grad(set_to_none=True)
+                l0, o0 = forward_loss()
+                l0.backward()
+                reached = [p.grad is not None for p in params]
+                del l0, o0
+                optimizer.zero_grad(set_to_none=True)
+                forward_backward()
+                got = [p.grad is not None for p in params]
+                optimizer.zero_grad(set_to_none=True)
+                if reached != got:
+                    raise RuntimeError("GraphedTrainStep: the captured step's forward reaches other parameters than loss.backward() does "
+                                       f"(ordinary backward: {reached}, captured route: {got}); a parameter is being used through a "
+                                       "reference the model's modules do not own")
             for _ in range(warmup - (1 if self.folded else 0)):          # (the applicability probe above was a step)
                 one_step()
         torch.cuda.current_stream(dev).wait_stream(side)

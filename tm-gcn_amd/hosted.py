@@ -14,8 +14,10 @@ takes the one-pass head + loss kernel from what the output was formed FROM — a
 AFTER `optimizer.step()` (experiment_reddit_our_link_prediction.py:76-87).  So gcn() hands back a placeholder and the
 logits are formed (a) by the criterion's own launch, as a by-product of the head + loss kernel — the values of the
 parameters BEFORE the step, which is what the reference's `output_train` holds —, or (b) on first use by anything else,
-from the embedding and U the placeholder carries (refused with an error if a parameter was modified in between: the
-values would not be the ones gcn() saw).  No launch whose result nobody reads: S1 script epoch 0.25 -> 0.18 ms.
+from the embedding and U the placeholder carries; if a parameter was modified in between (a step behind a custom loss that
+never showed the output to F.cross_entropy), from the snapshot of U and the folded W — at most 84 floats — that gcn() took:
+the reference's `output_train` is readable at any time, so is this.  No launch whose result nobody reads: S1 script epoch
+0.25 -> 0.18 ms.
 
 Two more conveniences for the scripts' idioms:
   * ``F.cross_entropy(input, target, weight)`` in its plain form (mean reduction, class-index
@@ -201,19 +203,40 @@ class DeviceResult(torch.Tensor):
 
 class LazyLogits(DeviceResult):
     """gcn()'s logits, not formed yet (module docstring).  An uninitialised [E, C] device tensor that carries the head it
-    stands for; `_tmgcn_value` holds the real logits once something has formed them."""
+    stands for; `_tmgcn_value` holds the real logits once something has formed them.
+
+    What it may be asked, and what it answers (the reference's `output_train` is an ordinary tensor: every one of these works
+    there, experiment_reddit_our_link_prediction.py:76-87):
+      criterion(out, target)        the one-pass head + loss launch; its logits (DETACHED: the loss no longer hangs off them)
+                                    are kept as a by-product — the values of the parameters before the step;
+      any read under no_grad, or after a parameter changed
+                                    that by-product if there is one; else the logits formed from the embedding — and, when U
+                                    (or the folded W) has been modified since gcn() ran, from the SNAPSHOT of those few floats
+                                    taken at gcn() time (detached: the parameters the graph would lead to have moved on);
+      a grad-mode read while the parameters are untouched
+                                    the logits WITH their autograd graph, formed through form() — also after the criterion
+                                    (a second loss term on the output, `criterion(out, t) + lam * out.pow(2).mean()`, is
+                                    differentiated; round 5 handed back the detached by-product there: ADVICE r5)."""
 
     _tmgcn_value = None          # (class defaults: an instance that did not come from make() is ordinary data)
     _tmgcn_form = None
     _tmgcn_versions = ()
+    _tmgcn_snapshot = None
 
     @staticmethod
-    def make(head, E: int, C: int, device, form):
+    def make(head, E: int, C: int, device, form, form_from=None):
+        """form() -> logits with their autograd graph; form_from(U, fold) -> logits of the given parameter VALUES (no graph)."""
         out = torch.empty(E, C, device=device, dtype=torch.float32).as_subclass(LazyLogits)
         out._tmgcn_head = head
         out._tmgcn_value = None
-        out._tmgcn_form = form                                   # () -> logits with their autograd graph
-        out._tmgcn_versions = [(t, t._version) for t in (head[2], head[3]) if t is not None]   # U and the folded W
+        out._tmgcn_form = form
+        live = [t for t in (head[2], head[3]) if t is not None]         # U and the folded W: what an optimizer step moves
+        out._tmgcn_versions = [(t, t._version) for t in live]
+        if form_from is not None:
+            # <= 84 floats (U 12 x 3, W 2 x 6 / 6 x 6), one launch: what lets a read AFTER the step still see gcn()'s values
+            with torch.no_grad():
+                flat = torch.cat([t.detach().reshape(-1) for t in live]) if len(live) > 1 else live[0].detach().clone().reshape(-1)
+            out._tmgcn_snapshot = (flat, [t.shape for t in live], head[3] is not None, form_from)
         return out
 
     @property
@@ -233,17 +256,36 @@ def _formed(x):
         return x
     if x._tmgcn_value is None and x._tmgcn_form is None:
         return torch.Tensor.as_subclass(x, DeviceResult)
-    if x._tmgcn_value is None:
-        for t, ver in x._tmgcn_versions:
-            if t._version != ver:
-                raise RuntimeError("tmgcn_amd: the output of gcn() is being read for the first time AFTER a parameter it depends on was "
-                                   "modified (an optimizer step?) and without having been through the criterion: the logits gcn() saw "
-                                   "can no longer be formed.  Read the output before the step, or set tmgcn_amd.hosted.FUSE_HEAD_LOSS = False")
-        with _plain_scope(), torch.enable_grad():
-            v = x._tmgcn_form().as_subclass(DeviceResult)
+    changed = any(t._version != ver for t, ver in x._tmgcn_versions)
+    if x._tmgcn_value is not None:
+        # the criterion's by-product (detached; form is still there) or logits formed earlier (form is gone)
+        if x._tmgcn_form is None or changed or not torch.is_grad_enabled():
+            return x._tmgcn_value
+    elif changed:
+        # first read after an optimizer step, the criterion never saw this output (a custom loss, or none): the reference's
+        # `output_train` holds the logits of the parameters gcn() ran with — formed here from their snapshot
+        snap = x._tmgcn_snapshot
+        if snap is None:
+            raise RuntimeError("tmgcn_amd: the output of gcn() is being read for the first time AFTER a parameter it depends on was "
+                               "modified and no snapshot of the parameters was kept: the logits gcn() saw can no longer be formed")
+        flat, shapes, has_fold, form_from = snap
+        parts, at = [], 0
+        for shp in shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            parts.append(flat[at:at + n].view(shp))
+            at += n
+        with _plain_scope(), torch.no_grad():
+            v = form_from(parts[0], parts[1] if has_fold else None).as_subclass(DeviceResult)
         v._tmgcn_head = x._tmgcn_head
         x._tmgcn_value, x._tmgcn_form = v, None
-    return x._tmgcn_value
+        return v
+    with _plain_scope(), torch.enable_grad():
+        v = x._tmgcn_form().as_subclass(DeviceResult)
+    v._tmgcn_head = x._tmgcn_head
+    x._tmgcn_value, x._tmgcn_form = v, None
+    return v
 
 
 def _fused_cross_entropy(input, target, weight=None, size_average=None, ignore_index=-100, reduce=None,
@@ -296,7 +338,8 @@ def _fused_head_loss(input, target, weight=None, size_average=None, ignore_index
     if lazy:
         # the placeholder's logits come out of the same launch (the values of the parameters as they are NOW: before the step)
         loss, logits = ops.head_loss(Z, eidx, U, target, weight, ignore_index, want_logits=True, fold_W=fold)
-        v = logits.detach().as_subclass(DeviceResult)
-        input._tmgcn_value, input._tmgcn_form = v, None
+        # the by-product is detached; `_tmgcn_form` stays: a later grad-mode use of the output (a second loss term) re-forms
+        # the logits with their graph as long as the parameters are untouched (_formed)
+        input._tmgcn_value = logits.detach().as_subclass(DeviceResult)
         return loss.as_subclass(DeviceResult)
     return ops.head_loss(Z, eidx, U, target, weight, ignore_index, fold_W=fold).as_subclass(DeviceResult)

@@ -239,7 +239,10 @@ class _Head:
                 if key not in ok:
                     ok[key] = ops.head_loss_supported(*key)
                 if ok[key]:
-                    return hosted.LazyLogits.make(head, eidx.E, U.shape[-1], Z.device, form)
+                    def form_from(U_then, fold_then):             # the logits of the parameter VALUES gcn() ran with (no graph)
+                        Zf = ops.feature_gemm(Z.detach(), fold_then) if fold_then is not None else Z.detach()
+                        return self._head(Zf, eidx, U_then)
+                    return hosted.LazyLogits.make(head, eidx.E, U.shape[-1], Z.device, form, form_from)
         return self._deliver(form(), head)
 
     def loss(self, criterion, target: torch.Tensor, At=None, X=None, edges=None, want_logits: bool = False,
