@@ -59,6 +59,132 @@ struct FusedArgs {
 #ifndef TMGCN_FUSED_US
 #define TMGCN_FUSED_US 1    // gathers in flight per lane on short tiles, as a multiple of U
 #endif
+#ifndef TMGCN_FUSED_MFMA_PRIO
+#define TMGCN_FUSED_MFMA_PRIO 3
+#endif
+#ifndef TMGCN_FUSED_BLOCKS
+#define TMGCN_FUSED_BLOCKS 4   // development only: resident blocks per CU the grid is sized for (of 4)
+#endif
+#ifndef TMGCN_DEV_SKIP
+#define TMGCN_DEV_SKIP 0    // development only (phase breakdown, profiles/r6/r6_05_*): 1 no gather, 2 no products, 4 no Y stores
+#endif
+
+// ---- the three pieces of the fused kernel ----------------------------------------------------------------------------
+
+// W fragments of a wave's 32-column strip (n0 .. n0+31): B operand of v_mfma_f32_32x32x2_f32, k = 8j + s + 4·lh
+template <int NJ>
+__device__ __forceinline__ void fused_load_w(const FusedArgs& a, int64_t batch, int n0, int li, int lh, float (&wreg)[NJ][4]) {
+  const float* Wb = a.W + (a.rows_per_batch ? batch * a.w_batch_stride : 0);
+  const int n = n0 + li;
+  const int nc = n < a.Nf ? n : 0;  // clamp: out-of-range columns load column 0, zeroed below
+  const float* Wl = a.trans_w ? Wb + (int64_t)nc * a.K + 4 * lh : Wb + (int64_t)(4 * lh) * a.Nf + nc;
+  const int64_t sk = a.trans_w ? 1 : a.Nf;  // stride of k
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float w = Wl[(int64_t)(8 * j + s) * sk];
+      wreg[j][s] = n < a.Nf ? w : 0.f;
+    }
+}
+
+// Phase 1: the row sums of one tile into the LDS tile `As` ([64][FLDA]) and, when asked for, to AX; all four waves.
+// A tile of few entries entry-major, several rows per wave at once (spmm_row.h "Short tiles"); otherwise 16 rows per wave,
+// long rows afterwards on all four waves.
+template <int LPR, int U, int US>
+__device__ __forceinline__ void fused_gather_tile(const FusedArgs& a, float* As, float4* s_part, const TileRows& rows, int64_t row0,
+                                                  int64_t row_end, int lane, int wave) {
+  const int F4 = a.K / 4;
+  const int n_tile_rows = row_end - row0 < FBM ? (int)(row_end - row0) : FBM;
+  const int64_t slice0 = row0 / a.N;
+  const bool is_short = short_tile(rows, row0 + n_tile_rows <= (slice0 + 1) * a.N);
+  if (TMGCN_DEV_SKIP & 1) return;
+  if (is_short) {
+    gather_short_tile<LPR, US>(a.col, a.val, a.X + slice0 * (int64_t)a.N * F4, rows, n_tile_rows, F4, lane, wave, F4,
+                               [&](int rr, const float4& acc, int fl) {
+                                 if (fl < F4) {
+                                   *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * fl]) = acc;
+                                   if (a.AX) store_f4(&reinterpret_cast<float4*>(a.AX)[(row0 + rr) * F4 + fl], acc);
+                                 }
+                               });
+    return;
+  }
+  for (int rr = wave; rr < FBM; rr += 4) {
+    const int64_t r = row0 + rr;
+    const bool lng = (rows.long_mask >> rr) & 1;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < row_end && !lng) {
+      const int64_t slice = r / a.N;
+      acc = gather_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, readlane64(rows.beg, rr),
+                               readlane64(rows.end, rr), F4, lane);
+    }
+    if (!lng && lane < LPR && lane < F4) {
+      *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
+      if (a.AX && r < row_end) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
+    }
+  }
+  for (uint64_t m = rows.long_mask; m; m &= m - 1) {
+    const int rr = __builtin_ctzll(m);
+    const int64_t r = row0 + rr;
+    const int64_t slice = r / a.N;
+    const int64_t beg = readlane64(rows.beg, rr), end = readlane64(rows.end, rr);
+    float4 acc;
+    const int gi = (a.giant.rows && end - beg > kGiantRow) ? giant_find(a.giant, r) : -1;   // uniform over the four waves
+    if (gi >= 0) {
+      if (wave != (rr & 3)) continue;
+      acc = giant_row_sum(a.giant, gi, F4, lane, 0, F4);
+    } else {
+      acc = gather_long_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, beg, end, F4, lane, wave, s_part);
+    }
+    if (wave == (rr & 3) && lane < LPR && lane < F4) {
+      *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
+      if (a.AX) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
+    }
+  }
+}
+
+// Phase 2: tile · Wop on the matrix cores, the wave's 32 output columns [n0, n0 + 32).
+// One 32-row half of the tile at a time: its 16 accumulators are stored before the other half's products
+// start, so only ONE accumulator set is live next to the 64 W-fragment registers (both halves live — the
+// round 1-3 form — cost 15 spilled VGPRs at 4 waves per SIMD; profiles/r4*_ab_fused_spill.txt).
+// A fragments are fetched one k-group ahead of the MFMAs that use them; the sched_barrier keeps hipcc
+// from hoisting all the ds_read_b128 to the top.
+template <int NJ>
+__device__ __forceinline__ void fused_mfma_tile(const FusedArgs& a, const float* As, const float (&wreg)[NJ][4], int64_t row0,
+                                                int64_t row_end, int n0, int li, int lh) {
+  if (n0 >= a.Nf || (TMGCN_DEV_SKIP & 2)) return;
+  const float* Arow = &As[li * FLDA + 4 * lh];
+  const int n = n0 + li;
+#pragma unroll
+  for (int mb = 0; mb < FBM / 32; ++mb) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 av_next = *reinterpret_cast<const float4*>(Arow + mb * 32 * FLDA);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float4 av = av_next;
+      if (j + 1 < NJ) av_next = *reinterpret_cast<const float4*>(Arow + mb * 32 * FLDA + 8 * (j + 1));
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wreg[j][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wreg[j][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wreg[j][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wreg[j][3], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (n < a.Nf) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t r = row0 + mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        if (r < row_end && ((TMGCN_DEV_SKIP & 4) == 0 || acc[i] == 12345.f)) {
+          const float s = acc[i];
+          if (a.pre) store_f1(&a.pre[r * a.Nf + n], s);
+          store_f1(&a.Y[r * a.Nf + n], act_apply(s, a.act));
+        }
+      }
+    }
+  }
+}
+
 template <int LPR, int U, int NJ, int US = TMGCN_FUSED_US * U>  // NJ = K / 8 (K is a multiple of 8 here)
 __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedArgs a) {
   __shared__ float As[FBM * FLDA];
@@ -67,8 +193,6 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 31;
   const int lh = lane >> 5;
-  const int F4 = a.K / 4;
-  constexpr int nj = NJ;
   const int n0 = wave * 32;
   const TileMap tm = a.tiles;
 
@@ -99,108 +223,18 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
       __syncthreads();                                                 // (s_tile is rewritten at the top)
       continue;
     }
-
     if (batch != cur_batch) {
-      const float* Wb = a.W + (a.rows_per_batch ? batch * a.w_batch_stride : 0);
-      const int n = n0 + li;
-      const int nc = n < a.Nf ? n : 0;  // clamp: out-of-range columns load column 0, zeroed below
-      const float* Wl = a.trans_w ? Wb + (int64_t)nc * a.K + 4 * lh : Wb + (int64_t)(4 * lh) * a.Nf + nc;
-      const int64_t sk = a.trans_w ? 1 : a.Nf;  // stride of k
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float w = Wl[(int64_t)(8 * j + s) * sk];
-          wreg[j][s] = n < a.Nf ? w : 0.f;
-        }
+      fused_load_w<NJ>(a, batch, n0, li, lh, wreg);
       cur_batch = batch;
     }
-
-    // ---- phase 1: gather 16 rows per wave into the LDS tile; long rows afterwards, on all four waves;
-    //      a tile of few entries entry-major, several rows per wave at once (spmm_row.h "Short tiles")
-    const int n_tile_rows = row_end - row0 < FBM ? (int)(row_end - row0) : FBM;
-    const int64_t slice0 = row0 / a.N;
-    const bool is_short = short_tile(rows, row0 + n_tile_rows <= (slice0 + 1) * a.N);
-    if (is_short)
-      gather_short_tile<LPR, US>(a.col, a.val, a.X + slice0 * (int64_t)a.N * F4, rows, n_tile_rows, F4, lane, wave, F4,
-                                 [&](int rr, const float4& acc, int fl) {
-                                   if (fl < F4) {
-                                     *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * fl]) = acc;
-                                     if (a.AX) store_f4(&reinterpret_cast<float4*>(a.AX)[(row0 + rr) * F4 + fl], acc);
-                                   }
-                                 });
-    for (int rr = wave; rr < (is_short ? 0 : FBM); rr += 4) {
-      const int64_t r = row0 + rr;
-      const bool lng = (rows.long_mask >> rr) & 1;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < row_end && !lng) {
-        const int64_t slice = r / a.N;
-        acc = gather_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, readlane64(rows.beg, rr),
-                                 readlane64(rows.end, rr), F4, lane);
-      }
-      if (!lng && lane < LPR && lane < F4) {
-        *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
-        if (a.AX && r < row_end) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
-      }
-    }
-    for (uint64_t m = rows.long_mask; m; m &= m - 1) {
-      const int rr = __builtin_ctzll(m);
-      const int64_t r = row0 + rr;
-      const int64_t slice = r / a.N;
-      const int64_t beg = readlane64(rows.beg, rr), end = readlane64(rows.end, rr);
-      float4 acc;
-      const int gi = (a.giant.rows && end - beg > kGiantRow) ? giant_find(a.giant, r) : -1;   // block-uniform
-      if (gi >= 0) {
-        if (wave != (rr & 3)) continue;
-        acc = giant_row_sum(a.giant, gi, F4, lane, 0, F4);
-      } else {
-        acc = gather_long_row<LPR, U>(a.col, a.val, a.X + slice * (int64_t)a.N * F4, beg, end, F4, lane, wave, s_part);
-      }
-      if (wave == (rr & 3) && lane < LPR && lane < F4) {
-        *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
-        if (a.AX) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
-      }
-    }
+    fused_gather_tile<LPR, U, US>(a, As, s_part, rows, row0, row_end, lane, wave);
     __syncthreads();
-
-    // ---- phase 2: tile · Wop on the matrix cores
-    if (n0 < a.Nf) {
-      // One 32-row half of the tile at a time: its 16 accumulators are stored before the other half's products
-      // start, so only ONE accumulator set is live next to the 64 W-fragment registers (both halves live — the
-      // round 1-3 form — cost 15 spilled VGPRs at 4 waves per SIMD; profiles/r4*_ab_fused_spill.txt).
-      // A fragments are fetched one k-group ahead of the MFMAs that use them; the sched_barrier keeps hipcc
-      // from hoisting all the ds_read_b128 to the top.
-      const float* Arow = &As[li * FLDA + 4 * lh];
-      const int n = n0 + li;
-#pragma unroll
-      for (int mb = 0; mb < FBM / 32; ++mb) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        float4 av_next = *reinterpret_cast<const float4*>(Arow + mb * 32 * FLDA);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const float4 av = av_next;
-          if (j + 1 < nj) av_next = *reinterpret_cast<const float4*>(Arow + mb * 32 * FLDA + 8 * (j + 1));
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wreg[j][0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, wreg[j][1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, wreg[j][2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, wreg[j][3], acc, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (n < a.Nf) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int64_t r = row0 + mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            if (r < row_end) {
-              const float s = acc[i];
-              if (a.pre) store_f1(&a.pre[r * a.Nf + n], s);
-              store_f1(&a.Y[r * a.Nf + n], act_apply(s, a.act));
-            }
-          }
-        }
-      }
-    }
+    // the product phase at raised issue priority: its waves hold the block's LDS tile and share the SIMD with three other
+    // blocks' waves that are waiting for gathered rows anyway (round 6: -4.5 % on the chess operand at bench size, -6 % at
+    // 4 random entries per row, S4 unchanged; profiles/r6/r6_08_*)
+    __builtin_amdgcn_s_setprio(TMGCN_FUSED_MFMA_PRIO);
+    fused_mfma_tile<NJ>(a, As, wreg, row0, row_end, n0, li, lh);
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();  // tile consumed before the next phase 1 overwrites it
   }
 }
@@ -351,12 +385,13 @@ extern "C" int tmgcn_spmm_gemm_f32_plan(const int64_t* rowptr, const int32_t* co
   TMGCN_REQUIRE(a.n_tiles < (int64_t)0x7fffffff, "spmm_gemm: too many row tiles");
   a.tile_counter = acquire_tile_counters((hipStream_t)stream, 2);      // [0] the main loop's tiles, [1] the heavy-tile scan windows
   TMGCN_REQUIRE(a.tile_counter, "spmm_gemm: no tile counter: %s", pool_error());
-  // persistent blocks: up to 4 per CU (LDS 33.8 KB each); tiles are dealt round-robin so the
-  // blocks resident at any moment work on neighbouring rows of the same slice
   hipStream_t st = (hipStream_t)stream;
+  // persistent blocks: up to 4 per CU (LDS 33.8 KB each); tiles are drawn in ascending order so the
+  // blocks resident at any moment work on neighbouring rows of the same slice
 #define TMGCN_FUSED_CASE(KK, L, UU)                                                              \
   case KK: {                                                                                     \
     int64_t gx = persistent_grid_reserved(spmm_gemm_kernel<L, UU, KK / 8>, 256, grid_reserve);                 \
+    gx = gx * TMGCN_FUSED_BLOCKS / 4;                                                            \
     if (gx > a.n_tiles) gx = a.n_tiles;                                                          \
     hipLaunchKernelGGL((spmm_gemm_kernel<L, UU, KK / 8>), dim3((unsigned)gx), dim3(256), 0, st, a); \
     break;                                                                                       \

@@ -18,7 +18,7 @@ p, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
 
 def load(path):
     lib = C.CDLL(path)
-    lib.tmgcn_spmm_gemm_f32.argtypes = [p, p, p, p, i64, i32, i32, p, i32, i32, i64, i64, i32, p, p, p, i32, p]
+    lib.tmgcn_spmm_gemm_f32_hint.argtypes = [p, p, p, p, i64, i32, i32, p, i32, i32, i64, i64, i32, p, p, p, i32, C.c_float, p]
     lib.tmgcn_spmm_csr_batched_f32.argtypes = [p, p, p, p, p, i64, i32, i32, p]
     return lib
 
@@ -44,8 +44,8 @@ def run(lib, which):
     if which == "spmm":
         return lib.tmgcn_spmm_csr_batched_f32(ptr(A.rowptr), ptr(A.col), ptr(A.val), ptr(X), ptr(Y), A.n_rows, N, F, st)
     ax = ptr(AX) if which == "fused+ax" else None
-    return lib.tmgcn_spmm_gemm_f32(ptr(A.rowptr), ptr(A.col), ptr(A.val), ptr(X), A.n_rows, N, F, ptr(W), F, 0, 0, 0, 0,
-                                   ptr(Y), ax, None, 0, st)
+    return lib.tmgcn_spmm_gemm_f32_hint(ptr(A.rowptr), ptr(A.col), ptr(A.val), ptr(X), A.n_rows, N, F, ptr(W), F, 0, 0, 0, 0,
+                                        ptr(Y), ax, None, 0, float(A.avg_nnz_per_row), st)   # the hint the torch ops pass
 
 
 res = {}
