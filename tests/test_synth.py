@@ -76,3 +76,22 @@ def test_row_blocks_partition_by_entries():
     assert set(range(0, T * N, 256)) <= set(blk.tolist())
     tri = A.trivial_row_blocks()
     assert tri.shape == ((T * N + 255) // 256, 2) and int(tri[:, 1].sum()) == T * N and int(tri[:, 1].max()) == 256
+
+
+def test_tile_block_diagonal_is_a_kronecker_replication():
+    """synth.tile_block_diagonal (bench.py --graph chess_tiled: the reference's real operand at bench size): slice s of the
+    result is I_reps ⊗ A[slices[s]] — row lengths, values and the order inside a row are kept; the default takes every slice."""
+    from tmgcn_amd.csr import BatchedCSR
+    g = synth.dynamic_graph(T=4, N=9, edges_per_slice=12, seed=0, no_diag=2)
+    A = BatchedCSR.from_coo_list(g.At_list())
+    B = synth.tile_block_diagonal(A, 3, [3, 1])
+    assert (B.T, B.N, B.nnz) == (2, 27, 3 * int(A.rowptr[4 * 9] - A.rowptr[3 * 9] + A.rowptr[2 * 9] - A.rowptr[9]))
+    D, E = A.to_dense(), B.to_dense()
+    for s, k in enumerate([3, 1]):
+        assert torch.equal(E[s], torch.kron(torch.eye(3, dtype=D.dtype), D[k]))
+    cnt = (A.rowptr[1:] - A.rowptr[:-1]).view(4, 9)
+    assert torch.equal((B.rowptr[1:] - B.rowptr[:-1]).view(2, 3, 9)[0], cnt[3].expand(3, -1))
+    C = synth.tile_block_diagonal(A, 2)
+    assert (C.T, C.N, C.nnz) == (4, 18, 2 * A.nnz)
+    # the slice choice of the bench leg: global slice g of the tiled tensor is chess slice (5 g + 4) mod 80
+    assert [(5 * s + 4) % 80 for s in range(16)] == list(range(4, 80, 5))

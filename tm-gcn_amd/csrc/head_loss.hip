@@ -90,7 +90,7 @@ __device__ __forceinline__ void load_in(const float* __restrict__ base, int64_t 
 }
 
 constexpr int kHeadLossMaxBlocks = 1024;   // (with the tree reduction the S2 kernel takes 30.5 - 31.0 us from 1 024 to 4 096 blocks; one last block
-                                           //  walking 2 048 slabs: 81 us instead of 62, profiles/r4d vs r4m)
+                                           //  walking 2 048 slabs: 81 us instead of 62, profiles/archive/r4d vs r4m)
 
 // What a lane gathers per endpoint is the row's INPUT of NIN floats: the embedding row itself (K = 0, NIN = F)
 // or, folded (K = 2), the AtXt row — then the head the logits see is H = W·U (per role), i.e.

@@ -26,8 +26,11 @@
 //                 block whatever the row lengths; the Bitcoin-OTC shape and real, skewed data;
 //   staged        small dense slices (above);
 //   lanes per row everything else: G = 1 … 16 lanes per row, entries strided over them (l12_fwd_kernel, l12_bwd_kernel).
-// dW2 = (Â⋆Y)ᵀ·dZ stays the narrow dW kernel (gemm.hip) on the Â⋆Y the forward stores for it (folding its 36 sums into
-// the backward kernel as well was measured: 72 us instead of 37 + 13 — 48 fp64 accumulators per lane; not kept).
+// dW2 = (Â⋆Y)ᵀ·(dZ ⊙ act2'(pre2)): the ENTRY-MAJOR backward forms it in the same launch (round 5: four lanes per row load the
+// row block's own rows of the two [R][6] tensors while the row pointers are in flight, the wave folds the 3 x 3 quadrant
+// products, the sums ride in the row block's slab; tmgcn_layer12_bwd_forms_dw2 tells a caller when) — the first attempt,
+// 48 fp64 accumulators per LANE, had cost 72 us against 37 + 13 and was not kept.  The staged and the lanes-per-row
+// backward leave dW2 to the narrow dW kernel (gemm.hip) on the Â⋆Y the forward stores for it.
 #include "common.h"
 
 namespace tmgcn {
@@ -1116,7 +1119,7 @@ extern "C" int tmgcn_layer12_bwd_f32(const int64_t* t_rowptr, const int32_t* t_c
     // 31.1 -> 27.9 us.  Grid: resident blocks that DRAW their row blocks (see the kernel).  One block per row block with the
     // hardware as the scheduler cost every row block the slab / ticket tail and a block launch (chess: 2 661 blocks of mean
     // life 12.9 us, 4.6 of it the tail: 49.0 us); row blocks dealt statically chained heavy ones (61.7); drawn: 42.3, and
-    // 37.8 with the partition cut at one tile of entries instead of two (tools/l12_trace.py, profiles/r5s_*).
+    // 37.8 with the partition cut at one tile of entries instead of two (tools/l12_trace.py, profiles/archive/r5s_*).
     a.blk = row_blocks;
     a.n_blk = n_row_blocks;
     l12_bwd_em_launch(a, F, Nf, row_blocks ? n_row_blocks : (n_rows + 255) / 256, st);

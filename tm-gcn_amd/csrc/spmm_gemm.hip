@@ -146,7 +146,7 @@ __device__ __forceinline__ void fused_gather_tile(const FusedArgs& a, float* As,
 // Phase 2: tile · Wop on the matrix cores, the wave's 32 output columns [n0, n0 + 32).
 // One 32-row half of the tile at a time: its 16 accumulators are stored before the other half's products
 // start, so only ONE accumulator set is live next to the 64 W-fragment registers (both halves live — the
-// round 1-3 form — cost 15 spilled VGPRs at 4 waves per SIMD; profiles/r4*_ab_fused_spill.txt).
+// round 1-3 form — cost 15 spilled VGPRs at 4 waves per SIMD; profiles/archive/r4*_ab_fused_spill.txt).
 // A fragments are fetched one k-group ahead of the MFMAs that use them; the sched_barrier keeps hipcc
 // from hoisting all the ds_read_b128 to the top.
 template <int NJ>

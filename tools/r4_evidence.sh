@@ -1,5 +1,5 @@
 #!/bin/bash
-# The GPU-box session behind the round-4 evidence files (profiles/r4z_*, final tree).  Usage: tools/r4_evidence.sh TAG
+# The GPU-box session behind the round-4 evidence files (profiles/archive/r4z_*, final tree).  Usage: tools/r4_evidence.sh TAG
 TAG=${1:-r4q}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"

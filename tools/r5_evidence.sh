@@ -1,5 +1,5 @@
 #!/bin/bash
-# The GPU-box session behind the round-5 evidence files (profiles/r5z_*, final tree).  Usage: tools/r5_evidence.sh TAG
+# The GPU-box session behind the round-5 evidence files (profiles/archive/r5z_*, final tree).  Usage: tools/r5_evidence.sh TAG
 TAG=${1:-r5z}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
