@@ -104,3 +104,21 @@ def unpack_sym(d, name, T, N):
     order = np.argsort((K * N + I) * N + J, kind="stable")
     assert len(order) == int(d[name + "_nnz"])
     return K[order], I[order], J[order], V[order]
+
+
+def head_loss_fp64(Z, W, U, edges, target, weight, N):
+    """The scripts' head + criterion in fp64 with stock torch ops + autograd, on whatever device Z lives:
+    logits = [Y[src], Y[dst]]·U with Y = Z (or Z·W: the folded 1-layer model, ehf:222), ehf:228-232;
+    loss = nn.CrossEntropyLoss(weight)(logits, target) (experiment_reddit_our_link_prediction.py:69, 79).
+    The checker of tests/test_gpu_head_loss.py; itself pinned on fixture G2's logits / loss / dW / dU (the real reference's
+    numbers) by tests/test_oracle_golden.py::test_head_loss_fp64_restatement_is_pinned_on_g2.
+    Returns (logits, loss, dZ, dU, dW or None)."""
+    Zd = Z.double().requires_grad_(True)
+    Ud = U.double().requires_grad_(True)
+    Wd = W.double().requires_grad_(True) if W is not None else None
+    Y = (Zd @ Wd if W is not None else Zd).reshape(-1, U.shape[0] // 2)
+    e = edges.to(Z.device)
+    logits = torch.cat((Y[e[0] * N + e[1]], Y[e[0] * N + e[2]]), dim=1) @ Ud
+    loss = torch.nn.functional.cross_entropy(logits, target, weight=weight.double())
+    loss.backward()
+    return logits.detach(), loss.detach(), Zd.grad, Ud.grad, (Wd.grad if W is not None else None)

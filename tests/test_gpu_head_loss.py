@@ -1,12 +1,13 @@
 """GPU: the one-pass edge head + class-weighted cross entropy + gradients (csrc/head_loss.hip, ops.head_loss,
 `model.loss(criterion, target)`) against (a) a torch fp64 restatement of the scripts' statements
-(ehf:228-232 + nn.CrossEntropyLoss(weight=...), autograd), (b) the unfused kernels it replaces, (c) the
+(ehf:228-232 + nn.CrossEntropyLoss(weight=...), autograd: tests/_util.head_loss_fp64, which the CPU suite pins on the real
+reference's G2 numbers), (b) the unfused kernels it replaces, (c) the
 reference's own numbers (fixtures G2, G3, G10)."""
 import numpy as np
 import pytest
 import torch
 
-from _util import REL_TOL, assert_close, coo_list, golden
+from _util import REL_TOL, assert_close, coo_list, golden, head_loss_fp64
 import tmgcn_amd.layers as ehf
 from tmgcn_amd import ops
 from tmgcn_amd.losses import WeightedCrossEntropy, weighted_ce
@@ -28,17 +29,7 @@ def _problem(T, N, F, C, E, seed, ignore_frac=0.0, K=0):
     return Z, W, U, edges, target.cuda(), weight.cuda()
 
 
-def _fp64(Z, W, U, edges, target, weight, N):
-    """The scripts' statements in fp64 on the device with stock torch ops + autograd."""
-    Zd = Z.double().requires_grad_(True)
-    Ud = U.double().requires_grad_(True)
-    Wd = W.double().requires_grad_(True) if W is not None else None
-    Y = (Zd @ Wd if W is not None else Zd).reshape(-1, U.shape[0] // 2)
-    e = edges.cuda()
-    logits = torch.cat((Y[e[0] * N + e[1]], Y[e[0] * N + e[2]]), dim=1) @ Ud
-    loss = torch.nn.functional.cross_entropy(logits, target, weight=weight.double())
-    loss.backward()
-    return logits.detach(), loss.detach(), Zd.grad, Ud.grad, (Wd.grad if W is not None else None)
+_fp64 = head_loss_fp64          # tests/_util.py: the fp64 restatement, pinned on fixture G2 by the CPU suite
 
 
 @pytest.mark.parametrize("T,N,F,C,E,ign", [(5, 40, 6, 2, 3000, 0.0),     # the reference's head, ~30 entries per row

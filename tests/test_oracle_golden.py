@@ -94,6 +94,23 @@ def test_g2_c_oracle_gemm_and_gemm_dw(name):
     assert_close(dA, ref, 1e-6, name + " dA through ref_gemm(trans_w)")
 
 
+def test_head_loss_fp64_restatement_is_pinned_on_g2():
+    """tests/_util.head_loss_fp64 — the checker of the one-pass head + loss kernel's GPU tests — against the real reference:
+    on G2's inputs (the condensed-W model: Z = AtXt, folded weight W0, head U0) it reproduces the fixture's logits, loss, dW
+    and dU.  A second oracle is only worth something pinned."""
+    from _util import head_loss_fp64
+    d = golden("g2_gcn_condensed1")
+    i = _inputs(d)
+    T, N, _ = i["X"].shape
+    AtXt = orc.compute_AtXt(i["M"], i["At"], i["X"]).contiguous()
+    logits, loss, _, dU, dW = head_loss_fp64(AtXt, torch.from_numpy(d["W0"]), torch.from_numpy(d["U0"]), i["edges"], i["labels"],
+                                             torch.tensor([0.9, 0.1]), N)
+    assert_close(logits, d["logits"], 1e-6, "fp64 head restatement: logits")
+    assert abs(float(loss) - float(d["loss"])) <= 1e-6 * max(1.0, abs(float(d["loss"])))
+    assert_close(dU, d["dU"], 1e-6, "fp64 head restatement: dU")
+    assert_close(dW, d["dW"], 1e-6, "fp64 head restatement: dW")
+
+
 def test_c_oracle_row_window_is_the_full_product():
     """ref_mtransform_rows (one window of output rows; used by bench.py's verify block) returns the
     rows ref_mtransform returns, bit for bit, forward and transposed."""
