@@ -69,6 +69,19 @@ struct FusedArgs {
 #define TMGCN_DEV_SKIP 0    // development only (phase breakdown, profiles/r6/r6_05_*): 1 no gather, 2 no products, 4 no Y stores
 #endif
 
+// Development build only (-DTMGCN_FUSED_TRACE, tools/fused_trace.py): thread 0 of every block sums the 100 MHz wall-clock time
+// it spends in each phase of its tiles — separately for short tiles (entry-major walk) and the others — and leaves the
+// sums in a device array read back through tmgcn_debug_fused_trace.  Not part of the library.
+#ifdef TMGCN_FUSED_TRACE
+__device__ unsigned long long fused_trace_words[4096 * 16];
+#define FT_NOW() wall_clock64()
+#define FT_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define FT_STAMP(name) const unsigned long long name = FT_NOW()
+#else
+#define FT_STAMP(name) do { } while (0)
+#define FT_WAIT() do { } while (0)
+#endif
+
 // ---- the three pieces of the fused kernel ----------------------------------------------------------------------------
 
 // W fragments of a wave's 32-column strip (n0 .. n0+31): B operand of v_mfma_f32_32x32x2_f32, k = 8j + s + 4·lh
@@ -202,7 +215,11 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
   HeavyScan heavy;
   heavy.init(a.rowptr, tm);
 
+#ifdef TMGCN_FUSED_TRACE
+  unsigned long long ft[16] = {0};        // [8·short + phase]: 0 draw, 1 row pointers, 2 gather (wave 0), 3 barrier, 4 products, 5 barrier, 6 tiles
+#endif
   for (;;) {
+    FT_STAMP(ft_a);
     // next tile: first the heavy tiles (spmm_row.h: windows drawn from counter[1]), then from the device counter
     // (counter[0]; ascending, so resident blocks stay inside one slice)
     int64_t tile = -1;
@@ -217,26 +234,51 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
     int64_t unit, row0, row_end;
     tile_extent(tm, tile, unit, row0, row_end);
     const int64_t batch = a.rows_per_batch ? row0 / a.rows_per_batch : 0;
+    FT_STAMP(ft_b);
     TileRows rows;
     rows.load(a.rowptr, row0, row_end, lane);
     if (TMGCN_HEAVY_FIRST && !scanning && rows.entries > heavy.thr) {   // done in somebody's pass 1
       __syncthreads();                                                 // (s_tile is rewritten at the top)
       continue;
     }
+    FT_WAIT();
+    FT_STAMP(ft_c);
     if (batch != cur_batch) {
       fused_load_w<NJ>(a, batch, n0, li, lh, wreg);
       cur_batch = batch;
     }
     fused_gather_tile<LPR, U, US>(a, As, s_part, rows, row0, row_end, lane, wave);
+    FT_WAIT();
+    FT_STAMP(ft_d);
     __syncthreads();
+    FT_STAMP(ft_e);
     // the product phase at raised issue priority: its waves hold the block's LDS tile and share the SIMD with three other
     // blocks' waves that are waiting for gathered rows anyway (round 6: -4.5 % on the chess operand at bench size, -6 % at
     // 4 random entries per row, S4 unchanged; profiles/r6/r6_08_*)
     __builtin_amdgcn_s_setprio(TMGCN_FUSED_MFMA_PRIO);
     fused_mfma_tile<NJ>(a, As, wreg, row0, row_end, n0, li, lh);
     __builtin_amdgcn_s_setprio(0);
+    FT_STAMP(ft_f);
     __syncthreads();  // tile consumed before the next phase 1 overwrites it
+#ifdef TMGCN_FUSED_TRACE
+    {
+      const int n_tile_rows = row_end - row0 < FBM ? (int)(row_end - row0) : FBM;
+      const int k = short_tile(rows, row0 + n_tile_rows <= (row0 / a.N + 1) * a.N) ? 8 : 0;
+      const unsigned long long ft_g = FT_NOW();
+      ft[k + 0] += ft_b - ft_a;
+      ft[k + 1] += ft_c - ft_b;
+      ft[k + 2] += ft_d - ft_c;
+      ft[k + 3] += ft_e - ft_d;
+      ft[k + 4] += ft_f - ft_e;
+      ft[k + 5] += ft_g - ft_f;
+      ft[k + 6] += 1;
+    }
+#endif
   }
+#ifdef TMGCN_FUSED_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < 16; ++i) fused_trace_words[blockIdx.x * 16 + i] = ft[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -436,3 +478,13 @@ extern "C" int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, co
   return tmgcn_spmm_gemm_f32_hint(rowptr, col, val, X, n_rows, N, K, W, Nf, trans_w, rows_per_batch, w_batch_stride,
                                   act, Y, AX, pre_act, grid_reserve, -1.f, stream);
 }
+
+#ifdef TMGCN_FUSED_TRACE
+extern "C" int tmgcn_debug_fused_trace(unsigned long long* dst, long n_words, int clear) {
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(tmgcn::fused_trace_words));
+  if (e == hipSuccess && n_words > 0) e = hipMemcpy(dst, p, (size_t)n_words * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && clear) e = hipMemset(p, 0, sizeof(unsigned long long) * 4096 * 16);
+  return (int)e;
+}
+#endif
