@@ -156,6 +156,33 @@ __device__ __forceinline__ void fused_gather_tile(const FusedArgs& a, float* As,
   }
 }
 
+// The 16 accumulators of a lane after a 32-row half: accumulator i is row k(i) + 4·lh of the half, k(i) = (i & 3) + 8·(i >> 2).
+template <bool GUARD, bool PRE, bool ACT>
+__device__ __forceinline__ void fused_store_half(const f32x16& acc, const ActApply& act, float* __restrict__ Yb, float* __restrict__ Pb,
+                                                 int Nf, int lane_off, int rows_left) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = (i & 3) + 8 * (i >> 2);
+    const float s = acc[i];
+    if ((TMGCN_DEV_SKIP & 4) && s != 12345.f) continue;
+    if (GUARD && k >= rows_left) continue;
+    if (PRE) store_f1(&Pb[k * Nf + lane_off], s);
+    store_f1(&Yb[k * Nf + lane_off], ACT ? act(s) : s);
+  }
+}
+template <bool GUARD>
+__device__ __forceinline__ void fused_store_half(const f32x16& acc, int act_id, float* __restrict__ Yb, float* __restrict__ Pb, int Nf,
+                                                 int lane_off, int rows_left) {
+  const ActApply act(act_id);             // decoded once (the same bits as act_apply); no activation: the raw sums, no select chain
+  if (act_id == TMGCN_ACT_NONE) {
+    if (Pb) fused_store_half<GUARD, true, false>(acc, act, Yb, Pb, Nf, lane_off, rows_left);
+    else fused_store_half<GUARD, false, false>(acc, act, Yb, Pb, Nf, lane_off, rows_left);
+  } else {
+    if (Pb) fused_store_half<GUARD, true, true>(acc, act, Yb, Pb, Nf, lane_off, rows_left);
+    else fused_store_half<GUARD, false, true>(acc, act, Yb, Pb, Nf, lane_off, rows_left);
+  }
+}
+
 // Phase 2: tile · Wop on the matrix cores, the wave's 32 output columns [n0, n0 + 32).
 // One 32-row half of the tile at a time: its 16 accumulators are stored before the other half's products
 // start, so only ONE accumulator set is live next to the 64 W-fragment registers (both halves live — the
@@ -185,27 +212,31 @@ __device__ __forceinline__ void fused_mfma_tile(const FusedArgs& a, const float*
       __builtin_amdgcn_sched_barrier(0);
     }
     if (n < a.Nf) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int64_t r = row0 + mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-        if (r < row_end && ((TMGCN_DEV_SKIP & 4) == 0 || acc[i] == 12345.f)) {
-          const float s = acc[i];
-          if (a.pre) store_f1(&a.pre[r * a.Nf + n], s);
-          store_f1(&a.Y[r * a.Nf + n], act_apply(s, a.act));
-        }
-      }
+      // Epilogue: accumulator i of the lane is row rbase + k(i) + 4·lh, column n.  Everything but (4·lh)·Nf + n is uniform: the
+      // stores take a scalar base + a 32-bit lane offset, the activation is decoded once (ActApply: the same bits as
+      // act_apply; none at all for TMGCN_ACT_NONE), and a half tile that lies inside the slice skips the row guard.  (Round 6:
+      // a 64-bit address, a row compare and an activation switch per ELEMENT had made the epilogues a third of the product
+      // phase: 6.7 us per tile on an otherwise idle CU where the MFMAs need 3.6.)
+      const int64_t rbase = row0 + mb * 32;
+      float* __restrict__ Yb = a.Y + rbase * a.Nf;
+      float* __restrict__ Pb = a.pre ? a.pre + rbase * a.Nf : nullptr;
+      const int lane_off = (4 * lh) * a.Nf + n;
+      if (rbase + 32 <= row_end) fused_store_half<false>(acc, a.act, Yb, Pb, a.Nf, lane_off, 32);      // uniform: inside the slice
+      else fused_store_half<true>(acc, a.act, Yb, Pb, a.Nf, lane_off, (int)(row_end - rbase) - 4 * lh);  // rows k < rows_left exist
     }
   }
 }
 
+#ifdef TMGCN_FUSED_US_ABS
+template <int LPR, int U, int NJ, int US = TMGCN_FUSED_US_ABS>
+#else
 template <int LPR, int U, int NJ, int US = TMGCN_FUSED_US * U>  // NJ = K / 8 (K is a multiple of 8 here)
+#endif
 __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedArgs a) {
   __shared__ float As[FBM * FLDA];
   __shared__ float4 s_part[4 * LPR];      // partial sums of a long row, one per wave (spmm_row.h)
-  const int lane = threadIdx.x & 63;
+  const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 31;
-  const int lh = lane >> 5;
   const int n0 = wave * 32;
   const TileMap tm = a.tiles;
 
@@ -219,6 +250,13 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
   unsigned long long ft[16] = {0};        // [8·short + phase]: 0 draw, 1 row pointers, 2 gather (wave 0), 3 barrier, 4 products, 5 barrier, 6 tiles
 #endif
   for (;;) {
+    // The lane index is laundered through an empty asm once per tile and once more in front of the product phase: what the
+    // two phases derive from it (feature lane, stream, LDS and output addresses) is then recomputed where it is used — a few
+    // VALU instructions — instead of being hoisted out of this loop and held in registers across the OTHER phase, where the
+    // 64 W fragments and the gather's loads in flight need them (round 6: two W fragments lived in scratch and were
+    // re-read inside the MFMA chain, four exposed loads per tile).
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
     FT_STAMP(ft_a);
     // next tile: first the heavy tiles (spmm_row.h: windows drawn from counter[1]), then from the device counter
     // (counter[0]; ascending, so resident blocks stay inside one slice)
@@ -244,7 +282,7 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
     FT_WAIT();
     FT_STAMP(ft_c);
     if (batch != cur_batch) {
-      fused_load_w<NJ>(a, batch, n0, li, lh, wreg);
+      fused_load_w<NJ>(a, batch, n0, lane & 31, lane >> 5, wreg);
       cur_batch = batch;
     }
     fused_gather_tile<LPR, U, US>(a, As, s_part, rows, row0, row_end, lane, wave);
@@ -256,7 +294,11 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
     // blocks' waves that are waiting for gathered rows anyway (round 6: -4.5 % on the chess operand at bench size, -6 % at
     // 4 random entries per row, S4 unchanged; profiles/r6/r6_08_*)
     __builtin_amdgcn_s_setprio(TMGCN_FUSED_MFMA_PRIO);
-    fused_mfma_tile<NJ>(a, As, wreg, row0, row_end, n0, li, lh);
+    {
+      int lane_p = lane0;
+      asm volatile("" : "+v"(lane_p));
+      fused_mfma_tile<NJ>(a, As, wreg, row0, row_end, n0, lane_p & 31, lane_p >> 5);
+    }
     __builtin_amdgcn_s_setprio(0);
     FT_STAMP(ft_f);
     __syncthreads();  // tile consumed before the next phase 1 overwrites it
