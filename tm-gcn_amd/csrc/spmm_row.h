@@ -217,9 +217,10 @@ __device__ __forceinline__ float4 gather_long_row(const int32_t* __restrict__ co
 // per row then spends two dependent round trips (col / val, then ONE gather on half of its lanes) per row, sixteen rows one
 // after the other per wave and tile: the launch is a latency chain (measured: fused forward 23.6 ms where its compulsory bytes
 // are 6.3 ms of HBM time and its products 6.7 ms of MFMA time).  A tile of at most kShortTile entries without a long row is
-// therefore walked ENTRY-major: wave w owns tile rows [16w, 16w+16), each of its S = 64/LPR lane groups RG = 16/S consecutive
-// rows of those — a CONTIGUOUS run of entries, fetched LPR at a time with one coalesced load per array; every lane finds the
-// row of the entry it loaded by comparing its position with the group's row ends; the group then walks its entries in order,
+// therefore walked ENTRY-major: each of the block's 4·S lane groups (S = 64/LPR per wave) takes consecutive whole rows — an
+// equal share of the tile's ENTRIES, up to one row — i.e. a CONTIGUOUS run of entries, fetched LPR at a time with one
+// coalesced load per array; every lane finds the row of the entry it loaded by bisecting the tile's row ends (which every
+// wave holds, one per lane); the group then walks its entries in order,
 // U gathers in flight whatever rows they belong to, and hands a row's sum to `flush` when the row changes.  A row is summed
 // by ONE group in entry order (an fmaf chain: bitwise the serial sum); no atomics, no LDS, reproducible.  The predicate is a
 // function of the tile's row pointers alone, so the plain and the fused kernel, and every rerun, take the same path.
@@ -229,39 +230,57 @@ __device__ __forceinline__ float4 gather_long_row(const int32_t* __restrict__ co
 #endif
 constexpr int kShortTile = TMGCN_SHORT_TILE;      // entries: a mean of at most 8 per row
 
-// flush(tile_row, sum, fl): called by the LPR lanes of the owning group (lane fl of the group holds float4 fl of the sum)
-// once for every row r < n_tile_rows of the wave's sixteen.  Xs = X of the tile's slice (a short tile lies in ONE slice).
+// flush(tile_row, sum, fl): called by the LPR lanes of ONE group (lane fl of the group holds float4 fl of the sum), exactly
+// once for every row r < n_tile_rows of the tile over the block's four waves.  Xs = X of the tile's slice (a short tile lies
+// in ONE slice).
 // The shuffles that hand out an entry's value and row run AFTER the batch's gathers are issued: only the U float4 in
 // flight and the lane's own (col, val, row) are live across the loads.
 template <int LPR, int U, class Flush>
 __device__ __forceinline__ void gather_short_tile(const int32_t* __restrict__ col, const float* __restrict__ val,
                                                   const float4* __restrict__ Xs, const TileRows& rows, int n_tile_rows,
                                                   int F4, int lane, int wave, int stride4, Flush&& flush) {
-  constexpr int S = kWave / LPR;
-  constexpr int RG = 16 / S > 0 ? 16 / S : 1;      // LPR = 4 (F = 16): sixteen groups of one row
-  static_assert(S * RG == 16, "a wave owns sixteen tile rows");
+  constexpr int S = kWave / LPR;                   // lane groups per wave
+  constexpr int NG = 4 * S;                        // ... per block
   const int sub = lane / LPR;
   const int fl = lane % LPR;
   const bool f_ok = fl < F4;
-  const int g0 = 16 * wave + sub * RG;             // first tile row of this lane's group
   // row extents relative to the tile's first entry (<= kShortTile: int32); rows behind the tile's last are empty at its end
   const int64_t tile_beg = readlane64(rows.beg, 0);
   const int tile_ent = (int)rows.entries;
+  const int rb = lane < n_tile_rows ? (int)(rows.beg - tile_beg) : tile_ent;
   const int re = lane < n_tile_rows ? (int)(rows.end - tile_beg) : tile_ent;
-  const int gprev = __shfl(re, g0 ? g0 - 1 : 0);  // every lane takes part: ds_bpermute reads 0 from an inactive lane
-  const int gb = g0 ? gprev : 0, ge = __shfl(re, g0 + RG - 1);
+  // The rows are dealt to the block's NG lane groups by ENTRIES: group G takes the rows that START in the G-th NG-th of the
+  // tile's entry range — consecutive rows, whole rows, at most one row's length off an equal share (a fixed sixteen rows per
+  // wave left the wave with the tile's one 60-entry row 2.3 us behind the others at the barrier).  The first row of group G =
+  // the number of rows that start before its share does: one ballot per boundary.
+  int gb = tile_ent, ge = tile_ent;
+  {
+    int r0 = 0, r1 = 0;
+#pragma unroll
+    for (int s = 0; s <= S; ++s) {
+      const int t = (int)(((int64_t)(wave * S + s) * tile_ent + NG - 1) / NG);        // uniform
+      const int cnt = __popcll(__ballot(rb < t));                                     // rows that start before t
+      if (s == sub) r0 = cnt;
+      if (s == sub + 1) r1 = cnt;
+    }
+    const int b_at_r0 = __shfl(rb, r0 & 63), b_at_r1 = __shfl(rb, r1 & 63);        // every lane takes part
+    gb = r0 < kWave ? b_at_r0 : tile_ent;
+    ge = r1 < kWave ? b_at_r1 : tile_ent;
+  }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int cur = -1;
   for (int b0 = gb; __any(b0 < ge); b0 += LPR) {
     const int e = b0 + fl;                         // the entry this lane fetches for its group
-    int c = 0, rid = g0;
+    int c = 0, rid = 0;
     float v = 0.f;
     if (e < ge) {
       c = col[tile_beg + e];
       v = val[tile_beg + e];
     }
+    // the row of entry e = the number of rows that end at or before e (the row ends ascend): a branch-free bisection over
+    // the 64 ends the lanes hold
 #pragma unroll
-    for (int j = 0; j < RG; ++j) rid += __shfl(re, g0 + j) <= e;   // + the rows of the group that end at or before e
+    for (int step = kWave / 2; step > 0; step >>= 1) rid += (__shfl(re, rid + step - 1) <= e) ? step : 0;
     const int nb = ge - b0 < LPR ? ge - b0 : LPR;  // entries of this batch (<= 0: the group is done)
     for (int p = 0; __any(p < nb); p += U) {
       float4 x[U];
