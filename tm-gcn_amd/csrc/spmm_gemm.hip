@@ -227,11 +227,7 @@ __device__ __forceinline__ void fused_mfma_tile(const FusedArgs& a, const float*
   }
 }
 
-#ifdef TMGCN_FUSED_US_ABS
-template <int LPR, int U, int NJ, int US = TMGCN_FUSED_US_ABS>
-#else
 template <int LPR, int U, int NJ, int US = TMGCN_FUSED_US * U>  // NJ = K / 8 (K is a multiple of 8 here)
-#endif
 __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedArgs a) {
   __shared__ float As[FBM * FLDA];
   __shared__ float4 s_part[4 * LPR];      // partial sums of a long row, one per wave (spmm_row.h)
