@@ -606,6 +606,34 @@ def test_spmm_gemm_fused(K, Nf, trans_w, per_slice):
     assert torch.equal(Y, Y2), "fused kernel not reproducible"
 
 
+@pytest.mark.parametrize("act", [None, "relu", "leaky", "selu"])
+@pytest.mark.parametrize("want_pre", [False, True])
+@pytest.mark.parametrize("N,K,Nf,deg", [(130, 128, 128, 3.0), (77, 64, 40, 20.0), (64, 32, 7, 6.0)])
+def test_spmm_gemm_wide_epilogue_variants(act, want_pre, N, K, Nf, deg):
+    """The wide fused kernel's epilogue (round 6: scalar bases, the activation decoded once — none at all for act = None —,
+    the row guard only in the half tile a slice ends in; csrc/spmm_gemm.hip fused_store_half): every activation, with and
+    without the pre-activation output, slices that end inside a half tile (N = 130, 77) and on its edge (64), output widths
+    that do and do not fill the waves' 32-column strips — Y, pre and AX against the oracle, reruns bit-equal."""
+    from oracle import tmgcn_oracle as orc
+    T = 3
+    csr = rand_csr(T, N, deg, seed=N + K)
+    g = torch.Generator().manual_seed(N * 3 + Nf)
+    X = torch.randn(T, N, K, generator=g)
+    W = torch.randn(K, Nf, generator=g) * 0.3
+    Y, AX, pre = ops.kernels.spmm_gemm(csr.to(DEV), X.to(DEV), W.to(DEV), act=act, want_ax=True, want_pre=want_pre)
+    ref_ax = ref_spmm(csr, X)
+    ref_pre = ref_gemm(ref_ax, W, False, False)
+    assert_close(AX, ref_ax, REL_TOL, "wide fused: SpMM intermediate")
+    if want_pre and act:                                   # (without an activation Y IS the pre-activation: the op returns none)
+        assert_close(pre, ref_pre, REL_TOL, "wide fused: pre-activation")
+    else:
+        assert pre is None
+    want = orc.ACTS[act](ref_pre) if act else ref_pre
+    assert_close(Y, want, REL_TOL, f"wide fused: act={act}")
+    Y2, _, pre2 = ops.kernels.spmm_gemm(csr.to(DEV), X.to(DEV), W.to(DEV), act=act, want_pre=want_pre)
+    assert torch.equal(Y, Y2) and (pre is None or torch.equal(pre, pre2))
+
+
 @pytest.mark.parametrize("act", [None, "selu"])
 def test_spmm_gemm_autograd_matches_unfused(act):
     """Fused op (backward = (ÂᵀdY)Wᵀ) against the two-kernel path (backward = Âᵀ(dY Wᵀ))."""
