@@ -127,6 +127,44 @@ def test_spmm_gemm_long_rows_split_across_waves(case, K, Nf, per_slice):
     assert torch.equal(Y, Y2)
 
 
+@pytest.mark.parametrize("F", [16, 24, 64, 128, 200, 256])
+def test_short_tiles_mix_with_the_other_walks(F):
+    """Tiles on both sides of the short-tile threshold (512 entries per 64 rows, csrc/spmm_row.h) in ONE launch: slices whose
+    rows hold 0-3 entries (entry-major walk; whole tiles of empty rows; a ragged last tile: N = 333), slices of 9-30 per row
+    (row per wave), a tile at exactly 512 and one at 513 entries, a short tile holding one 200-entry row, and a tile with a
+    300-entry row (four-wave split) — plain kernel vs the C oracle, the fused kernel's SpMM intermediate bit-equal to it
+    (one row-sum order whichever kernel and weight layout), reruns bit-equal."""
+    T, N = 4, 333
+    g = torch.Generator().manual_seed(F)
+    cnt = torch.zeros(T, N, dtype=torch.int64)
+    cnt[0] = torch.randint(0, 4, (N,), generator=g)
+    cnt[0, 64:128] = 0                                   # a tile of empty rows
+    cnt[1] = torch.randint(9, 31, (N,), generator=g)
+    cnt[2] = 8
+    cnt[2, 0:64] = 8                                     # exactly 512 entries
+    cnt[2, 64:128] = 8
+    cnt[2, 64] = 9                                       # 513: the other side of the threshold
+    cnt[2, 128:192] = 1
+    cnt[2, 130] = 200                                    # a short tile with one long-ish row (<= 256)
+    cnt[3] = 2
+    cnt[3, 200] = 300                                    # > 256: the four-wave split inside an otherwise short tile
+    rowptr = torch.zeros(T * N + 1, dtype=torch.int64)
+    torch.cumsum(cnt.reshape(-1), 0, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    csr = BatchedCSR(rowptr, torch.randint(0, N, (nnz,), generator=g, dtype=torch.int32), torch.randn(nnz, generator=g), T, N)
+    X = torch.randn(T, N, F, generator=g)
+    A = csr.to(DEV)
+    Y1 = ops.kernels.spmm(A, X.to(DEV))
+    assert_close(Y1, ref_spmm(csr, X), REL_TOL, f"mixed tiles F={F}")
+    assert torch.equal(Y1, ops.kernels.spmm(A, X.to(DEV)))
+    if F <= 128 and F % 8 == 0:
+        for per_slice in (False, True):
+            W = torch.randn(*((T, F, 40) if per_slice else (F, 40)), generator=g) * 0.2
+            Y, AX, _ = ops.kernels.spmm_gemm(A, X.to(DEV), W.to(DEV), want_ax=True)
+            assert torch.equal(AX, Y1), "fused and plain kernels sum a row in different orders"
+            assert_close(Y, ref_gemm(ref_spmm(csr, X), W, False, per_slice), REL_TOL, f"mixed tiles fused F={F}")
+
+
 @pytest.mark.parametrize("case", ["threshold", "one heavy tile of two"])
 @pytest.mark.parametrize("F,Nf", [(2, 6), (6, 6), (8, 4), (3, 16)])
 def test_narrow_kernels_leave_long_rows_to_the_whole_wave(case, F, Nf):
