@@ -10,10 +10,15 @@
 // (HBM idle); run back to back they cost the sum, fused the GEMM hides under the gather and
 // the [T,N,F] intermediate is not re-read (it is still written once when the caller needs it
 // for dW).  Structure per 64-row tile of a persistent 256-thread block:
-//   phase 1  each wave gathers 16 rows (spmm_row.h), row sums go to an LDS tile [64][K+4]
+//   phase 1  each wave gathers 16 rows — or, in a tile of few entries, the four waves' lane groups an equal share of the
+//            tile's entries each (spmm_row.h) —, row sums go to an LDS tile [64][K+4]
 //   phase 2  exact-f32 MFMA (v_mfma_f32_32x32x2_f32): wave w owns output columns
 //            [32w, 32w+32); its B fragments (a 32-column strip of W) stay in registers for the
 //            whole launch; A fragments come from the LDS tile with conflict-free ds_read_b128.
+// The two phases of a block alternate, and on gfx950 an exact-f32 MFMA chain does not overlap another wave's vector work on the
+// same SIMD (tools/probes/mfma_valu_overlap.hip): at S4's 33 entries per row the products are 5 % of a tile and disappear
+// in the bandwidth-bound gather of the CU's other blocks; at the 4 entries per row of the reference's real operand gather and
+// products add up (DESIGN.md §4 "Short tiles").
 #include "common.h"
 #include "spmm_row.h"
 
