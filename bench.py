@@ -1158,6 +1158,26 @@ def worker(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # a reader's summary on stderr (the JSON line on stdout stays the last line of stdout, alone)
+        try:
+            r = out["roofline"]
+            stage(f"summary: {out['ms_per_step']:.1f} ms/step, {out['value'] / 1e9:.2f} G edge-slices/s, roofline.frac {r['frac']:.3f}"
+                  + (f" (hbm-only {r['frac_hbm_only']:.3f})" if r.get("frac_hbm_only") is not None else "")
+                  + (f", verify {'ok' if (out.get('verify') or {}).get('ok') else 'FAILED'}" if out.get("verify") else ""))
+            for name, leg in (r.get("legs") or {}).items():
+                if "error" in leg:
+                    stage(f"summary: leg {name}: {leg['error']}")
+                else:
+                    stage(f"summary: leg {name}: forward {leg['forward_launch_ms']:.1f} ms / backward {leg['backward_launch_ms']:.1f} ms, "
+                          f"frac {leg['frac']:.3f} (forward {leg['frac_forward_only']:.3f} on {leg['basis_forward']} bytes, backward on "
+                          f"{leg['basis_backward']} bytes), {leg['ms_per_step']:.1f} ms/step, verify {'ok' if leg['verify_ok'] else 'FAILED'}")
+            cb = out.get("cpu_baseline")
+            if cb:
+                stage(f"summary: cpu_baseline {cb['value'] / 1e6:.2f} M edge-slices/s on {cb['cores']} threads (GPU / CPU {cb.get('gpu_over_cpu') or 0:.0f}x)"
+                      + "".join(f"; {k} epoch {v['gpu_captured_ms']:.3f} ms captured / {v.get('gpu_script_ms') or float('nan'):.3f} script / "
+                                f"{v['cpu_ms']:.0f} CPU" for k, v in (cb.get("epochs") or {}).items() if isinstance(v, dict) and k in ("S2",)))
+        except Exception as e:                       # never let a summary line cost the record
+            stage(f"summary: not printed ({e!r})")
         print(json.dumps(out), flush=True)
     stage("done")
     bad = [v for v in (res.get("verify"), ((compare or {}).get("full_n") or {}).get(
