@@ -71,7 +71,7 @@ struct FusedArgs {
 #define TMGCN_FUSED_BLOCKS 4   // development only: resident blocks per CU the grid is sized for (of 4)
 #endif
 #ifndef TMGCN_DEV_SKIP
-#define TMGCN_DEV_SKIP 0    // development only (phase breakdown, profiles/r6/r6_05_*): 1 no gather, 2 no products, 4 no Y stores
+#define TMGCN_DEV_SKIP 0    // development only (phase breakdown, profiles/r6/r6_05_*): 1 no gather, 2 no products, 4 no Y stores, 8 a third of the products
 #endif
 
 // Development build only (-DTMGCN_FUSED_TRACE, tools/fused_trace.py): thread 0 of every block sums the 100 MHz wall-clock time
@@ -207,7 +207,7 @@ __device__ __forceinline__ void fused_mfma_tile(const FusedArgs& a, const float*
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float4 av_next = *reinterpret_cast<const float4*>(Arow + mb * 32 * FLDA);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < ((TMGCN_DEV_SKIP & 8) ? (NJ + 2) / 3 : NJ); ++j) {      // (8: a THIRD of the products — a timing bound, wrong results)
       const float4 av = av_next;
       if (j + 1 < NJ) av_next = *reinterpret_cast<const float4*>(Arow + mb * 32 * FLDA + 8 * (j + 1));
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, wreg[j][0], acc, 0, 0, 0);
