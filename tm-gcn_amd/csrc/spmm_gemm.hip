@@ -111,7 +111,7 @@ __device__ __forceinline__ void fused_load_w(const FusedArgs& a, int64_t batch, 
 // long rows afterwards on all four waves.
 template <int LPR, int U, int US>
 __device__ __forceinline__ void fused_gather_tile(const FusedArgs& a, float* As, float4* s_part, const TileRows& rows, int64_t row0,
-                                                  int64_t row_end, int lane, int wave) {
+                                                  int64_t row_end, int lane, int wave, unsigned int* s_row) {
   const int F4 = a.K / 4;
   const int n_tile_rows = row_end - row0 < FBM ? (int)(row_end - row0) : FBM;
   const int64_t slice0 = row0 / a.N;
@@ -127,7 +127,14 @@ __device__ __forceinline__ void fused_gather_tile(const FusedArgs& a, float* As,
                                });
     return;
   }
-  for (int rr = wave; rr < FBM; rr += 4) {
+  // The rows of the tile are DRAWN by the four waves (an LDS counter, 4 at the start of a tile; the draw is issued in front of
+  // the row it follows, so its latency hides under that row's gather): with a fixed deal — rows w, w + 4, … — the waves of a
+  // skewed tile met 10.9 us apart at the barrier behind this loop (power-law graph, traced; equal rows: 1.5).  A row is summed
+  // by whichever wave draws it, in the same order: the same bits.  Worth 0.3-0.5 % on the power-law graph (the launch is
+  // bandwidth-bound: the CU's other blocks fill the wait), nothing on equal rows (profiles/r6/r6_35_*).
+  for (int rr = wave; rr < FBM;) {
+    unsigned int nxt = 0;
+    if (lane == 0) nxt = atomicAdd(s_row, 1u);
     const int64_t r = row0 + rr;
     const bool lng = (rows.long_mask >> rr) & 1;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -140,6 +147,7 @@ __device__ __forceinline__ void fused_gather_tile(const FusedArgs& a, float* As,
       *reinterpret_cast<float4*>(&As[rr * FLDA + 4 * lane]) = acc;
       if (a.AX && r < row_end) store_f4(&reinterpret_cast<float4*>(a.AX)[r * F4 + lane], acc);
     }
+    rr = (int)__builtin_amdgcn_readfirstlane(nxt);
   }
   for (uint64_t m = rows.long_mask; m; m &= m - 1) {
     const int rr = __builtin_ctzll(m);
@@ -243,7 +251,8 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
 
   float wreg[NJ][4];
   int64_t cur_batch = -1;
-  __shared__ unsigned int s_tile;
+  __shared__ unsigned int s_tile, s_row;
+  if (threadIdx.x == 0) s_row = 4;        // (the first use is behind the barrier of the first tile draw)
   HeavyScan heavy;
   heavy.init(a.rowptr, tm);
 
@@ -286,10 +295,11 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
       fused_load_w<NJ>(a, batch, n0, lane & 31, lane >> 5, wreg);
       cur_batch = batch;
     }
-    fused_gather_tile<LPR, U, US>(a, As, s_part, rows, row0, row_end, lane, wave);
+    fused_gather_tile<LPR, U, US>(a, As, s_part, rows, row0, row_end, lane, wave, &s_row);
     FT_WAIT();
     FT_STAMP(ft_d);
     __syncthreads();
+    if (threadIdx.x == 0) s_row = 4;        // for the next tile's row draws (two barriers away)
     FT_STAMP(ft_e);
     // the product phase at raised issue priority: its waves hold the block's LDS tile and share the SIMD with three other
     // blocks' waves that are waiting for gathered rows anyway (round 6: -4.5 % on the chess operand at bench size, -6 % at
