@@ -64,6 +64,12 @@ struct FusedArgs {
 #ifndef TMGCN_FUSED_US
 #define TMGCN_FUSED_US 1    // gathers in flight per lane on short tiles, as a multiple of U
 #endif
+#ifndef TMGCN_BX3_US
+#define TMGCN_BX3_US 4           // gathers in flight per lane on its short tiles
+#endif
+#ifndef TMGCN_BX3_MAX_DEG
+#define TMGCN_BX3_MAX_DEG 14     // launches with fewer entries per row (the caller's hint) take the bf16-product kernel (measured: -9 % at 4, -6 % at 8, -4 % at 12, 0 at 16)
+#endif
 #ifndef TMGCN_FUSED_MFMA_PRIO
 #define TMGCN_FUSED_MFMA_PRIO 3
 #endif
@@ -334,6 +340,190 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
 #endif
 }
 
+
+// ---- the low-degree kernel (round 6): the products on the bf16 matrix cores ---------------------------------------------------
+// On gfx950 an exact-f32 MFMA chain and another wave's vector work on the same SIMD serialize (tools/probes/mfma_valu_overlap.hip),
+// so at few entries per row — the reference's real operand has 4 — the tile kernel's launch is its gather PLUS its products
+// (8 + 9 ms on that operand at bench size).  This kernel does the products the way the library's standalone GEMM does
+// (gemm.hip gemm_bf16x3): every fp32 operand split exactly into three bf16 planes, the six plane products that matter on
+// v_mfma_f32_16x16x32_bf16 — a third of the matrix-pipe time, on a pipe of its own — i.e. the numerics of the unfused
+// default route (SpMM + bf16-split GEMM: within 1e-5 of the oracle, measured 3e-7), not the exact-f32 chain of the tile kernel.
+// Shape: 512-thread blocks, two per CU.  All eight waves gather (the same row walks in the same order: AX stays bit-equal to
+// the plain kernel's); a row's sum is split when it is flushed and written as three bf16 plane images [64][272 B] (gemm.hip's
+// conflict-free pitch); then each wave multiplies the tile by ITS 16-column strip of Wop, whose planes it holds in 12·K/32
+// registers (48 at K = 128 — fewer than the 64 f32 fragments of the tile kernel, which is what lets eight waves fit).
+typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float bx_f32x2 __attribute__((ext_vector_type(2)));
+typedef float bx_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int BX_PITCH = 272;                  // bytes per row of a plane image: 128 bf16 + 16 B pad
+constexpr int BX_PLANE = FBM * BX_PITCH;       // 17 408 B
+
+__device__ __forceinline__ unsigned bx_pack(float a, float b) {  // bf16(a) | bf16(b) << 16, RNE
+  bx_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bx_bf16x2));
+}
+__device__ __forceinline__ void bx_split3(float a, float b, unsigned& h, unsigned& m, unsigned& l) {   // x = hi + mid + lo, exactly
+  h = bx_pack(a, b);
+  a -= __uint_as_float(h << 16);
+  b -= __uint_as_float(h & 0xffff0000u);
+  m = bx_pack(a, b);
+  a -= __uint_as_float(m << 16);
+  b -= __uint_as_float(m & 0xffff0000u);
+  l = bx_pack(a, b);
+}
+
+template <int LPR, int U, int NKS, int US>     // NKS = K / 32
+__global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[3 * BX_PLANE];
+  __shared__ float4 s_part[4 * LPR];
+  __shared__ unsigned int s_tile, s_row;
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // 0..7
+  const int n0 = wave * 16;                                                // this wave's column strip
+  const int F4 = a.K / 4;
+  const TileMap tm = a.tiles;
+  unsigned bw[NKS][3][4];                                                  // B fragments of Wop: [k-step][plane][8 bf16]
+  int64_t cur_batch = -1;
+  if (threadIdx.x == 0) s_row = 8;
+  HeavyScan heavy;                                                         // the heaviest tiles first, as in the tile kernel
+  heavy.init(a.rowptr, tm);
+  for (;;) {
+    int lane = lane0;                                                      // laundered per tile (see the tile kernel)
+    asm volatile("" : "+v"(lane));
+    int64_t tile = -1;
+    if (heavy.scanning) tile = heavy.next(a.rowptr, tm, a.tile_counter + 1, &s_tile, lane);
+    const bool scanning = heavy.scanning;
+    if (!scanning) {
+      if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter, 1u);
+      __syncthreads();
+      tile = s_tile;
+      if (tile >= a.n_tiles) break;
+    }
+    int64_t unit, row0, row_end;
+    tile_extent(tm, tile, unit, row0, row_end);
+    const int64_t batch = a.rows_per_batch ? row0 / a.rows_per_batch : 0;
+    TileRows rows;
+    rows.load(a.rowptr, row0, row_end, lane);
+    if (TMGCN_HEAVY_FIRST && !scanning && rows.entries > heavy.thr) {     // done in somebody's pass 1
+      __syncthreads();
+      continue;
+    }
+    const int n_tile_rows = row_end - row0 < FBM ? (int)(row_end - row0) : FBM;
+    const int64_t slice0 = row0 / a.N;
+    const float4* Xs = a.X + slice0 * (int64_t)a.N * F4;                   // (tiles restart at every slice)
+    // a row's sum: three plane images in LDS (8 bytes per plane and lane) and, when asked for, AX
+    auto flush = [&](int rr, const float4& acc, int fl) __attribute__((always_inline)) {
+      if (fl < F4) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        bx_split3(acc.x, acc.y, h0, m0, l0);
+        bx_split3(acc.z, acc.w, h1, m1, l1);
+        unsigned char* w = sm + rr * BX_PITCH + fl * 8;
+        *reinterpret_cast<uint2*>(w) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(w + BX_PLANE) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(w + 2 * BX_PLANE) = make_uint2(l0, l1);
+        if (a.AX && rr < n_tile_rows) store_f4(&reinterpret_cast<float4*>(a.AX)[(row0 + rr) * F4 + fl], acc);
+      }
+    };
+    if (short_tile(rows, row0 + n_tile_rows <= (slice0 + 1) * a.N)) {
+      gather_short_tile<LPR, US, 8>(a.col, a.val, Xs, rows, n_tile_rows, F4, lane, wave, F4, flush);
+    } else {
+      for (int rr = wave; rr < FBM;) {                                    // rows drawn by the eight waves (LDS counter)
+        unsigned int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(&s_row, 1u);
+        const bool lng = (rows.long_mask >> rr) & 1;
+        if (!lng) {
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rr < n_tile_rows) acc = gather_row<LPR, U>(a.col, a.val, Xs, readlane64(rows.beg, rr), readlane64(rows.end, rr), F4, lane);
+          if (lane < LPR) flush(rr, acc, lane);
+        }
+        rr = (int)__builtin_amdgcn_readfirstlane(nxt);
+      }
+      for (uint64_t m = rows.long_mask; m; m &= m - 1) {                  // long rows: waves 0-3 share each (the same quarters, the
+        const int rr = __builtin_ctzll(m);                                // same order as everywhere); waves 4-7 keep the barriers company
+        const int64_t beg = readlane64(rows.beg, rr), end = readlane64(rows.end, rr);
+        if (wave < 4) {
+          const float4 acc = gather_long_row<LPR, U>(a.col, a.val, Xs, beg, end, F4, lane, wave, s_part);
+          if (wave == (rr & 3) && lane < LPR) flush(rr, acc, lane);
+        } else {
+          __syncthreads();
+          __syncthreads();
+        }
+      }
+    }
+    if (batch != cur_batch) {                                              // Wop[k][n0 + n]: this lane's column, k = 32 ks + 8 (lane / 16) + 2 j, + 1
+      const float* Wb = a.W + (a.rows_per_batch ? batch * a.w_batch_stride : 0);
+      const int n = n0 + (lane & 15);
+      const int nc = n < a.Nf ? n : 0;
+      const float zn = n < a.Nf ? 1.f : 0.f;
+      const int64_t sk = a.trans_w ? 1 : a.Nf, sn = a.trans_w ? a.K : 1;
+      const float* Wl = Wb + (int64_t)nc * sn + (int64_t)(8 * (lane >> 4)) * sk;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float w0 = Wl[(int64_t)(32 * ks + 2 * j) * sk] * zn;
+          const float w1 = Wl[(int64_t)(32 * ks + 2 * j + 1) * sk] * zn;
+          bx_split3(w0, w1, bw[ks][0][j], bw[ks][1][j], bw[ks][2][j]);
+        }
+      cur_batch = batch;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_row = 8;
+    // ---- products: 4 row blocks of 16 x this wave's 16 columns; per (row block, k-step) six plane products, small terms first
+    __builtin_amdgcn_s_setprio(TMGCN_FUSED_MFMA_PRIO);
+    if (n0 < a.Nf) {
+      int lane_p = lane0;
+      asm volatile("" : "+v"(lane_p));
+      const int lm = lane_p & 15, lg = lane_p >> 4;
+      const unsigned char* rd = sm + lm * BX_PITCH + lg * 16;
+      bx_f32x4 acc[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) acc[rb] = bx_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bx_bf16x8 bh = __builtin_bit_cast(bx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
+        const bx_bf16x8 bm = __builtin_bit_cast(bx_bf16x8, make_uint4(bw[ks][1][0], bw[ks][1][1], bw[ks][1][2], bw[ks][1][3]));
+        const bx_bf16x8 bl = __builtin_bit_cast(bx_bf16x8, make_uint4(bw[ks][2][0], bw[ks][2][1], bw[ks][2][2], bw[ks][2][3]));
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const unsigned char* p = rd + rb * 16 * BX_PITCH + ks * 64;
+          const bx_bf16x8 ah = __builtin_bit_cast(bx_bf16x8, *reinterpret_cast<const uint4*>(p));
+          const bx_bf16x8 am = __builtin_bit_cast(bx_bf16x8, *reinterpret_cast<const uint4*>(p + BX_PLANE));
+          const bx_bf16x8 al = __builtin_bit_cast(bx_bf16x8, *reinterpret_cast<const uint4*>(p + 2 * BX_PLANE));
+          bx_f32x4 c = acc[rb];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+          acc[rb] = c;
+        }
+      }
+      // epilogue: accumulator i of block rb is row 16 rb + 4 lg + i, column n0 + lm
+      const int n = n0 + lm;
+      if (n < a.Nf) {
+        const ActApply act(a.act);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rr = 16 * rb + 4 * lg + i;
+            if (rr < n_tile_rows) {
+              const float v = acc[rb][i];
+              const int64_t o = (row0 + rr) * a.Nf + n;
+              if (a.pre) store_f1(&a.pre[o], v);
+              store_f1(&a.Y[o], a.act == TMGCN_ACT_NONE ? v : act(v));
+            }
+          }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();      // the planes are consumed before the next tile's rows overwrite them
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Small-F variant (the reference's real widths: F = 2 -> 6 -> 6): G lanes share a
 // row and stride over its non-zeros as in spmm_small; after the shuffle butterfly every lane of
@@ -481,6 +671,19 @@ extern "C" int tmgcn_spmm_gemm_f32_plan(const int64_t* rowptr, const int32_t* co
   a.tile_counter = acquire_tile_counters((hipStream_t)stream, 2);      // [0] the main loop's tiles, [1] the heavy-tile scan windows
   TMGCN_REQUIRE(a.tile_counter, "spmm_gemm: no tile counter: %s", pool_error());
   hipStream_t st = (hipStream_t)stream;
+  // few entries per row (the caller's hint), no giant-row plan, K = 64 or 128: the products on the bf16 matrix cores
+  if (avg_nnz_per_row >= 0.f && avg_nnz_per_row < (float)TMGCN_BX3_MAX_DEG && n_giant == 0 && (K == 128 || K == 64)) {
+    if (K == 128) {
+      int64_t gx = persistent_grid(spmm_gemm_bx3_kernel<32, TMGCN_FUSED_U, 4, TMGCN_BX3_US>, 512, 0, 2);
+      if (gx > a.n_tiles) gx = a.n_tiles;
+      hipLaunchKernelGGL((spmm_gemm_bx3_kernel<32, TMGCN_FUSED_U, 4, TMGCN_BX3_US>), dim3((unsigned)gx), dim3(512), 0, st, a);
+    } else {
+      int64_t gx = persistent_grid(spmm_gemm_bx3_kernel<16, TMGCN_FUSED_U, 2, TMGCN_BX3_US>, 512, 0, 2);
+      if (gx > a.n_tiles) gx = a.n_tiles;
+      hipLaunchKernelGGL((spmm_gemm_bx3_kernel<16, TMGCN_FUSED_U, 2, TMGCN_BX3_US>), dim3((unsigned)gx), dim3(512), 0, st, a);
+    }
+    return check_launch("spmm_gemm (bf16-split products)");
+  }
   // persistent blocks: up to 4 per CU (LDS 33.8 KB each); tiles are drawn in ascending order so the
   // blocks resident at any moment work on neighbouring rows of the same slice
 #define TMGCN_FUSED_CASE(KK, L, UU)                                                              \

@@ -235,12 +235,12 @@ constexpr int kShortTile = TMGCN_SHORT_TILE;      // entries: a mean of at most 
 // in ONE slice).
 // The shuffles that hand out an entry's value and row run AFTER the batch's gathers are issued: only the U float4 in
 // flight and the lane's own (col, val, row) are live across the loads.
-template <int LPR, int U, class Flush>
+template <int LPR, int U, int NW = 4, class Flush>        // NW: the waves that share the tile (4; the bf16-product kernel: 8)
 __device__ __forceinline__ void gather_short_tile(const int32_t* __restrict__ col, const float* __restrict__ val,
                                                   const float4* __restrict__ Xs, const TileRows& rows, int n_tile_rows,
                                                   int F4, int lane, int wave, int stride4, Flush&& flush) {
   constexpr int S = kWave / LPR;                   // lane groups per wave
-  constexpr int NG = 4 * S;                        // ... per block
+  constexpr int NG = NW * S;                       // ... per block
   const int sub = lane / LPR;
   const int fl = lane % LPR;
   const bool f_ok = fl < F4;
@@ -311,7 +311,7 @@ __device__ __forceinline__ void gather_short_tile(const int32_t* __restrict__ co
   }
   if (cur >= 0) flush(cur, acc, fl);
   // rows without entries are never met by the walk: their sum is zero
-  const uint64_t empty = __ballot(lane < n_tile_rows && rows.end == rows.beg) & (0xffffull << (16 * wave));
+  const uint64_t empty = __ballot(lane < n_tile_rows && rows.end == rows.beg) & ((~0ull >> (kWave - kWave / NW)) << (kWave / NW * wave));
   for (uint64_t m = empty; m; m &= m - 1)
     if (sub == 0) flush(__builtin_ctzll(m), make_float4(0.f, 0.f, 0.f, 0.f), fl);
 }
