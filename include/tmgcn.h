@@ -173,7 +173,10 @@ int tmgcn_spmm_gemm_f32(const int64_t* rowptr, const int32_t* col, const float* 
                         float* Y, float* AX, float* pre_act, int32_t grid_reserve, void* stream);
 /* Same, with the caller's average stored non-zeros per row (< 0: unknown) — steers how many lanes
  * share a row in the narrow (K <= 8) kernel, i.e. the order in which a row's terms are added, as in
- * tmgcn_spmm_csr_batched_f32_hint. */
+ * tmgcn_spmm_csr_batched_f32_hint; and, for K = 64 / 128, how the products are formed: exact-f32 MFMAs (an fmaf chain in
+ * k order; always without a hint), or — below 14 non-zeros per row, where the products are as long as the gather — on the
+ * bf16 matrix cores after an exact 3-way split of both operands, i.e. the numerics of tmgcn_gemm_f32's TMGCN_GEMM_AUTO
+ * (the unfused default route).  AX does not depend on the hint. */
 int tmgcn_spmm_gemm_f32_hint(const int64_t* rowptr, const int32_t* col, const float* val,
                              const float* X, int64_t n_rows, int32_t N, int32_t K,
                              const float* W, int32_t Nf, int32_t trans_w,
