@@ -747,8 +747,10 @@ def measure_leg(args, name):
         rec["mfma"] = {"flops_per_launch": fl, "tflops_forward": fl / (cr["forward_launch_ms"] * 1e-3) / 1e12,
                        "peak_tflops_f32_matrix": F32_MATRIX_PEAK_TFLOPS,
                        "frac_forward": fl / (cr["forward_launch_ms"] * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS,
-                       "note": "v_mfma_f32_32x32x2_f32 (exact fp32): at 4 entries per row the products of a launch take as long on the "
-                               "matrix cores as its compulsory bytes take on HBM"}
+                       "note": "fp32-equivalent flops of the products (2·K·Nf per row) against the fp32 matrix peak; below 14 entries per "
+                               "row they are formed as six bf16 plane products per term on v_mfma_f32_16x16x32_bf16 (csrc/spmm_gemm.hip "
+                               "spmm_gemm_bx3_kernel): a third of the pipe time of the exact-f32 MFMAs, which at 4 entries per row took "
+                               "as long on the matrix cores as the launch's compulsory bytes take on HBM"}
     return rec
 
 
@@ -805,11 +807,12 @@ def measure_traffic(args, what="headline", **over):
             if r.returncode != 0:
                 return None, f"the {counter} pass exited {r.returncode}: {(r.stderr or '')[-300:]}"
             got[counter] = pmc_traffic.read_pass(d, counter)
-    fused_f = [v for k, v in got["FETCH_SIZE"].items() if "spmm_gemm_kernel" in k]
-    fused_w = [v for k, v in got["WRITE_SIZE"].items() if "spmm_gemm_kernel" in k]
+    fused = lambda k: "spmm_gemm_kernel" in k or "spmm_gemm_bx3_kernel" in k     # (few entries per row: the bf16-product kernel)
+    fused_f = [v for k, v in got["FETCH_SIZE"].items() if fused(k)]
+    fused_w = [v for k, v in got["WRITE_SIZE"].items() if fused(k)]
     band_f = [v for k, v in got["FETCH_SIZE"].items() if "mtransform_band_kernel" in k]
     if not fused_f or not fused_w:
-        return None, "no spmm_gemm_kernel dispatch in the counter output"
+        return None, "no spmm_gemm_kernel / spmm_gemm_bx3_kernel dispatch in the counter output"
     pairs = list(zip(fused_f[0], fused_w[0]))                       # dispatches alternate forward / backward
     fwd = max(pairs, key=lambda q: q[1])                            # forward also stores AX and Y
     bwd = min(pairs, key=lambda q: q[1])
