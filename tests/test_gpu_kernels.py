@@ -646,12 +646,15 @@ def test_spmm_gemm_fused(K, Nf, trans_w, per_slice):
 
 @pytest.mark.parametrize("act", [None, "relu", "leaky", "selu"])
 @pytest.mark.parametrize("want_pre", [False, True])
-@pytest.mark.parametrize("N,K,Nf,deg", [(130, 128, 128, 3.0), (77, 64, 40, 20.0), (64, 32, 7, 6.0)])
+@pytest.mark.parametrize("N,K,Nf,deg", [(130, 128, 128, 3.0), (77, 64, 40, 20.0), (64, 32, 7, 6.0),
+                                        (130, 128, 126, 3.0), (77, 64, 40, 3.0), (200, 128, 30, 2.0), (64, 64, 128, 5.0)])
 def test_spmm_gemm_wide_epilogue_variants(act, want_pre, N, K, Nf, deg):
     """The wide fused kernel's epilogue (round 6: scalar bases, the activation decoded once — none at all for act = None —,
     the row guard only in the half tile a slice ends in; csrc/spmm_gemm.hip fused_store_half): every activation, with and
     without the pre-activation output, slices that end inside a half tile (N = 130, 77) and on its edge (64), output widths
-    that do and do not fill the waves' 32-column strips — Y, pre and AX against the oracle, reruns bit-equal."""
+    that do and do not fill the waves' 32-column strips — Y, pre and AX against the oracle, reruns bit-equal.  The cases of
+    fewer than 14 entries per row at K = 128 / 64 run the bf16-product kernel (spmm_gemm_bx3_kernel): its Y tile leaves
+    through LDS as whole rows when a row is a whole number of float4 (Nf = 128, 40), from the accumulators otherwise (126, 30)."""
     from oracle import tmgcn_oracle as orc
     T = 3
     csr = rand_csr(T, N, deg, seed=N + K)

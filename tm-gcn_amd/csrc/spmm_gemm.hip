@@ -67,6 +67,9 @@ struct FusedArgs {
 #ifndef TMGCN_BX3_US
 #define TMGCN_BX3_US 4           // gathers in flight per lane on its short tiles
 #endif
+#ifndef TMGCN_BX_STAGED_Y
+#define TMGCN_BX_STAGED_Y 1      // the bf16-product kernel's Y tile leaves through LDS as whole rows (0: 64-byte pieces from the accumulators)
+#endif
 #ifndef TMGCN_BX3_MAX_DEG
 #define TMGCN_BX3_MAX_DEG 14     // launches with fewer entries per row (the caller's hint) take the bf16-product kernel (measured: -9 % at 4, -6 % at 8, -4 % at 12, 0 at 16)
 #endif
@@ -358,6 +361,7 @@ typedef float bx_f32x2 __attribute__((ext_vector_type(2)));
 typedef float bx_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BX_PITCH = 272;                  // bytes per row of a plane image: 128 bf16 + 16 B pad
 constexpr int BX_PLANE = FBM * BX_PITCH;       // 17 408 B
+constexpr int BX_YPITCH = 132;                 // floats per row of the Y tile handed over through LDS (33 792 B of the planes' 52 224): rows 4 apart are 16 banks apart
 
 __device__ __forceinline__ unsigned bx_pack(float a, float b) {  // bf16(a) | bf16(b) << 16, RNE
   bx_f32x2 v = {a, b};
@@ -386,6 +390,8 @@ __global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
   unsigned bw[NKS][3][4];                                                  // B fragments of Wop: [k-step][plane][8 bf16]
   int64_t cur_batch = -1;
   if (threadIdx.x == 0) s_row = 8;
+  // whole rows of aligned float4: Y leaves through LDS (see the epilogue)
+  const bool staged = TMGCN_BX_STAGED_Y && a.Nf % 4 == 0 && reinterpret_cast<uintptr_t>(a.Y) % 16 == 0 && reinterpret_cast<uintptr_t>(a.pre) % 16 == 0;
   HeavyScan heavy;                                                         // the heaviest tiles first, as in the tile kernel
   heavy.init(a.rowptr, tm);
   for (;;) {
@@ -472,14 +478,14 @@ __global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
     if (threadIdx.x == 0) s_row = 8;
     // ---- products: 4 row blocks of 16 x this wave's 16 columns; per (row block, k-step) six plane products, small terms first
     __builtin_amdgcn_s_setprio(TMGCN_FUSED_MFMA_PRIO);
-    if (n0 < a.Nf) {
-      int lane_p = lane0;
-      asm volatile("" : "+v"(lane_p));
-      const int lm = lane_p & 15, lg = lane_p >> 4;
-      const unsigned char* rd = sm + lm * BX_PITCH + lg * 16;
-      bx_f32x4 acc[4];
+    int lane_p = lane0;
+    asm volatile("" : "+v"(lane_p));
+    const int lm = lane_p & 15, lg = lane_p >> 4;
+    bx_f32x4 acc[4];
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) acc[rb] = bx_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < 4; ++rb) acc[rb] = bx_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n0 < a.Nf) {
+      const unsigned char* rd = sm + lm * BX_PITCH + lg * 16;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         const bx_bf16x8 bh = __builtin_bit_cast(bx_bf16x8, make_uint4(bw[ks][0][0], bw[ks][0][1], bw[ks][0][2], bw[ks][0][3]));
@@ -501,7 +507,10 @@ __global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
           acc[rb] = c;
         }
       }
-      // epilogue: accumulator i of block rb is row 16 rb + 4 lg + i, column n0 + lm
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // epilogue: accumulator i of block rb is row 16 rb + 4 lg + i, column n0 + lm
+    if (!staged) {                                                       // (an output that is not a whole number of aligned float4 per row)
       const int n = n0 + lm;
       if (n < a.Nf) {
         const ActApply act(a.act);
@@ -518,9 +527,41 @@ __global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
             }
           }
       }
+    } else {
+      // A wave owns 16 columns: stored from the accumulators, every row of Y is written as eight 64-byte pieces, a dword per lane
+      // (the tile kernel's 32-column strips write whole 128-byte lines).  Handed over through LDS — the planes' memory, free once
+      // every wave has read it — the tile is stored row by row, 16 bytes per lane: whole lines, a quarter of the store
+      // instructions.  Two more barriers per tile, and still 6 % off the launch (chess operand 13.76 -> 12.92 ms; profiles/r6/r6_70_*).
+      __syncthreads();                                                   // every wave is through with the planes
+      float* yt = reinterpret_cast<float*>(sm);
+      if (n0 < a.Nf) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) yt[(16 * rb + 4 * lg + i) * BX_YPITCH + n0 + lm] = acc[rb][i];
+      }
+      __syncthreads();                                                   // the tile is in LDS
+      int lane_s = lane0;
+      asm volatile("" : "+v"(lane_s));
+      const int c4 = lane_s & 31;                                        // float4 of the row; two rows per wave and pass
+      if (4 * c4 < a.Nf) {
+        const ActApply act(a.act);
+        float* __restrict__ Yb = a.Y + row0 * a.Nf;
+        float* __restrict__ Pb = a.pre ? a.pre + row0 * a.Nf : nullptr;
+#pragma unroll
+        for (int k = 0; k < FBM / 16; ++k) {
+          const int rr = 16 * k + 2 * wave + (lane_s >> 5);
+          if (rr < n_tile_rows) {
+            float4 v = *reinterpret_cast<const float4*>(&yt[rr * BX_YPITCH + 4 * c4]);
+            if (TMGCN_DEV_SKIP & 4) continue;
+            if (Pb) store_f4(reinterpret_cast<float4*>(&Pb[rr * a.Nf + 4 * c4]), v);
+            if (a.act != TMGCN_ACT_NONE) v = make_float4(act(v.x), act(v.y), act(v.z), act(v.w));
+            store_f4(reinterpret_cast<float4*>(&Yb[rr * a.Nf + 4 * c4]), v);
+          }
+        }
+      }
     }
-    __builtin_amdgcn_s_setprio(0);
-    __syncthreads();      // the planes are consumed before the next tile's rows overwrite them
+    __syncthreads();      // the planes (or the Y tile in their place) are consumed before the next tile's rows overwrite them
   }
 }
 
