@@ -70,6 +70,9 @@ struct FusedArgs {
 #ifndef TMGCN_BX_STAGED_Y
 #define TMGCN_BX_STAGED_Y 1      // the bf16-product kernel's Y tile leaves through LDS as whole rows (0: 64-byte pieces from the accumulators)
 #endif
+#ifndef TMGCN_BX_DRAW_AHEAD
+#define TMGCN_BX_DRAW_AHEAD 1
+#endif
 #ifndef TMGCN_BX3_MAX_DEG
 #define TMGCN_BX3_MAX_DEG 14     // launches with fewer entries per row (the caller's hint) take the bf16-product kernel (measured: -9 % at 4, -6 % at 8, -4 % at 12, 0 at 16)
 #endif
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
   const bool staged = TMGCN_BX_STAGED_Y && a.Nf % 4 == 0 && reinterpret_cast<uintptr_t>(a.Y) % 16 == 0 && reinterpret_cast<uintptr_t>(a.pre) % 16 == 0;
   HeavyScan heavy;                                                         // the heaviest tiles first, as in the tile kernel
   heavy.init(a.rowptr, tm);
+  bool have_next = false;                                                  // s_tile holds the main loop's next tile
   for (;;) {
     int lane = lane0;                                                      // laundered per tile (see the tile kernel)
     asm volatile("" : "+v"(lane));
@@ -401,9 +405,12 @@ __global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
     if (heavy.scanning) tile = heavy.next(a.rowptr, tm, a.tile_counter + 1, &s_tile, lane);
     const bool scanning = heavy.scanning;
     if (!scanning) {
-      if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter, 1u);
-      __syncthreads();
+      if (!have_next) {                                                    // (else: drawn under the products of the tile before)
+        if (threadIdx.x == 0) s_tile = atomicAdd(a.tile_counter, 1u);
+        __syncthreads();
+      }
       tile = s_tile;
+      have_next = false;
       if (tile >= a.n_tiles) break;
     }
     int64_t unit, row0, row_end;
@@ -476,6 +483,9 @@ __global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) s_row = 8;
+    // the main loop's next tile is drawn now, under the products (one barrier and the draw's round trip less per tile)
+    unsigned int drawn = 0;
+    if (TMGCN_BX_DRAW_AHEAD && !scanning && threadIdx.x == 0) drawn = atomicAdd(a.tile_counter, 1u);
     // ---- products: 4 row blocks of 16 x this wave's 16 columns; per (row block, k-step) six plane products, small terms first
     __builtin_amdgcn_s_setprio(TMGCN_FUSED_MFMA_PRIO);
     int lane_p = lane0;
@@ -560,6 +570,10 @@ __global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
           }
         }
       }
+    }
+    if (TMGCN_BX_DRAW_AHEAD && !scanning) {
+      if (threadIdx.x == 0) s_tile = drawn;                                // (everybody read the current tile's number before the barrier behind the gather)
+      have_next = true;
     }
     __syncthreads();      // the planes (or the Y tile in their place) are consumed before the next tile's rows overwrite them
   }
