@@ -808,12 +808,12 @@ def measure_traffic(args, what="headline", **over):
                 return None, f"the {counter} pass exited {r.returncode}: {(r.stderr or '')[-300:]}"
             got[counter] = pmc_traffic.read_pass(d, counter)
     fused = lambda k: "spmm_gemm_kernel" in k or "spmm_gemm_bx3_kernel" in k     # (few entries per row: the bf16-product kernel)
-    fused_f = [v for k, v in got["FETCH_SIZE"].items() if fused(k)]
-    fused_w = [v for k, v in got["WRITE_SIZE"].items() if fused(k)]
     band_f = [v for k, v in got["FETCH_SIZE"].items() if "mtransform_band_kernel" in k]
-    if not fused_f or not fused_w:
+    # (fetch, write) per dispatch, kernel by kernel: the two launches of a step may be different kernels (a plan for the giant
+    # rows of A but none for those of its transpose), and each pass lists a kernel's dispatches in order
+    pairs = [q for k, v in got["FETCH_SIZE"].items() if fused(k) and k in got["WRITE_SIZE"] for q in zip(v, got["WRITE_SIZE"][k])]
+    if not pairs:
         return None, "no spmm_gemm_kernel / spmm_gemm_bx3_kernel dispatch in the counter output"
-    pairs = list(zip(fused_f[0], fused_w[0]))                       # dispatches alternate forward / backward
     fwd = max(pairs, key=lambda q: q[1])                            # forward also stores AX and Y
     bwd = min(pairs, key=lambda q: q[1])
     # calibration: the band M-transform reads one [T,N,F] fp32 tensor exactly once (chess_tiled rounds N by < 0.03 %)

@@ -74,7 +74,7 @@ struct FusedArgs {
 #define TMGCN_BX_DRAW_AHEAD 1
 #endif
 #ifndef TMGCN_BX3_MAX_DEG
-#define TMGCN_BX3_MAX_DEG 14     // launches with fewer entries per row (the caller's hint) take the bf16-product kernel (measured: -9 % at 4, -6 % at 8, -4 % at 12, 0 at 16)
+#define TMGCN_BX3_MAX_DEG 14     // launches with fewer entries per row (the caller's hint) take the bf16-product kernel (measured against the tile kernel: -9 % at 4, -6 % at 8, -4 % at 12; at 33 = S4 it would be 2 % faster too, but the adjoint identity at S4 size then holds to 4-7e-5 instead of 1e-5: the headline stays on the exact-f32 chain; profiles/r6/r6_44_*, r6_73_*, r6_74_*)
 #endif
 #ifndef TMGCN_FUSED_MFMA_PRIO
 #define TMGCN_FUSED_MFMA_PRIO 3
