@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
 // the plain kernel's); a row's sum is split when it is flushed and written as three bf16 plane images [64][272 B] (gemm.hip's
 // conflict-free pitch); then each wave multiplies the tile by ITS 16-column strip of Wop, whose planes it holds in 12·K/32
 // registers (48 at K = 128 — fewer than the 64 f32 fragments of the tile kernel, which is what lets eight waves fit).
+// The Y tile does not leave from the accumulators (a wave owns 16 columns: 64-byte pieces of every row) but through LDS, the planes'
+// memory, as whole rows — see the epilogue; the main loop's next tile is drawn while the products run.
+// Measured and not kept for this regime: a 16-wave ring kernel, gather waves and product waves decoupled through 16-row LDS slots
+// (profiles/r6/r6_66_low_degree_ring_kernel_not_kept.patch): bit-equal, never faster — the gather runs at the plain SpMM's rate
+// either way, the rest is products, barriers and stores.
 typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bx_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float bx_f32x2 __attribute__((ext_vector_type(2)));
