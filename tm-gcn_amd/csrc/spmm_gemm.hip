@@ -74,7 +74,7 @@ struct FusedArgs {
 #define TMGCN_BX_DRAW_AHEAD 1
 #endif
 #ifndef TMGCN_BX3_MAX_DEG
-#define TMGCN_BX3_MAX_DEG 14     // launches with fewer entries per row (the caller's hint) take the bf16-product kernel (measured against the tile kernel: -9 % at 4, -6 % at 8, -4 % at 12; at 33 = S4 it would be 2 % faster too, but the adjoint identity at S4 size then holds to 4-7e-5 instead of 1e-5: the headline stays on the exact-f32 chain; profiles/r6/r6_44_*, r6_73_*, r6_74_*)
+#define TMGCN_BX3_MAX_DEG 14     // launches with fewer entries per row (the caller's hint) take the bf16-product kernel (measured against the tile kernel: -9 % at 4, -6 % at 8, -4 % at 12; at 33 = S4 it would be 2 % faster too, but the adjoint identity at S4 size then holds to 4-7e-5 instead of 1e-5: the headline stays on the exact-f32 chain; profiles/r6/r6_44_*, not_kept/r6_73_*, not_kept/r6_74_*)
 #endif
 #ifndef TMGCN_FUSED_MFMA_PRIO
 #define TMGCN_FUSED_MFMA_PRIO 3
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, TMGCN_FUSED_OCC) void spmm_gemm_kernel(FusedAr
 // The Y tile does not leave from the accumulators (a wave owns 16 columns: 64-byte pieces of every row) but through LDS, the planes'
 // memory, as whole rows — see the epilogue; the main loop's next tile is drawn while the products run.
 // Measured and not kept for this regime: a 16-wave ring kernel, gather waves and product waves decoupled through 16-row LDS slots
-// (profiles/r6/r6_66_low_degree_ring_kernel_not_kept.patch): bit-equal, never faster — the gather runs at the plain SpMM's rate
+// (profiles/r6/not_kept/r6_66_low_degree_ring_kernel_not_kept.patch): bit-equal, never faster — the gather runs at the plain SpMM's rate
 // either way, the rest is products, barriers and stores.
 typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bx_bf16x2 __attribute__((ext_vector_type(2)));
