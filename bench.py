@@ -1036,7 +1036,9 @@ def worker(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S4 TM-GCN layer fwd+bwd: {Tl} slices/GPU (T={res['T']}), N={N}, "
-                                   f"deg={args.deg}+self{'' if args.graph == 'er' else ' on average (' + args.graph + ' row lengths)'}, "
+                                   + (f"{res['total_nnz'] / (world * Tl * N):.2f} entries per row (the chess operand's own row lengths), "
+                                      if args.graph == "chess_tiled" else
+                                      f"deg={args.deg}+self{'' if args.graph == 'er' else ' on average (' + args.graph + ' row lengths)'}, ") +
                                    f"F={F}->{F}, band-M b={args.band}, fp32",
                        "exchange": args.exchange if res["collective"] else "none", "grid_reserve": res["grid_reserve"],
                        "cu_reserve": res["cu_reserve"],
