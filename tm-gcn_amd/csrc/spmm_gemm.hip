@@ -525,7 +525,29 @@ __global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
     }
     __builtin_amdgcn_s_setprio(0);
     // epilogue: accumulator i of block rb is row 16 rb + 4 lg + i, column n0 + lm
-    if (!staged) {                                                       // (an output that is not a whole number of aligned float4 per row)
+    if (TMGCN_BX_STAGED_Y == 2 && staged) {
+      // development (measured: the same time as the dword stores, profiles/r6/r6_82_*): no LDS, no barrier — the 4 x 4 blocks
+      // transposed on the lane quads (common.h), 16 bytes per lane: a quarter of the store instructions, every row still leaving as
+      // 64-byte pieces.  It is the pieces that cost, not the instruction count.
+      const int j = lm & 3, cq = n0 + 4 * (lm >> 2);
+      if (cq < a.Nf) {
+        const ActApply act(a.act);
+        float* __restrict__ Yb = a.Y + row0 * a.Nf;
+        float* __restrict__ Pb = a.pre ? a.pre + row0 * a.Nf : nullptr;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          float v[4] = {acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]};
+          quad_transpose4(v, j);
+          const int rr = 16 * rb + 4 * lg + j;
+          if (rr < n_tile_rows) {
+            float4 q = make_float4(v[0], v[1], v[2], v[3]);
+            if (Pb) store_f4(reinterpret_cast<float4*>(&Pb[rr * a.Nf + cq]), q);
+            if (a.act != TMGCN_ACT_NONE) q = make_float4(act(q.x), act(q.y), act(q.z), act(q.w));
+            store_f4(reinterpret_cast<float4*>(&Yb[rr * a.Nf + cq]), q);
+          }
+        }
+      }
+    } else if (!staged) {                                                // (an output that is not a whole number of aligned float4 per row)
       const int n = n0 + lm;
       if (n < a.Nf) {
         const ActApply act(a.act);
@@ -546,7 +568,7 @@ __global__ __launch_bounds__(512, 4) void spmm_gemm_bx3_kernel(FusedArgs a) {
       // A wave owns 16 columns: stored from the accumulators, every row of Y is written as eight 64-byte pieces, a dword per lane
       // (the tile kernel's 32-column strips write whole 128-byte lines).  Handed over through LDS — the planes' memory, free once
       // every wave has read it — the tile is stored row by row, 16 bytes per lane: whole lines, a quarter of the store
-      // instructions.  Two more barriers per tile, and still 6 % off the launch (chess operand 13.76 -> 12.92 ms; profiles/r6/r6_70_*).
+      // instructions.  Two more barriers per tile, and still 6-7 % off the launch (chess operand 13.76 -> 12.92 ms; profiles/r6/r6_70_*, r6_82_*).
       __syncthreads();                                                   // every wave is through with the planes
       float* yt = reinterpret_cast<float*>(sm);
       if (n0 < a.Nf) {
