@@ -84,6 +84,10 @@ LONG_ROW_CASES = {
     "hubs": (2, 100_003, {(0, 17): 100_000, (0, 18): 10_000, (0, 4000): 300, (1, 100_002): 100_000, (1, 50_000): 65_536,
                           (1, 50_001): 9_000, (1, 0): 20_000, (0, 99_968): 12_345}),
     "one heavy tile of two": (1, 100, {(0, 70): 20_000}),
+    # 4 entries per row on average, no giant row: the fused launch takes the bf16-product kernel (csrc/spmm_gemm.hip
+    # spmm_gemm_bx3_kernel) — its heavy tiles first, then the main loop with the next tile drawn under the products, long rows on
+    # four of its eight waves
+    "heavy tiles among short rows": (2, 20_000, {(0, 70): 20_000, (0, 71): 9_000, (1, 19_999): 12_000, (1, 5): 300, (1, 6): 0}),
 }
 
 
