@@ -756,11 +756,13 @@ extern "C" int tmgcn_spmm_gemm_f32_plan(const int64_t* rowptr, const int32_t* co
   // few entries per row (the caller's hint), no giant-row plan, K = 64 or 128: the products on the bf16 matrix cores
   if (avg_nnz_per_row >= 0.f && avg_nnz_per_row < (float)TMGCN_BX3_MAX_DEG && n_giant == 0 && (K == 128 || K == 64)) {
     if (K == 128) {
-      int64_t gx = persistent_grid(spmm_gemm_bx3_kernel<32, TMGCN_FUSED_U, 4, TMGCN_BX3_US>, 512, 0, 2);
+      int64_t gx = persistent_grid(spmm_gemm_bx3_kernel<32, TMGCN_FUSED_U, 4, TMGCN_BX3_US>, 512, 0, 2) - grid_reserve / 2;   // (a block of this kernel fills two of the tile kernel's slots)
+      if (gx < 64) gx = 64;
       if (gx > a.n_tiles) gx = a.n_tiles;
       hipLaunchKernelGGL((spmm_gemm_bx3_kernel<32, TMGCN_FUSED_U, 4, TMGCN_BX3_US>), dim3((unsigned)gx), dim3(512), 0, st, a);
     } else {
-      int64_t gx = persistent_grid(spmm_gemm_bx3_kernel<16, TMGCN_FUSED_U, 2, TMGCN_BX3_US>, 512, 0, 2);
+      int64_t gx = persistent_grid(spmm_gemm_bx3_kernel<16, TMGCN_FUSED_U, 2, TMGCN_BX3_US>, 512, 0, 2) - grid_reserve / 2;
+      if (gx < 64) gx = 64;
       if (gx > a.n_tiles) gx = a.n_tiles;
       hipLaunchKernelGGL((spmm_gemm_bx3_kernel<16, TMGCN_FUSED_U, 2, TMGCN_BX3_US>), dim3((unsigned)gx), dim3(512), 0, st, a);
     }
